@@ -1,0 +1,318 @@
+"""TEST INFRASTRUCTURE -- container-only: validate the oracle against the imported reference and
+write the golden fixtures under tests/golden/.
+
+Run:  python -m oracle.make_golden            (from /root/repo; needs /root/reference)
+
+What it does
+  1. imports the real reference (oracle/ref_import.py), builds its modules with a deterministic
+     RandomState fill (oracle/fill.py), dropout = 0;
+  2. runs reference forward/backward and the oracle restatement on the same tensors and asserts
+     agreement (fp64: <= 1e-10 rel-L2, fp32: <= 2e-5);
+  3. saves inputs, expected outputs and expected gradients as .npz (tiny configs: full tensors;
+     full-size K64 config: per-tensor L2 norms + 2048 sampled elements).
+
+Fixtures are data only (arrays + JSON strings); no reference source or pickled reference objects.
+"""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+warnings.filterwarnings("ignore")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import fill, vptr_oracle as O  # noqa: E402
+from oracle.ref_import import import_reference  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def template_of(sd):
+    return [(k, list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in sd.items()]
+
+
+def np_sd(d):
+    return {k: v.detach().cpu().numpy() for k, v in d.items()}
+
+
+def build_nar(ref, cfg, seed, far=False):
+    if far:
+        m = ref.VPTRFormerFAR(cfg["Tp"], cfg["Tf"], cfg["H"], cfg["W"], cfg["C"], cfg["nhead"],
+                              cfg["num_encoder_layers"], 0.0, cfg["window_size"], 4, cfg["rpe"])
+    else:
+        m = ref.VPTRFormerNAR(cfg["Tp"], cfg["Tf"], cfg["H"], cfg["W"], cfg["C"], cfg["nhead"],
+                              cfg["num_encoder_layers"], cfg["num_decoder_layers"], 0.0, cfg["window_size"], 4,
+                              False, cfg["rpe"])
+    fill.apply_fill(m, seed)
+    return m
+
+
+def transformer_case(ref, name, cfg, far, N, seed, full=True, check64=True):
+    torch.manual_seed(0)
+    m = build_nar(ref, cfg, seed, far)
+    Tin = cfg.get("Tin", cfg["Tp"])
+    Tout = Tin if far else cfg["Tf"]
+    x = fill.rand_normal((N, Tin, cfg["C"], cfg["H"], cfg["W"]), seed + 1).abs()  # encoder output is post-ReLU
+    g = fill.rand_normal((N, Tout, cfg["C"], cfg["H"], cfg["W"]), seed + 2)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+
+    # ---- reference: train-mode fwd/bwd (dropout 0 => deterministic; BN uses batch statistics)
+    m.train()
+    xr = x.clone().requires_grad_(True)
+    out_r = m(xr)
+    (out_r * g).sum().backward()
+    grads_r = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    sd_after = {k: v.clone() for k, v in m.state_dict().items()}
+    # ---- reference: eval-mode fwd from the ORIGINAL state
+    m.load_state_dict(sd0)
+    m.eval()
+    with torch.no_grad():
+        out_eval_r = m(x)
+
+    # ---- oracle on the same state
+    fwd = O.far_forward if far else O.nar_forward
+    P = {k: v.clone() for k, v in sd0.items()}
+    leaves = {}
+    for k, _ in m.named_parameters():
+        P[k] = P[k].clone().requires_grad_(True)
+        leaves[k] = P[k]
+    xo = x.clone().requires_grad_(True)
+    out_o = fwd(P, xo, cfg, training=True)
+    (out_o * g).sum().backward()
+    e_out = rel(out_o, out_r)
+    e_dx = rel(xo.grad, xr.grad)
+    e_g = 0.0
+    for k in grads_r:
+        # gradients that are analytically zero (k-bias: softmax shift invariance) are pure round-off: use an
+        # absolute floor tied to the typical gradient scale
+        floor = 1e-2 * float(np.median([float(v.norm()) for v in grads_r.values()]))
+        e = float((leaves[k].grad.double() - grads_r[k].double()).norm() / (grads_r[k].double().norm() + floor))
+        if e > 1e-4:
+            print("   grad mismatch", k, e, float(grads_r[k].norm()))
+        e_g = max(e_g, e)
+    assert all((leaves[k].grad is None) == (k not in grads_r) for k in leaves)
+    P2 = {k: v.clone() for k, v in sd0.items()}
+    with torch.no_grad():
+        out_eval_o = fwd(P2, x, cfg, training=False)
+    e_eval = rel(out_eval_o, out_eval_r)
+    e_bn = 0.0
+    for k in sd_after:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            e_bn = max(e_bn, rel(P[k], sd_after[k]))
+    print(f"[{name}] fp32 oracle-vs-ref: out {e_out:.2e} dx {e_dx:.2e} dparam(max) {e_g:.2e} eval {e_eval:.2e} bn {e_bn:.2e}")
+    assert max(e_out, e_dx, e_eval, e_bn) < 2e-5 and e_g < 2e-4, name
+
+    if check64:
+        m64 = build_nar(ref, cfg, seed, far).double().train()
+        o64 = m64(x.double())
+        P64 = {k: v.double() for k, v in sd0.items()}
+        oo64 = fwd(P64, x.double(), cfg, training=True)
+        e64 = rel(oo64, o64)
+        print(f"[{name}] fp64 oracle-vs-ref: out {e64:.2e}")
+        assert e64 < 1e-10, name
+
+    save = {"cfg": json.dumps(cfg), "far": np.array(int(far)), "seed": np.array(seed), "N": np.array(N),
+            "template": json.dumps(template_of(sd0))}
+    if full:
+        save.update({"x": x.numpy(), "g": g.numpy(), "out_train": out_r.detach().numpy(), "out_eval": out_eval_r.numpy(),
+                     "dx": xr.grad.numpy()})
+        for k, v in grads_r.items():
+            save["grad:" + k] = v.numpy()
+        for k, v in sd_after.items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                save["bn_after:" + k] = v.numpy()
+        for k in ("temporal_pos", "lw_pos", "Tlw_pos"):
+            if k in sd0:
+                save["buf:" + k] = sd0[k].numpy()
+    else:
+        n, s = fill.digest(out_r)
+        save["out_train_norm"], save["out_train_samples"] = np.array(n), s
+        n, s = fill.digest(out_eval_r)
+        save["out_eval_norm"], save["out_eval_samples"] = np.array(n), s
+        n, s = fill.digest(xr.grad)
+        save["dx_norm"], save["dx_samples"] = np.array(n), s
+        gn = {}
+        for k, v in grads_r.items():
+            n, s = fill.digest(v, count=256)
+            gn[k] = n
+            save["gsamp:" + k] = s
+        save["grad_norms"] = json.dumps(gn)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
+
+
+def ae_case(ref, name, img_ch, feat, HW, N, T, padding_type, out_layer, seed):
+    enc = ref.VPTREnc(img_ch, feat_dim=feat, n_downsampling=3, padding_type=padding_type)
+    dec = ref.VPTRDec(img_ch, feat_dim=feat, n_downsampling=3, out_layer=out_layer, padding_type=padding_type)
+    fill.apply_fill(enc, seed)
+    fill.apply_fill(dec, seed + 10)
+    enc.eval(), dec.eval()
+    x = fill.rand_input((N, T, img_ch, HW, HW), seed + 1, -0.25, 0.25)
+    g = fill.rand_normal((N, T, img_ch, HW, HW), seed + 2)
+    with torch.no_grad():
+        f_r = enc(x)
+    fin = f_r.clone().requires_grad_(True)
+    y_r = dec(fin)
+    (y_r * g).sum().backward()
+    dgr = {k: p.grad.clone() for k, p in dec.named_parameters()}
+    Pe, Pd = dict(enc.state_dict()), {k: v.clone() for k, v in dec.state_dict().items()}
+    for k, _ in dec.named_parameters():
+        Pd[k].requires_grad_(True)
+    with torch.no_grad():
+        f_o = O.enc_forward(Pe, x, padding_type=padding_type)
+    fo_in = f_r.clone().requires_grad_(True)
+    y_o = O.dec_forward(Pd, fo_in, out_layer=out_layer)
+    (y_o * g).sum().backward()
+    e = [rel(f_o, f_r), rel(y_o, y_r), rel(fo_in.grad, fin.grad), max(rel(Pd[k].grad, dgr[k]) for k in dgr)]
+    print(f"[{name}] fp32 oracle-vs-ref: enc {e[0]:.2e} dec {e[1]:.2e} dfeat {e[2]:.2e} dparam {e[3]:.2e}")
+    assert max(e) < 2e-5, name
+    # train-mode (stage-1) forward for completeness
+    enc.train(), dec.train()
+    sd_e0, sd_d0 = {k: v.clone() for k, v in enc.state_dict().items()}, {k: v.clone() for k, v in dec.state_dict().items()}
+    with torch.no_grad():
+        y_tr = dec(enc(x))
+    Pe2, Pd2 = {k: v.clone() for k, v in sd_e0.items()}, {k: v.clone() for k, v in sd_d0.items()}
+    with torch.no_grad():
+        y_tr_o = O.dec_forward(Pd2, O.enc_forward(Pe2, x, padding_type=padding_type, training=True), out_layer=out_layer,
+                               training=True)
+    print(f"[{name}] train-mode AE fwd: {rel(y_tr_o, y_tr):.2e}")
+    assert rel(y_tr_o, y_tr) < 2e-5
+    save = {"meta": json.dumps(dict(img_ch=img_ch, feat=feat, HW=HW, N=N, T=T, padding_type=padding_type,
+                                    out_layer=out_layer, seed=seed)),
+            "enc_template": json.dumps(template_of(sd_e0)), "dec_template": json.dumps(template_of(sd_d0)),
+            "x": x.numpy(), "g": g.numpy(), "feat": f_r.numpy(), "y": y_r.detach().numpy(), "dfeat": fin.grad.numpy(),
+            "y_train": y_tr.numpy()}
+    for k, v in dgr.items():
+        save["dgrad:" + k] = v.numpy()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
+
+
+def losses_case(ref, name, seed):
+    N, T, C, h, w = 2, 3, 24, 8, 8
+    gt = fill.rand_normal((N, T, 1, 64, 64), seed)
+    pr = fill.rand_normal((N, T, 1, 64, 64), seed + 1).requires_grad_(True)
+    gf = fill.rand_normal((N, T, C, h, w), seed + 2)
+    pf = fill.rand_normal((N, T, C, h, w), seed + 3).requires_grad_(True)
+    mse, gdl, nce = ref.MSELoss(), ref.GDL(alpha=1), ref.BiPatchNCE(N, T, h, w, 1.0)
+    l = gdl(gt, pr) + mse(pr, gt) + 0.1 * nce(F.normalize(gf, p=2.0, dim=2), F.normalize(pf, p=2.0, dim=2))
+    l.backward()
+    pr2, pf2 = pr.detach().clone().requires_grad_(True), pf.detach().clone().requires_grad_(True)
+    l2 = O.gdl_loss(gt, pr2) + O.mse_loss(pr2, gt) + 0.1 * O.bipatch_nce(F.normalize(gf, p=2.0, dim=2),
+                                                                        F.normalize(pf2, p=2.0, dim=2))
+    l2.backward()
+    e = [abs(l.item() - l2.item()) / abs(l.item()), rel(pr2.grad, pr.grad), rel(pf2.grad, pf.grad)]
+    print(f"[{name}] losses: {e}")
+    assert max(e) < 1e-5
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), gt=gt.numpy(), pr=pr.detach().numpy(), gf=gf.numpy(),
+                        pf=pf.detach().numpy(), loss=np.array(l.item()), dpr=pr.grad.numpy(), dpf=pf.grad.numpy(),
+                        mse=np.array(mse(pr, gt).item()), gdl=np.array(gdl(gt, pr).item()),
+                        nce=np.array(nce(F.normalize(gf, p=2.0, dim=2), F.normalize(pf, p=2.0, dim=2)).item()))
+
+
+def step_case(ref, name, cfg, feat, HW, N, seed, steps=2):
+    """single_iter recipe of train_NAR.py:49-107 with the real reference modules, dropout 0, no GAN."""
+    enc = ref.VPTREnc(1, feat_dim=feat, n_downsampling=3, padding_type="reflect").eval()
+    dec = ref.VPTRDec(1, feat_dim=feat, n_downsampling=3, out_layer="Tanh", padding_type="reflect").eval()
+    T = build_nar(ref, cfg, seed + 20)
+    fill.apply_fill(enc, seed)
+    fill.apply_fill(dec, seed + 10)
+    opt = torch.optim.AdamW(T.parameters(), lr=1e-4)
+    mse, gdl = ref.MSELoss(), ref.GDL(alpha=1)
+    nce = ref.BiPatchNCE(N, cfg["Tf"], cfg["H"], cfg["W"], 1.0)
+    st = O.NARStep(dict(enc.state_dict()), dict(dec.state_dict()), dict(T.state_dict()), cfg)
+    recs = []
+    for s in range(steps):
+        past = (fill.rand_input((N, cfg["Tp"], 1, HW, HW), seed + 100 + s) - 0.6013795) / 2.7570653
+        fut = (fill.rand_input((N, cfg["Tf"], 1, HW, HW), seed + 200 + s) - 0.6013795) / 2.7570653
+        with torch.no_grad():
+            pf, ff = enc(past), enc(fut)
+        T.train()
+        T.zero_grad(set_to_none=True)
+        dec.zero_grad(set_to_none=True)
+        pred_f = T(pf)
+        pred = dec(pred_f)
+        a = T.NCE_projector(pred_f.permute(0, 1, 3, 4, 2)).permute(0, 1, 4, 2, 3)
+        b = T.NCE_projector(ff.permute(0, 1, 3, 4, 2)).permute(0, 1, 4, 2, 3)
+        l_mse, l_gdl = mse(pred, fut), gdl(fut, pred)
+        l_pc = nce(F.normalize(b, p=2.0, dim=2), F.normalize(a, p=2.0, dim=2))
+        loss = l_gdl + l_mse + 0.1 * l_pc
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(T.parameters(), max_norm=1.0, norm_type=2)
+        opt.step()
+        r = st.step(past, fut)
+        rec = {"T_total": loss.item(), "T_GDL": l_gdl.item(), "T_MSE": l_mse.item(), "T_bpc": l_pc.item(),
+               "grad_norm": float(gn)}
+        for k in rec:
+            assert abs(rec[k] - r[k]) <= 2e-4 * abs(rec[k]) + 1e-7, (k, rec[k], r[k])
+        recs.append(rec)
+    e = max(rel(st.P_T[k], v) for k, v in T.state_dict().items() if v.is_floating_point())
+    print(f"[{name}] {steps} train steps: losses {recs}; post-step params oracle-vs-ref {e:.2e}")
+    assert e < 1e-4
+    save = {"cfg": json.dumps(cfg), "meta": json.dumps(dict(feat=feat, HW=HW, N=N, seed=seed, steps=steps)),
+            "records": json.dumps(recs), "T_template": json.dumps(template_of(T.state_dict())),
+            "enc_template": json.dumps(template_of(enc.state_dict())),
+            "dec_template": json.dumps(template_of(dec.state_dict()))}
+    for k, v in T.state_dict().items():
+        if v.is_floating_point() and k not in ("temporal_pos", "lw_pos", "Tlw_pos"):
+            save["post:" + k] = v.numpy()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
+
+
+def pos_case(ref, name):
+    from utils.position_encoding import PositionEmbeddding1D, PositionEmbeddding2D, PositionEmbeddding3D
+    from utils.misc import NestedTensor
+    save = {}
+    for (T, E, ws) in [(6, 96, 4), (20, 528, 4), (50, 528, 8)]:
+        t1 = PositionEmbeddding1D()(L=T, N=1, E=E)[:, 0, :]
+        t2 = PositionEmbeddding2D()(N=1, E=E, H=ws, W=ws)[0].permute(1, 2, 0)
+        t3 = PositionEmbeddding3D(E=E, T=T)(NestedTensor(torch.empty(T, E, ws, ws), None))[0].permute(1, 2, 3, 0)
+        assert rel(O.pos1d(T, E), t1) < 1e-6 and rel(O.pos2d(E, ws, ws), t2) < 1e-6 and rel(O.pos3d(E, T, ws, ws), t3) < 1e-6
+        tag = f"{T}_{E}_{ws}"
+        save["p1:" + tag], save["p2:" + tag] = t1.numpy(), t2.numpy()
+        if E == 96:
+            save["p3:" + tag] = t3.numpy()
+        else:
+            n, s = fill.digest(t3)
+            save["p3n:" + tag], save["p3s:" + tag] = np.array(n), s
+    from model.MultiHeadAttentionRPE import MultiheadAttentionRPE
+    for ws in (4, 8):
+        idx = MultiheadAttentionRPE(16, 2, rpe=True, window_size=ws).relative_position_index
+        assert torch.equal(idx, O.rpe_index(ws))
+        save[f"rpe_index:{ws}"] = idx.numpy()
+    print(f"[{name}] position tables + RPE index match")
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    ref = import_reference()
+    torch.set_num_threads(8)
+    pos_case(ref, "pos_tables")
+    tiny = dict(Tp=3, Tf=3, H=8, W=8, C=48, nhead=8, window_size=4, num_encoder_layers=1, num_decoder_layers=1, rpe=True)
+    transformer_case(ref, "nar_tiny", tiny, False, 2, 11)
+    transformer_case(ref, "nar_tiny_norpe", dict(tiny, rpe=False), False, 2, 12)
+    transformer_case(ref, "far_tiny", dict(tiny, Tin=5, num_encoder_layers=2), True, 2, 13)
+    transformer_case(ref, "nar_tiny_pad", dict(tiny, H=6, W=6, Tp=2, Tf=2), False, 1, 14)
+    transformer_case(ref, "nar_tiny_T", dict(tiny, Tp=2, Tf=4, num_decoder_layers=2), False, 1, 15)
+    ae_case(ref, "ae_tiny_reflect", 1, 48, 32, 1, 2, "reflect", "Tanh", 21)
+    ae_case(ref, "ae_tiny_zero", 3, 48, 32, 1, 2, "zero", "Sigmoid", 22)
+    losses_case(ref, "losses_tiny", 31)
+    step_case(ref, "step_tiny", dict(tiny, Tp=2, Tf=2), 48, 64, 2, 41)
+    k64 = dict(Tp=10, Tf=10, H=8, W=8, C=528, nhead=8, window_size=4, num_encoder_layers=4, num_decoder_layers=8, rpe=True)
+    transformer_case(ref, "nar_k64_digest", k64, False, 1, 51, full=False, check64=False)
+    far = dict(Tp=2, Tf=10, Tin=11, H=8, W=8, C=528, nhead=8, window_size=4, num_encoder_layers=12, rpe=True)
+    transformer_case(ref, "far_bair_digest", far, True, 1, 52, full=False, check64=False)
+    print("all golden fixtures written to", GOLD)
+
+
+if __name__ == "__main__":
+    main()

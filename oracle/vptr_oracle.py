@@ -1,0 +1,447 @@
+"""TEST INFRASTRUCTURE -- CPU oracle for the VPTR hot path (not product code).
+
+A functional, state_dict-driven restatement of the reference algorithm
+(XiYe20/VPTR) written with plain torch CPU ops.  Only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import
+this file; the product path (`vptr_amd/`) never does, and fails loudly when the
+HIP library is missing.
+
+Parity pin: the reference has no tests or golden vectors of its own
+(SURVEY.md section 4).  This restatement is pinned against the *imported
+reference itself* (run in the build container, see `oracle/make_golden.py`)
+and against the fixtures under `tests/golden/` that the same script generated.
+`tests/test_oracle_golden.py` re-checks the pin on every CPU test run.
+
+Every function cites the reference file:line it follows (paths relative to
+the reference repo root).  Dropout / DropPath are identity here: the reference
+RNG stream is not reproducible across implementations, so parity is defined at
+dropout = 0.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------
+# position tables  (utils/position_encoding.py:29-49, 67-93, 117-161)
+# ----------------------------------------------------------------------------
+
+
+def _sincos(pos, E):
+    """pos: (...,) float positions starting at 1; returns (..., E) interleaved sin/cos."""
+    i = torch.arange(E, dtype=torch.float32)
+    dim_t = 10000.0 ** (2 * torch.div(i, 2, rounding_mode="floor") / E)
+    ang = pos[..., None] / dim_t
+    out = torch.empty_like(ang)
+    out[..., 0::2] = ang[..., 0::2].sin()
+    out[..., 1::2] = ang[..., 1::2].cos()
+    return out
+
+
+def pos1d(L, E):
+    """temporal_pos (L, E): utils/position_encoding.py:29-49, used VPTR_modules.py:118-121."""
+    return _sincos(torch.arange(1, L + 1, dtype=torch.float32), E)
+
+
+def pos2d(E, H, W):
+    """lw_pos (H, W, E): cat(y-half, x-half); utils/position_encoding.py:67-93, VPTR_modules.py:123-125."""
+    y = torch.arange(1, H + 1, dtype=torch.float32)[:, None].expand(H, W)
+    x = torch.arange(1, W + 1, dtype=torch.float32)[None, :].expand(H, W)
+    return torch.cat([_sincos(y, E // 2), _sincos(x, E // 2)], dim=-1)
+
+
+def pos3d(E, T, H, W):
+    """Tlw_pos (T, H, W, E): cat(t, y, x thirds); utils/position_encoding.py:117-161, VPTR_modules.py:127-129."""
+    t = torch.arange(1, T + 1, dtype=torch.float32)[:, None, None].expand(T, H, W)
+    y = torch.arange(1, H + 1, dtype=torch.float32)[None, :, None].expand(T, H, W)
+    x = torch.arange(1, W + 1, dtype=torch.float32)[None, None, :].expand(T, H, W)
+    return torch.cat([_sincos(t, E // 3), _sincos(y, E // 3), _sincos(x, E // 3)], dim=-1)
+
+
+def rpe_index(ws):
+    """relative_position_index (ws*ws, ws*ws) int64: MultiHeadAttentionRPE.py:373-387."""
+    ys, xs = torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")
+    ys, xs = ys.flatten(), xs.flatten()
+    dy = ys[:, None] - ys[None, :] + ws - 1
+    dx = xs[:, None] - xs[None, :] + ws - 1
+    return dy * (2 * ws - 1) + dx
+
+
+# ----------------------------------------------------------------------------
+# window partition (VidHRFormer_modules.py:497-525, pad 538-561)
+# ----------------------------------------------------------------------------
+
+
+def _pad_amounts(H, W, ws):
+    ph = math.ceil(H / ws) * ws - H
+    pw = math.ceil(W / ws) * ws - W
+    return ph, pw
+
+
+def win_partition(x, ws):
+    """x (B,H,W,C) -> (B*nqh*nqw, ws*ws, C); centre zero pad if needed."""
+    B, H, W, C = x.shape
+    ph, pw = _pad_amounts(H, W, ws)
+    if ph or pw:
+        x = F.pad(x, (0, 0, pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+    Hp, Wp = H + ph, W + pw
+    x = x.reshape(B, Hp // ws, ws, Wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5)
+    return x.reshape(B * (Hp // ws) * (Wp // ws), ws * ws, C)
+
+
+def win_reverse(xw, B, H, W, ws):
+    C = xw.shape[-1]
+    ph, pw = _pad_amounts(H, W, ws)
+    Hp, Wp = H + ph, W + pw
+    x = xw.reshape(B, Hp // ws, Wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+    if ph or pw:
+        x = x[:, ph // 2: ph // 2 + H, pw // 2: pw // 2 + W, :]
+    return x
+
+
+# ----------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------
+
+
+def _heads(x, nh):
+    """(B, L, C) -> (B, nh, L, hd); channel c -> head c // hd  (MultiHeadAttentionRPE.py:586-590)."""
+    B, L, C = x.shape
+    return x.reshape(B, L, nh, C // nh).transpose(1, 2)
+
+
+def _attend(q, k, v, bias=None, causal=False):
+    """q already scaled. q (B,nh,Lq,hd), k/v (B,nh,Lk,hd)."""
+    s = q @ k.transpose(-1, -2)
+    if bias is not None:
+        s = s + bias
+    if causal:
+        Lq, Lk = s.shape[-2:]
+        m = torch.triu(torch.ones(Lq, Lk, dtype=torch.bool), diagonal=1)
+        s = s.masked_fill(m, float("-inf"))
+    p = s.softmax(dim=-1)
+    o = p @ v
+    B, nh, L, hd = o.shape
+    return o.transpose(1, 2).reshape(B, L, nh * hd)
+
+
+def win_attn(P, pre, xqk, xv, ws, nh, rpe, lw_pos=None):
+    """SpatialLocalMultiheadAttention.forward (VidHRFormer_modules.py:321-357).
+
+    xqk, xv: (N,T,H,W,C).  rpe=True -> MultiheadAttentionRPE (separate q/k/v
+    Linears + bias table, MultiHeadAttentionRPE.py:543-545, 629-650);
+    rpe=False -> stock packed-weight MHA with q=k=x+lw_pos.
+    """
+    N, T, H, W, C = xqk.shape
+    hd = C // nh
+    Xq = win_partition(xqk.reshape(N * T, H, W, C), ws)
+    Xv = win_partition(xv.reshape(N * T, H, W, C), ws)
+    a = pre + "attn."
+    if rpe:
+        q = F.linear(Xq, P[a + "q_proj.weight"], P[a + "q_proj.bias"]) * (hd ** -0.5)
+        k = F.linear(Xq, P[a + "k_proj.weight"], P[a + "k_proj.bias"])
+        v = F.linear(Xv, P[a + "v_proj.weight"], P[a + "v_proj.bias"])
+        table = P[a + "relative_position_bias_table"]
+        idx = P[a + "relative_position_index"].reshape(-1).long()
+        bias = table[idx].reshape(ws * ws, ws * ws, nh).permute(2, 0, 1)
+    else:
+        Xq = Xq + lw_pos.reshape(ws * ws, C)
+        Wq, Wk, Wv = P[a + "in_proj_weight"].chunk(3)
+        bq, bk, bv = P[a + "in_proj_bias"].chunk(3)
+        q = F.linear(Xq, Wq, bq) * (hd ** -0.5)
+        k = F.linear(Xq, Wk, bk)
+        v = F.linear(Xv, Wv, bv)
+        bias = None
+    o = _attend(_heads(q, nh), _heads(k, nh), _heads(v, nh), bias)
+    o = F.linear(o, P[a + "out_proj.weight"], P[a + "out_proj.bias"])
+    return win_reverse(o, N * T, H, W, ws).reshape(N, T, H, W, C)
+
+
+def mha(P, pre, qi, ki, vi, nh, causal=False):
+    """stock nn.MultiheadAttention, seq-first (L, B, C) (VidHRFormer_modules.py:49,79-84,185-187,204-205)."""
+    C = qi.shape[-1]
+    hd = C // nh
+    Wq, Wk, Wv = P[pre + "in_proj_weight"].chunk(3)
+    bq, bk, bv = P[pre + "in_proj_bias"].chunk(3)
+    q = F.linear(qi, Wq, bq).transpose(0, 1) * (hd ** -0.5)
+    k = F.linear(ki, Wk, bk).transpose(0, 1)
+    v = F.linear(vi, Wv, bv).transpose(0, 1)
+    o = _attend(_heads(q, nh), _heads(k, nh), _heads(v, nh), None, causal)
+    o = F.linear(o, P[pre + "out_proj.weight"], P[pre + "out_proj.bias"])
+    return o.transpose(0, 1)
+
+
+# ----------------------------------------------------------------------------
+# conv-FFN  (MlpDWBN.forward, VidHRFormer_modules.py:424-442)
+# ----------------------------------------------------------------------------
+
+
+def _ffn_norm(P, pre, y, norm, training, eps=1e-5):
+    if norm == "bn":
+        return F.batch_norm(y, P[pre + "running_mean"], P[pre + "running_var"], P[pre + "weight"], P[pre + "bias"],
+                            training, 0.1, eps)
+    w = P[pre + "weight"]
+    return F.layer_norm(y, tuple(w.shape), w, P[pre + "bias"], eps)
+
+
+def conv_ffn(P, pre, x, norm, training):
+    """x (N,T,H,W,C).  norm 'bn' (NAR encoder blocks) or 'ln' (LayerNorm((ch,H,W)): FAR + all NAR decoder blocks)."""
+    N, T, H, W, C = x.shape
+    y = x.reshape(N * T, H, W, C).permute(0, 3, 1, 2)
+    y = F.conv2d(y, P[pre + "fc1.weight"], P[pre + "fc1.bias"])
+    y = F.gelu(_ffn_norm(P, pre + "norm1.", y, norm, training))
+    y = F.conv2d(y, P[pre + "dw3x3.weight"], P[pre + "dw3x3.bias"], padding=1, groups=y.shape[1])
+    y = F.gelu(_ffn_norm(P, pre + "norm2.", y, norm, training))
+    y = F.conv2d(y, P[pre + "fc2.weight"], P[pre + "fc2.bias"])
+    y = F.gelu(_ffn_norm(P, pre + "norm3.", y, norm, training))
+    return y.permute(0, 2, 3, 1).reshape(N, T, H, W, -1)
+
+
+def _ln(P, pre, x):
+    return F.layer_norm(x, (x.shape[-1],), P[pre + "weight"], P[pre + "bias"], 1e-5)
+
+
+# ----------------------------------------------------------------------------
+# blocks  (VidHRFormer_modules.py:60-93, 164-211)
+# ----------------------------------------------------------------------------
+
+
+def enc_block(P, pre, x, lw_pos, tpos, cfg, far, training):
+    N, T, H, W, C = x.shape
+    nh, ws, rpe = cfg["nhead"], cfg["window_size"], cfg["rpe"]
+    u = _ln(P, pre + "norm1.", x)
+    x = x + win_attn(P, pre + "SLMHSA.", u, u, ws, nh, rpe, lw_pos)
+    x = x + conv_ffn(P, pre + "SpatialFFN.", _ln(P, pre + "norm2.", x), "ln" if far else "bn", training)
+    x = x.permute(1, 0, 2, 3, 4).reshape(T, N * H * W, C)
+    u = _ln(P, pre + "norm3.", x)
+    qk = u + tpos[:, None, :]
+    x = x + mha(P, pre + "temporal_MHSA.", qk, qk, u, nh, causal=far)
+    u = _ln(P, pre + "norm4.", x)
+    x = x + F.linear(F.gelu(F.linear(u, P[pre + "linear1.weight"], P[pre + "linear1.bias"])),
+                     P[pre + "linear2.weight"], P[pre + "linear2.bias"])
+    return x.reshape(T, N, H, W, C).permute(1, 0, 2, 3, 4)
+
+
+def dec_block(P, pre, tgt, qpos, mem, lw_pos, tpos_f, tpos_p, cfg, training):
+    N, T2, H, W, C = tgt.shape
+    T1 = mem.shape[1]
+    nh, ws, rpe = cfg["nhead"], cfg["window_size"], cfg["rpe"]
+    t = _ln(P, pre + "norm1.", tgt)
+    x = tgt + win_attn(P, pre + "SLMHSA.", t + qpos, t, ws, nh, rpe, lw_pos)
+    x = x + conv_ffn(P, pre + "SpatialFFN.", _ln(P, pre + "norm2.", x), "ln", training)
+    x = x.permute(1, 0, 2, 3, 4).reshape(T2, N * H * W, C)
+    u = _ln(P, pre + "norm3.", x)
+    qk = u + tpos_f[:, None, :]
+    x = x + mha(P, pre + "temporal_MHSA.", qk, qk, u, nh)
+    u = _ln(P, pre + "norm4.", x)
+    x = x + F.linear(F.gelu(F.linear(u, P[pre + "linear1.weight"], P[pre + "linear1.bias"])),
+                     P[pre + "linear2.weight"], P[pre + "linear2.bias"])
+    u = _ln(P, pre + "norm5.", x)
+    mem_s = mem.permute(1, 0, 2, 3, 4).reshape(T1, N * H * W, C)
+    qpos_s = qpos.permute(1, 0, 2, 3, 4).reshape(T2, N * H * W, C)
+    x = x + mha(P, pre + "EncDecAttn.", u + qpos_s + tpos_f[:, None, :], mem_s + tpos_p[:, None, :], mem_s, nh)
+    x = x.reshape(T2, N, H, W, C).permute(1, 0, 2, 3, 4)
+    x = x + conv_ffn(P, pre + "SpatialFFN1.", _ln(P, pre + "norm6.", x), "ln", training)
+    return x
+
+
+def nar_forward(P, feat, cfg, training=False):
+    """VPTRFormerNAR.forward (VPTR_modules.py:140-147) -> VidHRFormerNAR.forward (VidHRFormer.py:28-53).
+
+    feat (N,Tp,C,H,W) -> (N,Tf,C,H,W).  cfg keys: Tp, Tf, nhead, window_size,
+    num_encoder_layers, num_decoder_layers, rpe.
+    """
+    Tp = feat.shape[1]
+    x = feat.permute(0, 1, 3, 4, 2)
+    tpos, lw = P["temporal_pos"], P["lw_pos"]
+    for i in range(cfg["num_encoder_layers"]):
+        x = enc_block(P, f"transformer.encoder.layers.{i}.", x, lw, tpos[:Tp], cfg, False, training)
+    mem = _ln(P, "transformer.encoder.norm.", x)
+    N = feat.shape[0]
+    qpos = P["frame_queries"][None].expand(N, -1, -1, -1, -1)
+    out = torch.zeros_like(qpos)
+    for i in range(cfg["num_decoder_layers"]):
+        out = dec_block(P, f"transformer.decoder.layers.{i}.", out, qpos, mem, lw, tpos[Tp:], tpos[:Tp], cfg, training)
+    out = _ln(P, "transformer.decoder.norm.", out)
+    return F.relu(out.permute(0, 1, 4, 2, 3))
+
+
+def far_forward(P, feat, cfg, training=False):
+    """VPTRFormerFAR.forward (VPTR_modules.py:186-192) -> VidHRFormerFAR.forward (VidHRFormer.py:71-88)."""
+    T = feat.shape[1]
+    x = feat.permute(0, 1, 3, 4, 2)
+    for i in range(cfg["num_encoder_layers"]):
+        x = enc_block(P, f"transformer.encoder.layers.{i}.", x, P["lw_pos"], P["temporal_pos"][:T], cfg, True, training)
+    x = _ln(P, "transformer.encoder.norm.", x)
+    return F.relu(x.permute(0, 1, 4, 2, 3))
+
+
+def nce_projector(P, feat):
+    """NCE_projector on channel-last feats (VPTR_modules.py:135-137; train_NAR.py:81-82). feat (N,T,C,H,W)."""
+    x = feat.permute(0, 1, 3, 4, 2)
+    x = F.linear(F.relu(F.linear(x, P["NCE_projector.0.weight"], P["NCE_projector.0.bias"])),
+                 P["NCE_projector.2.weight"], P["NCE_projector.2.bias"])
+    return x.permute(0, 1, 4, 2, 3)
+
+
+# ----------------------------------------------------------------------------
+# ResNet auto-encoder (ResNetAutoEncoder.py:8-51, 53-101, 104-158)
+# ----------------------------------------------------------------------------
+
+
+def _pad(x, p, padding_type):
+    if padding_type == "reflect":
+        return F.pad(x, (p, p, p, p), mode="reflect"), 0
+    if padding_type == "replicate":
+        return F.pad(x, (p, p, p, p), mode="replicate"), 0
+    if padding_type == "zero":
+        return x, p
+    raise NotImplementedError("padding [%s] is not implemented" % padding_type)
+
+
+def _bn(P, pre, x, training):
+    return F.batch_norm(x, P[pre + "running_mean"], P[pre + "running_var"], P[pre + "weight"], P[pre + "bias"],
+                        training, 0.1, 1e-5)
+
+
+def enc_forward(P, x, n_down=3, padding_type="reflect", training=False):
+    """VPTREnc.forward (VPTR_modules.py:16-29). x (N,T,Cimg,H,W) -> (N,T,feat,H/8,W/8)."""
+    N, T = x.shape[:2]
+    y = x.flatten(0, 1)
+    m = "encoder.model."
+    y = F.conv2d(F.pad(y, (3, 3, 3, 3), mode="reflect"), P[m + "1.weight"])
+    y = F.relu(_bn(P, m + "2.", y, training))
+    idx = 4
+    for _ in range(n_down):
+        y = F.conv2d(y, P[m + f"{idx}.weight"], stride=2, padding=1)
+        y = F.relu(_bn(P, m + f"{idx + 1}.", y, training))
+        idx += 3
+    for _ in range(9):
+        b = m + f"{idx}.conv_block."
+        if padding_type == "zero":
+            c1, n1, c2, n2 = 0, 1, 3, 4
+        else:
+            c1, n1, c2, n2 = 1, 2, 5, 6
+        h, p = _pad(y, 1, padding_type)
+        h = F.relu(_bn(P, b + f"{n1}.", F.conv2d(h, P[b + f"{c1}.weight"], padding=p), training))
+        h, p = _pad(h, 1, padding_type)
+        h = _bn(P, b + f"{n2}.", F.conv2d(h, P[b + f"{c2}.weight"], padding=p), training)
+        y = y + h
+        idx += 1
+    y = F.relu(y)
+    return y.reshape(N, T, *y.shape[1:])
+
+
+def dec_forward(P, feat, n_down=3, out_layer="Tanh", training=False):
+    """VPTRDec.forward (VPTR_modules.py:36-47). feat (N,T,C,h,w) -> (N,T,Cimg,8h,8w)."""
+    N, T = feat.shape[:2]
+    y = feat.flatten(0, 1)
+    m = "decoder.model."
+    idx = 0
+    for _ in range(n_down):
+        y = F.conv_transpose2d(y, P[m + f"{idx}.weight"], stride=2, padding=1, output_padding=1)
+        y = F.relu(_bn(P, m + f"{idx + 1}.", y, training))
+        idx += 3
+    y = F.conv2d(F.pad(y, (3, 3, 3, 3), mode="reflect"), P[m + f"{idx + 1}.weight"], P[m + f"{idx + 1}.bias"])
+    if out_layer == "Tanh":
+        y = torch.tanh(y)
+    elif out_layer == "Sigmoid":
+        y = torch.sigmoid(y)
+    else:
+        raise ValueError("Unsupported output layer")
+    return y.reshape(N, T, *y.shape[1:])
+
+
+# ----------------------------------------------------------------------------
+# losses (criterion.py:115-132, 145-204, 227-259)
+# ----------------------------------------------------------------------------
+
+
+def mse_loss(gt, pred):
+    return ((pred - gt) ** 2).mean()
+
+
+def gdl_loss(gt, pred):
+    """alpha = 1, no temporal weight (train_NAR.py:215)."""
+    g, p = gt.flatten(0, -4), pred.flatten(0, -4)
+    t1 = (g[:, :, 1:, :] - g[:, :, :-1, :]).abs()
+    t2 = (p[:, :, 1:, :] - p[:, :, :-1, :]).abs()
+    t3 = (g[:, :, :, :-1] - g[:, :, :, 1:]).abs()
+    t4 = (p[:, :, :, :-1] - p[:, :, :, 1:]).abs()
+    return (t1 - t2).abs().mean() + (t3 - t4).abs().mean()
+
+
+def bipatch_nce(gt_f, pred_f, temperature=1.0):
+    """gt_f/pred_f (N,T,C,h,w), stop-grad on negatives (criterion.py:227-259)."""
+    N, T, C, h, w = gt_f.shape
+    g = gt_f.permute(0, 1, 3, 4, 2).reshape(N * T, h * w, C)
+    p = pred_f.permute(0, 1, 3, 4, 2).reshape(N * T, h * w, C)
+    eye = torch.eye(h * w, dtype=g.dtype)
+    s1 = (g @ p.transpose(1, 2)) * eye + (g @ p.detach().transpose(1, 2)) * (1 - eye)
+    s2 = (p @ g.transpose(1, 2)) * eye + (p @ g.detach().transpose(1, 2)) * (1 - eye)
+    tgt = torch.arange(h * w).repeat(N * T)
+    l1 = F.cross_entropy(s1.flatten(0, 1) / temperature, tgt)
+    l2 = F.cross_entropy(s2.flatten(0, 1) / temperature, tgt)
+    return 0.5 * (l1 + l2)
+
+
+def nar_losses(P_T, pred_frames, future, pred_feats, future_feats, lam_pc=0.1):
+    """cal_lossT without GAN (train_NAR.py:33-47) incl. the NCE projector calls (:81-82)."""
+    pf = nce_projector(P_T, pred_feats)
+    gf = nce_projector(P_T, future_feats)
+    l_mse = mse_loss(pred_frames, future)
+    l_gdl = gdl_loss(future, pred_frames)
+    l_pc = bipatch_nce(F.normalize(gf, p=2.0, dim=2), F.normalize(pf, p=2.0, dim=2))
+    return l_gdl + l_mse + lam_pc * l_pc, l_gdl, l_mse, l_pc
+
+
+# ----------------------------------------------------------------------------
+# the measured step: single_iter (train_NAR.py:49-107), dropout 0
+# ----------------------------------------------------------------------------
+
+
+class NARStep:
+    """Functional NAR train step on plain tensors: 2x Enc (no grad), NAR, Dec, MSE+GDL+0.1*BiPatchNCE,
+    backward, clip_grad_norm_(1.0) on the transformer params, AdamW(1e-4).  State lives in dicts of leaf tensors."""
+
+    def __init__(self, P_enc, P_dec, P_T, cfg, padding_type="reflect", out_layer="Tanh", lr=1e-4, max_grad_norm=1.0,
+                 lam_pc=0.1):
+        self.cfg, self.padding_type, self.out_layer = cfg, padding_type, out_layer
+        self.P_enc = {k: v.detach().clone() for k, v in P_enc.items()}
+        self.P_dec = {k: v.detach().clone() for k, v in P_dec.items()}
+        self.P_T = {k: v.detach().clone() for k, v in P_T.items()}
+        self.buffers_T = {"temporal_pos", "lw_pos", "Tlw_pos"}
+        for k, v in self.P_T.items():
+            if v.is_floating_point() and not self._is_buffer(k):
+                v.requires_grad_(True)
+        for k, v in self.P_dec.items():
+            if v.is_floating_point() and not self._is_buffer(k):
+                v.requires_grad_(True)  # reference leaves Dec params trainable (train_NAR.py:190-191)
+        self.params_T = [v for k, v in self.P_T.items() if v.requires_grad]
+        self.opt = torch.optim.AdamW(self.params_T, lr=lr)
+        self.max_grad_norm, self.lam_pc = max_grad_norm, lam_pc
+
+    def _is_buffer(self, k):
+        return (k in ("temporal_pos", "lw_pos", "Tlw_pos") or k.endswith("running_mean") or k.endswith("running_var")
+                or k.endswith("num_batches_tracked") or k.endswith("relative_position_index"))
+
+    def forward_losses(self, past, future):
+        with torch.no_grad():
+            pf = enc_forward(self.P_enc, past, padding_type=self.padding_type)
+            ff = enc_forward(self.P_enc, future, padding_type=self.padding_type)
+        pred_feats = nar_forward(self.P_T, pf, self.cfg, training=True)
+        pred_frames = dec_forward(self.P_dec, pred_feats, out_layer=self.out_layer)
+        return nar_losses(self.P_T, pred_frames, future, pred_feats, ff, self.lam_pc) + (pred_frames,)
+
+    def step(self, past, future):
+        for p in self.params_T:
+            p.grad = None
+        for v in self.P_dec.values():
+            if v.requires_grad:
+                v.grad = None
+        loss, l_gdl, l_mse, l_pc, _ = self.forward_losses(past, future)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(self.params_T, self.max_grad_norm)
+        self.opt.step()
+        return {"T_total": loss.item(), "T_GDL": l_gdl.item(), "T_MSE": l_mse.item(), "T_bpc": l_pc.item(),
+                "grad_norm": float(gn)}
