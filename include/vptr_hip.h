@@ -1,0 +1,212 @@
+/*
+ * vptr_hip.h -- C ABI of libvptr_hip.so: hand-written HIP kernels (gfx950 / CDNA4) for the VPTR hot path.
+ *
+ * The reference (XiYe20/VPTR) is pure PyTorch and has no FFI layer of its own; its hot path is a
+ * sequence of stock ATen op call sites.  Each entry point below
+ * replaces one group of those call sites and cites them (paths relative to the reference root).
+ * Python host code (vptr_amd/) binds these with ctypes and passes tensor.data_ptr() values and the
+ * current HIP stream; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data unless stated otherwise; the library is
+ *     borrow-only: it never allocates, frees or synchronises; all work is enqueued on `stream`.
+ *   - activations are token-major, channel-last:  x[(n,t,h,w)][c]  ==  (N,T,H,W,C) contiguous.
+ *   - return value: 0 on success, negative on error; vptr_last_error() gives a thread-local message.
+ *   - dropout: p == 0 disables it; otherwise the mask of element i at a call site is
+ *     hash(seed_dev[0], site, i) < keep, with seed_dev a DEVICE pointer to one uint64 (so that a
+ *     captured hipGraph sees a fresh seed at every replay).
+ */
+#ifndef VPTR_HIP_H
+#define VPTR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vptr_stream_t; /* hipStream_t */
+
+int vptr_abi_version(void);
+const char* vptr_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM + fused epilogue on MFMA (bf16 inputs split from fp32 in the staging path, fp32 accumulate).
+ *   D[M,N] = epilogue( op(A)[M,K] * op(B)[K,N] )
+ * Replaces: F.linear / nn.Linear (MultiHeadAttentionRPE.py:543-545,687-688; VidHRFormer_modules.py:87-89,
+ * 190-192; nn.MultiheadAttention in/out projections :79-84,185-187,204-205), the 1x1 convs of MlpDWBN
+ * (:430,:436) and their autograd dgrad/wgrad; with a_mode = VPTR_A_CONV also Conv2d / ConvTranspose2d of
+ * the ResNet auto-encoder (ResNetAutoEncoder.py:26-48,74-88,138,151) as implicit GEMM.
+ *
+ * precision: 1 = single bf16 MFMA pass (rel. error ~2e-3 per GEMM),
+ *            3 = split-bf16 (hi*hi + hi*lo + lo*hi, fp32-class accuracy ~1e-5).
+ * epilogue, in this order (null pointer / zero flag = skipped):
+ *   v = acc; v *= colscale[n]; v += bias[n]; v *= alpha; v = act(v) (1 = exact-erf GELU, 2 = ReLU);
+ *   v *= rowscale[(m / rs_div) % rs_mod]; dropout(p, site); v += residual[m, n]; if (act_after) v = relu(v);
+ *   atomic: D[m,n] += v (split-K / gradient accumulation)  else  D[m,n] = v
+ * ---------------------------------------------------------------------------------------------- */
+enum { VPTR_A_KCONTIG = 0, VPTR_A_KSTRIDED = 1, VPTR_A_CONV = 2 };
+enum { VPTR_B_KCONTIG = 0, VPTR_B_KSTRIDED = 1 };
+enum { VPTR_ACT_NONE = 0, VPTR_ACT_GELU = 1, VPTR_ACT_RELU = 2 };
+enum { VPTR_PAD_ZERO = 0, VPTR_PAD_REFLECT = 1, VPTR_PAD_REPLICATE = 2 };
+
+typedef struct vptr_gemm_desc {
+  const float* A; /* a_mode 0: [M, lda] (k contiguous); 1: [K, lda] (m contiguous); 2: NHWC image, see conv_* */
+  const float* B; /* b_mode 0: [N, ldb] (k contiguous, i.e. nn.Linear weight); 1: [K, ldb] (n contiguous) */
+  float* D;       /* [M, ldd] */
+  float* Dpre;    /* optional [M, ldd]: value BEFORE the activation (after colscale/bias/alpha), saved for backward */
+  int64_t lda, ldb, ldd;
+  int M, N, K;
+  int a_mode, b_mode;
+  int precision; /* 1 or 3 */
+  int split_k;   /* >= 1; > 1 forces atomic accumulation into D */
+  int atomic;    /* 1: D += result (D must be initialised by the caller) */
+  const float* colscale; /* [N] */
+  const float* bias;     /* [N] */
+  float alpha;
+  int act;
+  const float* rowscale; /* [rs_mod] */
+  int rs_div, rs_mod;
+  float dropout_p;
+  const uint64_t* seed_dev;
+  uint32_t site;
+  const float* residual; /* [M, ldr] */
+  int64_t ldr;
+  int act_after; /* ReLU after the residual add */
+  /* implicit-GEMM convolution (a_mode == VPTR_A_CONV): A is the NHWC input [frames, IH, IW, Cin];
+     row m = (frame, oy, ox) of the [frames, OH, OW] output grid, k = (ky*KW + kx)*Cin + ci.
+     transposed = 0: iy = oy*stride - pad + ky (pad_mode for out-of-range);
+     transposed = 1: iy = (oy + pad - ky)/stride when divisible and in range, else zero
+                     (gather form of ConvTranspose2d, ResNetAutoEncoder.py:74-88). */
+  int conv_IH, conv_IW, conv_Cin, conv_OH, conv_OW, conv_KH, conv_KW, conv_stride, conv_pad, conv_pad_mode,
+      conv_transposed;
+} vptr_gemm_desc;
+
+int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm over the channel dim (nn.LayerNorm(C), VidHRFormer_modules.py:44-48,56,137-161; VidHRFormer.py:24,26).
+ *   y = LN(x); optional y2 = y + tab[((row / tab_div) % tab_mod), :]   (positional adds of :79,176,185,204)
+ * ---------------------------------------------------------------------------------------------- */
+int vptr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* y2, const float* tab,
+                       int tab_div, int tab_mod, float* mean, float* rstd, int rows, int C, float eps,
+                       vptr_stream_t stream);
+/* dx = LN'(dy + dy2); dgamma/dbeta are ACCUMULATED (+=) with atomics; dy2 may be null. */
+int vptr_layernorm_bwd(const float* dy, const float* dy2, const float* x, const float* gamma, const float* mean,
+                       const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int C,
+                       vptr_stream_t stream);
+
+/* out[(row / div) % mod, :] += src[row, :]   (gradient of a row-broadcast table; out must be zeroed by the caller) */
+int vptr_rowmod_sum(const float* src, float* out, int rows, int C, int div, int mod, vptr_stream_t stream);
+/* out[c] += sum_rows src[row, c]  (bias gradients) */
+int vptr_colsum(const float* src, float* out, int rows, int C, vptr_stream_t stream);
+/* y = x + tab[((row / div) % mod), :] */
+int vptr_add_rowtab(const float* x, const float* tab, float* y, int rows, int C, int div, int mod, vptr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Local-window attention core with relative-position bias
+ * (MultiHeadAttentionRPE.py:586-590,623,629-650,677-682 + window partition VidHRFormer_modules.py:497-525,
+ *  done by index arithmetic).  q (pre-scaled), k, v, o: [B*H*W, C] token-major, B = N*T frames.
+ *  bias_table [(2ws-1)^2, nh] or null; rel_index int64 [ws*ws, ws*ws].
+ * ---------------------------------------------------------------------------------------------- */
+int vptr_winattn_fwd(const float* q, const float* k, const float* v, const float* bias_table, const int64_t* rel_index,
+                     float* o, int B, int H, int W, int C, int nh, int ws, float dropout_p, const uint64_t* seed_dev,
+                     uint32_t site, vptr_stream_t stream);
+/* dq,dk,dv are written; dbias_table is ACCUMULATED (may be null). */
+int vptr_winattn_bwd(const float* q, const float* k, const float* v, const float* bias_table, const int64_t* rel_index,
+                     const float* dout, float* dq, float* dk, float* dv, float* dbias_table, int B, int H, int W, int C,
+                     int nh, int ws, float dropout_p, const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Temporal attention core (nn.MultiheadAttention slow path, VidHRFormer_modules.py:74-84,183-187,199-206):
+ * for every (n, pixel, head) attend over time.  q,o: [(n,tq,p), C]; k,v: [(n,tk,p), C]; q pre-scaled.
+ * causal != 0 masks j > i (FAR, :76-82).
+ * ---------------------------------------------------------------------------------------------- */
+int vptr_tattn_fwd(const float* q, const float* k, const float* v, float* o, int Nb, int Tq, int Tk, int HW, int C, int nh,
+                   int causal, float dropout_p, const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream);
+int vptr_tattn_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk, float* dv,
+                   int Nb, int Tq, int Tk, int HW, int C, int nh, int causal, float dropout_p, const uint64_t* seed_dev,
+                   uint32_t site, vptr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Conv-FFN pieces (MlpDWBN, VidHRFormer_modules.py:424-442) on channel-last [rows = frames*HW, F].
+ * Normalisation statistics:
+ *   group_rows == rows : BatchNorm2d batch statistics per channel  -> mean[F], var[F] (biased)
+ *   group_rows == HW   : LayerNorm((F,H,W)) statistics per frame   -> mean[frames], var[frames]
+ * ---------------------------------------------------------------------------------------------- */
+int vptr_colstats(const float* x, float* mean, float* var, float* scratch /* >= 2*F*ceil(rows/256) floats */, int rows,
+                  int F, vptr_stream_t stream);
+int vptr_groupstats(const float* x, float* mean, float* var, int groups, int group_elems, vptr_stream_t stream);
+/* y = rowscale[(row/rs_div)%rs_mod] * dropout(act( (x - mean)*rstd * w + b )) + residual
+ * per_col != 0: stats indexed by column (BN), affine [F];
+ * per_col == 0: stats indexed by row / HW (LN over (F,H,W)), affine given channel-last as [HW, F].
+ * rowscale (DropPath, VidHRFormer_modules.py:563-575) and residual may be null. */
+int vptr_norm_act_fwd(const float* x, const float* mean, const float* rstd, const float* w, const float* b, float* y,
+                      int rows, int F, int HW, int per_col, int act, float dropout_p, const uint64_t* seed_dev,
+                      uint32_t site, const float* rowscale, int rs_div, int rs_mod, const float* residual,
+                      vptr_stream_t stream);
+/* backward: dx written; dw/db ACCUMULATED (same layout as w/b). scratch >= 2*max(F, rows/HW) floats, zeroed inside.
+ * const_stats != 0: mean/rstd are constants (BatchNorm in eval mode) -> no statistics terms in dx. */
+int vptr_norm_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w, const float* b,
+                      float* dx, float* dw, float* db, float* scratch, int rows, int F, int HW, int per_col, int act,
+                      int const_stats, float dropout_p, const uint64_t* seed_dev, uint32_t site, const float* rowscale,
+                      int rs_div, int rs_mod, vptr_stream_t stream);
+/* depthwise 3x3, pad 1 (VidHRFormer_modules.py:404-409,433); w given tap-major [9, F]. */
+int vptr_dwconv3x3_fwd(const float* x, const float* w9, const float* b, float* y, int frames, int H, int W, int F,
+                       vptr_stream_t stream);
+int vptr_dwconv3x3_bwd(const float* dy, const float* x, const float* w9, float* dx, float* dw9, float* db, int frames,
+                       int H, int W, int F, vptr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise / layout helpers
+ * ---------------------------------------------------------------------------------------------- */
+/* [B, C, HW] (NCHW) <-> [B, HW, C] (tokens); relu != 0 applies ReLU to the output
+ * (VidHRFormer.py:43,51 permutes + relu_). */
+int vptr_nchw_to_tokens(const float* src, float* dst, int B, int C, int HW, vptr_stream_t stream);
+int vptr_tokens_to_nchw(const float* src, float* dst, int B, int C, int HW, int relu, vptr_stream_t stream);
+/* backward of tokens_to_nchw(relu): dtok = nchw_to_tokens(dout * (out > 0)) */
+int vptr_nchw_to_tokens_masked(const float* dout, const float* out, float* dtok, int B, int C, int HW, vptr_stream_t stream);
+/* backward of the GEMM epilogue: dx[m,n] = dy[m,n] * dropmask(site) * rowscale[(m / rs_div) % rs_mod] * act'(h[m,n]) * alpha
+ * (act 1: exact GELU on the saved pre-activation h; act 2: ReLU mask h > 0; act 0: h unused). rowscale may be null. */
+int vptr_act_bwd(const float* dy, const float* h, float* dx, int rows, int C, int act, float alpha, const float* rowscale,
+                 int rs_div, int rs_mod, float dropout_p, const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream);
+/* y = x * mask(site)/keep -- standalone dropout (fwd and bwd are the same call) */
+int vptr_dropout(const float* x, float* y, int64_t n, float dropout_p, const uint64_t* seed_dev, uint32_t site,
+                 vptr_stream_t stream);
+/* dx[m,n] = dy[m,n] * rowscale[(m / div) % mod] */
+int vptr_rowscale(const float* dy, const float* rowscale, float* dx, int rows, int C, int div, int mod, vptr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Direct convolutions of the auto-encoder ends (ResNetAutoEncoder.py:26-29 and :89-96).
+ * ---------------------------------------------------------------------------------------------- */
+/* first layer: ReflectionPad2d(3) + Conv7x7(Cimg -> Cout) + folded BN + ReLU; x NCHW [B,Cimg,H,W] -> y NHWC [B,H,W,Cout];
+ * w is the PyTorch weight [Cout, Cimg, 7, 7]. */
+int vptr_conv7_in_fwd(const float* x, const float* w, const float* scale, const float* shift, float* y, int B, int Cimg,
+                      int H, int W, int Cout, vptr_stream_t stream);
+/* last layer: ReflectionPad2d(3) + Conv7x7(Cin -> Cimg) + bias + Tanh(1)/Sigmoid(2); x NHWC -> y NCHW; w [Cimg,Cin,7,7] */
+int vptr_conv7_out_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cimg,
+                       int out_act, vptr_stream_t stream);
+/* backward of the last layer w.r.t. its input: dy, y NCHW [B,Cimg,H,W] -> dx NHWC [B,H,W,Cin] */
+int vptr_conv7_out_bwd_data(const float* dy, const float* y, const float* w, float* dx, int B, int Cin, int H, int W,
+                            int Cimg, int out_act, vptr_stream_t stream);
+/* backward of the last layer w.r.t. weight/bias: dw [Cimg,Cin,7,7], db [Cimg] ACCUMULATED */
+int vptr_conv7_out_bwd_weight(const float* dy, const float* y, const float* x, float* dw, float* db, int B, int Cin, int H,
+                              int W, int Cimg, int out_act, vptr_stream_t stream);
+/* dx = dy * (y > 0) * scale[c]   (ReLU + folded-BN backward on channel-last [rows, C]) */
+int vptr_bnrelu_bwd(const float* dy, const float* y, const float* scale, float* dx, int64_t rows, int C, vptr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer: global-norm clip + AdamW on flat fp32 buffers (train_NAR.py:85-86,205).
+ * ---------------------------------------------------------------------------------------------- */
+/* sumsq_dev[0] += sum(g^2) */
+int vptr_sumsq(const float* g, int64_t n, float* sumsq_dev, vptr_stream_t stream);
+/* p,m,v updated in place. clip coefficient = min(1, max_norm / (sqrt(sumsq_dev[0]) + 1e-6)) if sumsq_dev != null.
+ * step_dev: DEVICE pointer to the (float) step count already incremented for this step. grad_scale multiplies g first. */
+int vptr_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+               float weight_decay, const float* step_dev, const float* sumsq_dev, float max_norm, float grad_scale,
+               vptr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPTR_HIP_H */

@@ -1,0 +1,39 @@
+"""Shared test helpers (CPU + GPU)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import fill
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def rel(a, b, floor=0.0):
+    a = torch.as_tensor(a).detach().double().cpu().reshape(-1)
+    b = torch.as_tensor(b).detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / (b.norm() + floor + 1e-300))
+
+
+def jload(z, key):
+    return json.loads(str(z[key]))
+
+
+def build_transformer(pkg, cfg, far, dropout=0.0):
+    """pkg: a module exposing VPTRFormerNAR / VPTRFormerFAR (vptr_amd.model)."""
+    if far:
+        return pkg.VPTRFormerFAR(cfg["Tp"], cfg["Tf"], cfg["H"], cfg["W"], cfg["C"], cfg["nhead"], cfg["num_encoder_layers"],
+                                 dropout, cfg["window_size"], 4, cfg["rpe"])
+    return pkg.VPTRFormerNAR(cfg["Tp"], cfg["Tf"], cfg["H"], cfg["W"], cfg["C"], cfg["nhead"], cfg["num_encoder_layers"],
+                             cfg["num_decoder_layers"], dropout, cfg["window_size"], 4, False, cfg["rpe"])
+
+
+def grad_floor(norms):
+    """Gradients that are analytically zero (biases in front of a train-mode BatchNorm, the k-bias of a softmax) are pure
+    round-off; errors are measured against ||ref|| + 1e-2 * median gradient norm (same rule as oracle/make_golden.py)."""
+    return 1e-2 * float(np.median(list(norms)))

@@ -1,0 +1,216 @@
+"""CPU-only tests: the oracle against the golden vectors captured from the reference, host-side logic (module tree,
+state_dict keys, position tables, init), and that the C-ABI library loads and exports every declared symbol."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_transformer, grad_floor, jload, load, rel
+from oracle import fill
+from oracle import vptr_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------------------------------- oracle pinning
+@pytest.mark.parametrize("name", ["nar_tiny", "nar_tiny_norpe", "far_tiny", "nar_tiny_pad", "nar_tiny_T"])
+def test_oracle_matches_reference_golden(name):
+    z = load(name)
+    cfg, far = jload(z, "cfg"), bool(int(z["far"]))
+    tmpl = jload(z, "template")
+    P = fill.fill_state([tuple(t) for t in tmpl], int(z["seed"]))
+    for k, shape, dt in tmpl:  # entries the fill does not produce
+        if k not in P:
+            if "buf:" + k in z.files:
+                P[k] = torch.from_numpy(z["buf:" + k])
+            elif k.endswith("relative_position_index"):
+                P[k] = O.rpe_index(cfg["window_size"])
+            elif k.endswith("num_batches_tracked"):
+                P[k] = torch.zeros((), dtype=torch.long)
+    leaves = {}
+    for k, shape, dt in tmpl:
+        if "grad:" + k in z.files:
+            P[k] = P[k].clone().requires_grad_(True)
+            leaves[k] = P[k]
+    x = torch.from_numpy(z["x"]).requires_grad_(True)
+    fwd = O.far_forward if far else O.nar_forward
+    with torch.no_grad():
+        Pe = {k: v.detach().clone() for k, v in P.items()}
+        assert rel(fwd(Pe, x, cfg, training=False), z["out_eval"]) < 1e-5
+    out = fwd(P, x, cfg, training=True)
+    assert rel(out, z["out_train"]) < 1e-5
+    (out * torch.from_numpy(z["g"])).sum().backward()
+    assert rel(x.grad, z["dx"]) < 1e-5
+    floor = grad_floor(np.linalg.norm(z[k]) for k in z.files if k.startswith("grad:"))
+    for k, t in leaves.items():
+        assert rel(t.grad, z["grad:" + k], floor) < 2e-4, k
+    for k in z.files:
+        if k.startswith("bn_after:"):
+            assert rel(P[k[9:]], z[k]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["ae_tiny_reflect", "ae_tiny_zero"])
+def test_oracle_autoencoder_golden(name):
+    z = load(name)
+    meta = jload(z, "meta")
+    Pe = fill.fill_state([tuple(t) for t in jload(z, "enc_template")], meta["seed"])
+    Pd = fill.fill_state([tuple(t) for t in jload(z, "dec_template")], meta["seed"] + 10)
+    x = torch.from_numpy(z["x"])
+    with torch.no_grad():
+        f = O.enc_forward(Pe, x, padding_type=meta["padding_type"])
+    assert rel(f, z["feat"]) < 1e-5
+    fin = torch.from_numpy(z["feat"]).requires_grad_(True)
+    y = O.dec_forward(Pd, fin, out_layer=meta["out_layer"])
+    assert rel(y, z["y"]) < 1e-5
+    (y * torch.from_numpy(z["g"])).sum().backward()
+    assert rel(fin.grad, z["dfeat"]) < 1e-5
+
+
+def test_oracle_losses_golden():
+    import torch.nn.functional as F
+    z = load("losses_tiny")
+    gt, gf = torch.from_numpy(z["gt"]), torch.from_numpy(z["gf"])
+    pr, pf = torch.from_numpy(z["pr"]).requires_grad_(True), torch.from_numpy(z["pf"]).requires_grad_(True)
+    l = O.gdl_loss(gt, pr) + O.mse_loss(pr, gt) + 0.1 * O.bipatch_nce(F.normalize(gf, p=2.0, dim=2), F.normalize(pf, p=2.0, dim=2))
+    l.backward()
+    assert abs(l.item() - float(z["loss"])) < 1e-6 * abs(float(z["loss"]))
+    assert rel(pr.grad, z["dpr"]) < 1e-6 and rel(pf.grad, z["dpf"]) < 1e-6
+    assert abs(O.mse_loss(pr, gt).item() - float(z["mse"])) < 1e-6 and abs(O.gdl_loss(gt, pr).item() - float(z["gdl"])) < 1e-6
+
+
+def test_oracle_position_tables_golden():
+    z = load("pos_tables")
+    for tag in ("6_96_4", "20_528_4", "50_528_8"):
+        T, E, ws = (int(s) for s in tag.split("_"))
+        assert rel(O.pos1d(T, E), z["p1:" + tag]) < 1e-6
+        assert rel(O.pos2d(E, ws, ws), z["p2:" + tag]) < 1e-6
+        if "p3:" + tag in z.files:
+            assert rel(O.pos3d(E, T, ws, ws), z["p3:" + tag]) < 1e-6
+        else:
+            n, s = fill.digest(O.pos3d(E, T, ws, ws))
+            assert abs(n - float(z["p3n:" + tag])) < 1e-5 * n and rel(s, z["p3s:" + tag]) < 1e-6
+    for ws in (4, 8):
+        assert np.array_equal(O.rpe_index(ws).numpy(), z[f"rpe_index:{ws}"])
+
+
+def test_oracle_train_step_golden():
+    z = load("step_tiny")
+    cfg, meta = jload(z, "cfg"), jload(z, "meta")
+    Pe = fill.fill_state([tuple(t) for t in jload(z, "enc_template")], meta["seed"])
+    Pd = fill.fill_state([tuple(t) for t in jload(z, "dec_template")], meta["seed"] + 10)
+    tm = jload(z, "T_template")
+    PT = fill.fill_state([tuple(t) for t in tm], meta["seed"] + 20)
+    PT["temporal_pos"] = O.pos1d(cfg["Tp"] + cfg["Tf"], cfg["C"])
+    PT["lw_pos"] = O.pos2d(cfg["C"], cfg["window_size"], cfg["window_size"])
+    for k, s, d in tm:
+        if k.endswith("relative_position_index"):
+            PT[k] = O.rpe_index(cfg["window_size"])
+        elif k.endswith("num_batches_tracked"):
+            PT[k] = torch.zeros((), dtype=torch.long)
+    for P, t in ((Pe, jload(z, "enc_template")), (Pd, jload(z, "dec_template"))):
+        for k, s, d in t:
+            if k.endswith("num_batches_tracked"):
+                P[k] = torch.zeros((), dtype=torch.long)
+    st = O.NARStep(Pe, Pd, PT, cfg)
+    for s, ref in enumerate(jload(z, "records")):
+        past = (fill.rand_input((meta["N"], cfg["Tp"], 1, meta["HW"], meta["HW"]), meta["seed"] + 100 + s) - 0.6013795) / 2.7570653
+        fut = (fill.rand_input((meta["N"], cfg["Tf"], 1, meta["HW"], meta["HW"]), meta["seed"] + 200 + s) - 0.6013795) / 2.7570653
+        r = st.step(past, fut)
+        for k in ref:
+            assert abs(r[k] - ref[k]) <= 2e-4 * abs(ref[k]) + 1e-7, (k, r[k], ref[k])
+    worst = max(rel(st.P_T[k[5:]], z[k]) for k in z.files if k.startswith("post:"))
+    assert worst < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------------ host-side logic
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "vptr_hip.h")).read()
+    declared = set(re.findall(r"\b(vptr_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"vptr_gemm_desc"}
+    from vptr_amd import _lib
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.lib.vptr_abi_version() == 1
+    assert ctypes.sizeof(_lib.GemmDesc) % 8 == 0
+
+
+def test_product_path_has_no_cpu_fallback():
+    import vptr_amd.ops as ops
+    x = torch.randn(8, 16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.linear(x, torch.randn(4, 16), None)
+    for root, _, files in os.walk(os.path.join(ROOT, "vptr_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+@pytest.mark.parametrize("name", ["nar_tiny", "nar_tiny_norpe", "far_tiny", "nar_k64_digest", "far_bair_digest"])
+def test_state_dict_keys_match_reference(name):
+    import vptr_amd.model as pkg
+    z = load(name)
+    cfg, far = jload(z, "cfg"), bool(int(z["far"]))
+    m = build_transformer(pkg, cfg, far)
+    assert [(k, list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in m.state_dict().items()] == \
+        [tuple(t) if False else (t[0], t[1], t[2]) for t in jload(z, "template")]
+    for k in ("temporal_pos", "lw_pos", "Tlw_pos"):
+        if "buf:" + k in z.files:
+            assert torch.equal(m.state_dict()[k], torch.from_numpy(z["buf:" + k])), k
+
+
+def test_autoencoder_keys_and_api():
+    import vptr_amd.model as pkg
+    import model as shim
+    assert shim.VPTREnc is pkg.VPTREnc and shim.VPTRFormerNAR is pkg.VPTRFormerNAR and shim.init_weights is pkg.init_weights
+    for name in ("ae_tiny_reflect", "ae_tiny_zero"):
+        z = load(name)
+        meta = jload(z, "meta")
+        enc = pkg.VPTREnc(meta["img_ch"], meta["feat"], 3, meta["padding_type"])
+        dec = pkg.VPTRDec(meta["img_ch"], meta["feat"], 3, meta["out_layer"], meta["padding_type"])
+        assert [(k, list(v.shape)) for k, v in enc.state_dict().items()] == [(k, s) for k, s, _ in jload(z, "enc_template")]
+        assert [(k, list(v.shape)) for k, v in dec.state_dict().items()] == [(k, s) for k, s, _ in jload(z, "dec_template")]
+    with pytest.raises(ValueError):
+        pkg.VPTRDec(1, 48, 3, "Softmax")
+    with pytest.raises(NotImplementedError):
+        pkg.VPTREnc(1, 48, 3, "circular")
+    enc = pkg.VPTREnc(1, 48, 3)
+    pkg.init_weights(enc)
+    w = enc.encoder.model[1].weight
+    assert abs(float(w.std()) - 0.02) < 0.005
+    assert abs(float(enc.encoder.model[2].weight.mean()) - 1.0) < 0.02
+
+
+def test_reset_parameters_quirks():
+    """xavier over every dim>1 parameter: RPE table, frame_queries and the 3-D LayerNorm affines are re-initialised
+    (VPTR_modules.py:149-152, SURVEY.md section 8b 'Init semantics')."""
+    import vptr_amd.model as pkg
+    torch.manual_seed(0)
+    m = pkg.VPTRFormerNAR(2, 2, 8, 8, 48, 8, 1, 1, 0.1, 4, 4, False, True)
+    assert m.num_future_frames == 2 and callable(m.NCE_projector)
+    ln = m.transformer.decoder.layers[0].SpatialFFN.norm1
+    assert ln.weight.dim() == 3 and float(ln.weight.abs().max()) < 0.2       # not ones any more
+    assert float(m.frame_queries.std()) < 0.1                                   # not randn any more
+    bn = m.transformer.encoder.layers[0].SpatialFFN.norm1
+    assert isinstance(bn, torch.nn.BatchNorm2d) and float(bn.weight.min()) == 1.0
+    assert m.transformer.encoder.layers[0]._site != m.transformer.decoder.layers[0]._site
+
+
+def test_losses_cpu_match_oracle():
+    import torch.nn.functional as F
+    import vptr_amd.model as pkg
+    z = load("losses_tiny")
+    gt, gf = torch.from_numpy(z["gt"]), torch.from_numpy(z["gf"])
+    pr, pf = torch.from_numpy(z["pr"]), torch.from_numpy(z["pf"])
+    N, T, C, h, w = gf.shape
+    l = pkg.GDL(alpha=1)(gt, pr) + pkg.MSELoss()(pr, gt) + 0.1 * pkg.BiPatchNCE(N, T, h, w, 1.0)(
+        F.normalize(gf, p=2.0, dim=2), F.normalize(pf, p=2.0, dim=2))
+    assert abs(l.item() - float(z["loss"])) < 1e-6 * abs(float(z["loss"]))
+    w = pkg.temporal_weight_func(10)
+    assert abs(float(w[-1]) - 10.0) < 1e-4 and float(w[0]) == 1.0

@@ -1,0 +1,351 @@
+"""GPU parity of every C-ABI kernel against plain torch fp64/fp32 CPU math on the same seeded inputs.
+
+Tolerances (rel-L2): split-bf16 GEMM (precision 3) 3e-5; single-pass bf16 (precision 1) 1.5e-2; fp32 vector kernels 2e-5.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel
+from oracle import fill
+from oracle import vptr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL3, TOL1, TOLV = 3e-5, 1.5e-2, 2e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import vptr_amd.ops as ops
+    return ops
+
+
+def rn(shape, seed, scale=1.0):
+    return fill.rand_normal(shape, seed, scale)
+
+
+# ---------------------------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("prec,tol", [(3, TOL3), (1, TOL1)])
+@pytest.mark.parametrize("M,N,K", [(300, 528, 528), (257, 100, 72), (128, 352, 2112), (64, 48, 48), (1000, 1584, 528)])
+def test_gemm_nt_epilogue(ops, dev, M, N, K, prec, tol):
+    x, W, b, r = rn((M, K), 1), rn((N, K), 2, K ** -0.5), rn((N,), 3), rn((M, N), 4)
+    ref = F.gelu((x.double() @ W.double().t() + b.double()) * 0.5) + r.double()
+    y = torch.empty((M, N), device=dev)
+    pre = torch.empty((M, N), device=dev)
+    ops.gemm_raw(x.to(dev), W.to(dev), y, M, N, K, 0, 0, bias=b.to(dev), alpha=0.5, act=ops.ACT_GELU, Dpre=pre,
+                 residual=r.to(dev), precision=prec)
+    assert rel(y, ref) < tol
+    assert rel(pre, (x.double() @ W.double().t() + b.double()) * 0.5) < tol
+    # asymmetric check against a transposed result (would catch a swapped C/D fragment layout)
+    if M != N:
+        assert y.shape == (M, N)
+
+
+@pytest.mark.parametrize("prec,tol", [(3, TOL3), (1, TOL1)])
+def test_gemm_dgrad_wgrad_modes(ops, dev, prec, tol):
+    M, N, K = 777, 528, 2112
+    g, W, x = rn((M, N), 5), rn((N, K), 6, N ** -0.5), rn((M, K), 7)
+    dx = torch.empty((M, K), device=dev)
+    ops.gemm_raw(g.to(dev), W.to(dev), dx, M, K, N, 0, 1, precision=prec)          # g[M,N] @ W[N,K]
+    assert rel(dx, g.double() @ W.double()) < tol
+    dW = torch.zeros((N, K), device=dev)
+    ops.gemm_raw(g.to(dev), x.to(dev), dW, N, K, M, 1, 1, atomic=True, split_k=3, precision=prec)  # g^T @ x
+    assert rel(dW, g.double().t() @ x.double()) < tol
+    dW2 = torch.zeros((N, K), device=dev)
+    ops.gemm_raw(g.to(dev), x.to(dev), dW2, N, K, M, 1, 1, atomic=True, split_k=1, precision=prec)
+    assert rel(dW2, g.double().t() @ x.double()) < tol
+    # A k-strided x B k-contiguous
+    Bk = rn((260, M + 3), 8)[:, :M].contiguous()  # [n, k] with k = M contiguous; M % 4 != 0 would be rejected
+    if M % 4 == 0:
+        out = torch.empty((N, 260), device=dev)
+        ops.gemm_raw(g.to(dev), Bk.to(dev), out, N, 260, M, 1, 0, precision=prec)
+        assert rel(out, g.double().t() @ Bk.double().t()) < tol
+
+
+def test_gemm_epilogue_variants(ops, dev):
+    M, N, K = 200, 176, 64
+    x, W = rn((M, K), 9), rn((N, K), 10, K ** -0.5)
+    cs, b, rs = rn((N,), 11).abs() + 0.5, rn((N,), 12), rn((10,), 13).abs()
+    r = rn((M, N), 14)
+    acc = x.double() @ W.double().t()
+    rows = torch.arange(M)
+    ref = torch.relu(torch.relu(acc * cs.double() + b.double()) * rs.double()[(rows // 4) % 10][:, None] + r.double())
+    y = torch.empty((M, N), device=dev)
+    ops.gemm_raw(x.to(dev), W.to(dev), y, M, N, K, 0, 0, colscale=cs.to(dev), bias=b.to(dev), act=ops.ACT_RELU,
+                 rowscale=rs.to(dev), rs_div=4, rs_mod=10, residual=r.to(dev), act_after=True, precision=3)
+    assert rel(y, ref) < TOL3
+
+
+def test_linear_autograd(ops, dev):
+    M, K, N = 384, 96, 192
+    x, W, b, r = rn((M, K), 20), rn((N, K), 21, K ** -0.5), rn((N,), 22), rn((M, N), 23)
+    gout = rn((M, N), 24)
+    xs = [t.clone().requires_grad_(True) for t in (x.double(), W.double(), b.double(), r.double())]
+    ref = F.gelu((xs[0] @ xs[1].t() + xs[2]) * 0.7) + xs[3]
+    ref.backward(gout.double())
+    ds = [t.to(dev).requires_grad_(True) for t in (x, W, b, r)]
+    y = ops.linear(ds[0], ds[1], ds[2], residual=ds[3], alpha=0.7, act=ops.ACT_GELU)
+    y.backward(gout.to(dev))
+    assert rel(y, ref) < TOL3
+    for a, c in zip(ds, xs):
+        assert rel(a.grad, c.grad) < 5e-5
+
+
+def test_linear_dropout_mask_consistency(ops, dev):
+    M, K = 512, 64
+    ops.manual_seed(dev, 1234)
+    ops.new_seed_scope(dev)
+    x = torch.ones((M, K), device=dev, requires_grad=True)
+    W = torch.eye(K, device=dev)
+    y = ops.linear(x, W, None, dropout_p=0.25, site=7)
+    y.backward(torch.ones_like(y))
+    yv = y.detach().cpu()
+    kept = (yv != 0).float().mean().item()
+    assert abs(kept - 0.75) < 0.02
+    assert torch.allclose(yv[yv != 0], torch.full_like(yv[yv != 0], 1 / 0.75), rtol=1e-4)
+    assert rel(x.grad, yv) < 1e-4      # backward re-creates the same mask
+    ops.new_seed_scope(dev)
+    y2 = ops.linear(x.detach(), W, None, dropout_p=0.25, site=7)
+    assert (y2.cpu() != yv).float().mean().item() > 0.2  # fresh scope -> fresh mask
+
+
+# ----------------------------------------------------------------------------------------------------------- conv GEMM
+@pytest.mark.parametrize("pad_mode", ["zero", "reflect", "replicate"])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_conv_gather(ops, dev, pad_mode, stride):
+    B, Cin, Cout, H, W = 3, 16, 40, 12, 10
+    x, w = rn((B, Cin, H, W), 30), rn((Cout, Cin, 3, 3), 31, 0.1)
+    if pad_mode == "zero":
+        ref = F.conv2d(x.double(), w.double(), stride=stride, padding=1)
+    else:
+        ref = F.conv2d(F.pad(x.double(), (1, 1, 1, 1), mode=pad_mode), w.double(), stride=stride)
+    OH, OW = ref.shape[2:]
+    xt = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().to(dev)
+    y = ops.conv_nhwc(xt, ops.conv_weight_as_gemm_b(w, False).to(dev), B, H, W, Cin, OH, OW, 3, 3, stride, 1, pad_mode, False, Cout)
+    assert rel(y.reshape(B, OH, OW, Cout).permute(0, 3, 1, 2), ref) < TOL3
+
+
+def test_conv_transposed_gather(ops, dev):
+    B, Cin, Cout, H, W = 2, 24, 20, 6, 5
+    x, w = rn((B, Cin, H, W), 32), rn((Cin, Cout, 3, 3), 33, 0.1)
+    ref = F.conv_transpose2d(x.double(), w.double(), stride=2, padding=1, output_padding=1)
+    xt = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().to(dev)
+    y = ops.conv_nhwc(xt, ops.conv_weight_as_gemm_b(w, True).to(dev), B, H, W, Cin, 2 * H, 2 * W, 3, 3, 2, 1, "zero", True, Cout)
+    assert rel(y.reshape(B, 2 * H, 2 * W, Cout).permute(0, 3, 1, 2), ref) < TOL3
+
+
+# ----------------------------------------------------------------------------------------------------------- layernorm
+def test_layernorm_fwd_bwd(ops, dev):
+    rows, C, HW, T = 2 * 3 * 16, 48, 16, 3
+    x, g, b, tab = rn((rows, C), 40), rn((C,), 41).abs() + 0.5, rn((C,), 42), rn((T, C), 43)
+    go, go2 = rn((rows, C), 44), rn((rows, C), 45)
+    xs = [t.double().clone().requires_grad_(True) for t in (x, g, b, tab)]
+    y = F.layer_norm(xs[0], (C,), xs[1], xs[2], 1e-5)
+    t_idx = (torch.arange(rows) // HW) % T
+    y2 = y + xs[3][t_idx]
+    (y * go.double()).sum().backward(retain_graph=True)
+    (y2 * go2.double()).sum().backward()
+    ds = [t.to(dev).requires_grad_(True) for t in (x, g, b, tab)]
+    o, o2 = ops.layernorm(ds[0], ds[1], ds[2], tab=ds[3], tab_div=HW, tab_mod=T)
+    ((o * go.to(dev)).sum() + (o2 * go2.to(dev)).sum()).backward()
+    assert rel(o, y) < TOLV and rel(o2, y2) < TOLV
+    for a, c in zip(ds, xs):
+        assert rel(a.grad, c.grad) < 5e-5
+    # single-output form
+    d0 = x.to(dev).requires_grad_(True)
+    o = ops.layernorm(d0, ds[1].detach(), ds[2].detach())
+    assert rel(o, y) < TOLV
+
+
+def test_rowtab_colsum(ops, dev):
+    rows, C = 7 * 5 * 4, 32
+    x, tab = rn((rows, C), 46), rn((5, C), 47)
+    xd, td = x.to(dev).requires_grad_(True), tab.to(dev).requires_grad_(True)
+    y = ops.add_rowtab(xd, td, 4, 5)
+    idx = (torch.arange(rows) // 4) % 5
+    assert rel(y, x + tab[idx]) < 1e-6
+    y.backward(torch.ones_like(y) * 2)
+    ref = torch.zeros(5, C).index_add_(0, idx, torch.full((rows, C), 2.0))
+    assert rel(td.grad, ref) < 1e-6
+
+
+# ----------------------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("ws,H,W", [(4, 8, 8), (8, 16, 8)])
+def test_window_attention(ops, dev, ws, H, W):
+    B, C, nh = 3, 48, 8
+    L = ws * ws
+    q, k, v = rn((B * H * W, C), 50, 0.5), rn((B * H * W, C), 51, 0.5), rn((B * H * W, C), 52)
+    table = rn(((2 * ws - 1) ** 2, nh), 53, 0.5)
+    idx = O.rpe_index(ws)
+    go = rn((B * H * W, C), 54)
+    ins = [t.double().clone().requires_grad_(True) for t in (q, k, v, table)]
+
+    def part(t):
+        return O.win_partition(t.reshape(B, H, W, C), ws)
+    bias = ins[3][idx.reshape(-1)].reshape(L, L, nh).permute(2, 0, 1)
+    o = O._attend(O._heads(part(ins[0]), nh), O._heads(part(ins[1]), nh), O._heads(part(ins[2]), nh), bias)
+    o = O.win_reverse(o, B, H, W, ws).reshape(B * H * W, C)
+    (o * go.double()).sum().backward()
+    ds = [t.to(dev).requires_grad_(True) for t in (q, k, v, table)]
+    od = ops.window_attention(ds[0], ds[1], ds[2], ds[3], idx.to(dev), B, H, W, nh, ws)
+    (od * go.to(dev)).sum().backward()
+    assert rel(od, o) < TOLV
+    for a, c in zip(ds, ins):
+        assert rel(a.grad, c.grad) < 5e-5
+    # without a bias table (rpe=False path)
+    od2 = ops.window_attention(ds[0].detach(), ds[1].detach(), ds[2].detach(), None, None, B, H, W, nh, ws)
+    o2 = O._attend(O._heads(part(q.double()), nh), O._heads(part(k.double()), nh), O._heads(part(v.double()), nh), None)
+    assert rel(od2, O.win_reverse(o2, B, H, W, ws).reshape(B * H * W, C)) < TOLV
+
+
+@pytest.mark.parametrize("Tq,Tk,causal", [(5, 5, False), (5, 5, True), (3, 7, False), (29, 29, True)])
+def test_temporal_attention(ops, dev, Tq, Tk, causal):
+    N, HW, C, nh = 2, 6, 48, 8
+    q, k, v = rn((N * Tq * HW, C), 60, 0.5), rn((N * Tk * HW, C), 61, 0.5), rn((N * Tk * HW, C), 62)
+    go = rn((N * Tq * HW, C), 63)
+    ins = [t.double().clone().requires_grad_(True) for t in (q, k, v)]
+
+    def seq(t, T):  # (n,t,p) rows -> (n*p, T, C)
+        return t.reshape(N, T, HW, C).permute(0, 2, 1, 3).reshape(N * HW, T, C)
+    o = O._attend(O._heads(seq(ins[0], Tq), nh), O._heads(seq(ins[1], Tk), nh), O._heads(seq(ins[2], Tk), nh), None, causal)
+    o = o.reshape(N, HW, Tq, C).permute(0, 2, 1, 3).reshape(N * Tq * HW, C)
+    (o * go.double()).sum().backward()
+    ds = [t.to(dev).requires_grad_(True) for t in (q, k, v)]
+    od = ops.temporal_attention(ds[0], ds[1], ds[2], N, Tq, Tk, HW, nh, causal)
+    (od * go.to(dev)).sum().backward()
+    assert rel(od, o) < TOLV
+    for a, c in zip(ds, ins):
+        assert rel(a.grad, c.grad) < 5e-5
+
+
+# ------------------------------------------------------------------------------------------------------ conv-FFN pieces
+@pytest.mark.parametrize("mode", ["bn", "ln", "bn_eval"])
+def test_norm_act(ops, dev, mode):
+    frames, H, W, Fc = 6, 4, 4, 32
+    HW, rows = H * W, frames * H * W
+    x, go, res = rn((rows, Fc), 70, 2.0) + 0.3, rn((rows, Fc), 71), rn((rows, Fc), 72)
+    rs = rn((3,), 73).abs() + 0.5
+    rs_idx = (torch.arange(rows) // (2 * HW)) % 3
+    xn = x.double().reshape(frames, H, W, Fc).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    if mode == "ln":
+        w, b = rn((Fc, H, W), 74).abs() + 0.5, rn((Fc, H, W), 75)
+        wd, bd = w.double().clone().requires_grad_(True), b.double().clone().requires_grad_(True)
+        z = F.layer_norm(xn, (Fc, H, W), wd, bd, 1e-5)
+    else:
+        w, b = rn((Fc,), 74).abs() + 0.5, rn((Fc,), 75)
+        rm, rv = rn((Fc,), 76, 0.1), rn((Fc,), 77).abs() + 0.5
+        wd, bd = w.double().clone().requires_grad_(True), b.double().clone().requires_grad_(True)
+        rmd, rvd = rm.double().clone(), rv.double().clone()
+        z = F.batch_norm(xn, rmd, rvd, wd, bd, mode == "bn", 0.1, 1e-5)
+    y = F.gelu(z).permute(0, 2, 3, 1).reshape(rows, Fc) * rs.double()[rs_idx][:, None] + res.double()
+    (y * go.double()).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    resd = res.to(dev).requires_grad_(True)
+    if mode == "ln":
+        wp, bp = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        wcl = wp.reshape(Fc, HW).t().contiguous()
+        bcl = bp.reshape(Fc, HW).t().contiguous()
+        yd = ops.norm_act(xd, wcl, bcl, "ln", HW, True, rowscale=rs.to(dev), rs_div=2 * HW, rs_mod=3, residual=resd)
+    else:
+        wp, bp = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        rmg, rvg = rm.to(dev), rv.to(dev)
+        yd = ops.norm_act(xd, wp, bp, "bn", HW, mode == "bn", rmg, rvg, rowscale=rs.to(dev), rs_div=2 * HW, rs_mod=3, residual=resd)
+        if mode == "bn":
+            assert rel(rmg, rmd) < 1e-5 and rel(rvg, rvd) < 1e-5
+    (yd * go.to(dev)).sum().backward()
+    assert rel(yd, y) < TOLV
+    assert rel(xd.grad, xn.grad.permute(0, 2, 3, 1).reshape(rows, Fc)) < 1e-4
+    assert rel(wp.grad, wd.grad) < 1e-4 and rel(bp.grad, bd.grad) < 1e-4
+    assert rel(resd.grad, go) < 1e-6
+
+
+def test_dwconv(ops, dev):
+    frames, H, W, Fc = 5, 8, 6, 32
+    x, w, b, go = rn((frames * H * W, Fc), 80), rn((Fc, 1, 3, 3), 81, 0.3), rn((Fc,), 82), rn((frames * H * W, Fc), 83)
+    xn = x.double().reshape(frames, H, W, Fc).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wd, bd = w.double().clone().requires_grad_(True), b.double().clone().requires_grad_(True)
+    y = F.conv2d(xn, wd, bd, padding=1, groups=Fc).permute(0, 2, 3, 1).reshape(-1, Fc)
+    (y * go.double()).sum().backward()
+    xd, wp, bp = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    yd = ops.dwconv3x3(xd, wp, bp, frames, H, W)
+    (yd * go.to(dev)).sum().backward()
+    assert rel(yd, y) < TOLV
+    assert rel(xd.grad, xn.grad.permute(0, 2, 3, 1).reshape(-1, Fc)) < 2e-5
+    assert rel(wp.grad, wd.grad) < 5e-5 and rel(bp.grad, bd.grad) < 5e-5
+
+
+def test_layout(ops, dev):
+    B, C, H, W = 3, 50, 5, 7
+    x, go = rn((B, C, H, W), 90), rn((B, C, H, W), 91)
+    xd = x.to(dev).requires_grad_(True)
+    t = ops.nchw_to_tokens(xd)
+    assert torch.equal(t.cpu(), x.permute(0, 2, 3, 1).reshape(-1, C))
+    back = ops.tokens_to_nchw(t, B, C, H, W, relu=True)
+    assert torch.equal(back.detach().cpu(), torch.relu(x))
+    back.backward(go.to(dev))
+    assert torch.equal(xd.grad.cpu(), go * (x > 0))
+
+
+# ------------------------------------------------------------------------------------------------------------ 7x7 convs
+@pytest.mark.parametrize("cimg", [1, 3])
+def test_conv7_ends(ops, dev, cimg):
+    from vptr_amd._lib import check, lib, ptr, stream
+    B, H, W = 2, 16, 24
+    x, w = rn((B, cimg, H, W), 100), rn((64, cimg, 7, 7), 101, 0.1)
+    sc, sh = rn((64,), 102).abs() + 0.5, rn((64,), 103)
+    ref = torch.relu(F.conv2d(F.pad(x.double(), (3, 3, 3, 3), mode="reflect"), w.double()) * sc.double()[None, :, None, None]
+                     + sh.double()[None, :, None, None])
+    y = torch.empty((B * H * W, 64), device=dev)
+    check(lib.vptr_conv7_in_fwd(ptr(x.to(dev)), ptr(w.to(dev)), ptr(sc.to(dev)), ptr(sh.to(dev)), ptr(y), B, cimg, H, W, 64,
+                                stream()), "conv7_in")
+    assert rel(y.reshape(B, H, W, 64).permute(0, 3, 1, 2), ref) < TOLV
+    # output layer fwd + bwd-data
+    for act, fn in ((1, torch.tanh), (2, torch.sigmoid)):
+        xin = rn((B, 64, H, W), 104, 0.5).double().requires_grad_(True)
+        w2, b2 = rn((cimg, 64, 7, 7), 105, 0.03), rn((cimg,), 106, 0.1)
+        go = rn((B, cimg, H, W), 107)
+        out = fn(F.conv2d(F.pad(xin, (3, 3, 3, 3), mode="reflect"), w2.double(), b2.double()))
+        (out * go.double()).sum().backward()
+        xt = xin.detach().float().permute(0, 2, 3, 1).reshape(-1, 64).contiguous().to(dev)
+        yo = torch.empty((B, cimg, H, W), device=dev)
+        check(lib.vptr_conv7_out_fwd(ptr(xt), ptr(w2.to(dev)), ptr(b2.to(dev)), ptr(yo), B, 64, H, W, cimg, act, stream()), "c7o")
+        assert rel(yo, out) < TOLV
+        dx = torch.empty((B * H * W, 64), device=dev)
+        check(lib.vptr_conv7_out_bwd_data(ptr(go.to(dev)), ptr(yo), ptr(w2.to(dev)), ptr(dx), B, 64, H, W, cimg, act, stream()),
+              "c7obd")
+        assert rel(dx.reshape(B, H, W, 64).permute(0, 3, 1, 2), xin.grad) < 5e-5
+        dw = torch.zeros((cimg, 64, 7, 7), device=dev)
+        db = torch.zeros((cimg,), device=dev)
+        w2d = w2.double().clone().requires_grad_(True)
+        b2d = b2.double().clone().requires_grad_(True)
+        out2 = fn(F.conv2d(F.pad(xin.detach(), (3, 3, 3, 3), mode="reflect"), w2d, b2d))
+        (out2 * go.double()).sum().backward()
+        check(lib.vptr_conv7_out_bwd_weight(ptr(go.to(dev)), ptr(yo), ptr(xt), ptr(dw), ptr(db), B, 64, H, W, cimg, act,
+                                            stream()), "c7obw")
+        assert rel(dw, w2d.grad) < 5e-5 and rel(db, b2d.grad) < 5e-5
+
+
+# ------------------------------------------------------------------------------------------------------------ optimizer
+def test_adamw_clip(ops, dev):
+    from vptr_amd._lib import check, lib, ptr, stream
+    n = 10007
+    p0, g = rn((n,), 110), rn((n,), 111, 0.3)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3)
+    pd, m, v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    step = torch.zeros(1, device=dev)
+    for it in range(3):
+        gi = g * (it + 1)
+        pr.grad = gi.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        ss = torch.zeros(1, device=dev)
+        gd = gi.to(dev)
+        check(lib.vptr_sumsq(ptr(gd), n, ptr(ss), stream()), "sumsq")
+        step += 1
+        check(lib.vptr_adamw(ptr(pd), ptr(gd), ptr(m), ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 1e-2, ptr(step), ptr(ss), 1.0, 1.0,
+                             stream()), "adamw")
+    assert rel(pd, pr) < 1e-6

@@ -1,0 +1,113 @@
+"""ctypes binding of libvptr_hip.so (the C ABI declared in include/vptr_hip.h).
+
+The product path has no CPU or PyTorch fallback: if the shared library is missing or a symbol cannot be
+resolved, importing this module raises, and every op raises RuntimeError with the library's own message when a
+call returns non-zero.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvptr_hip.so")
+
+c_void_p, c_int, c_float, c_int64, c_uint32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64, ctypes.c_uint32
+
+
+class GemmDesc(ctypes.Structure):
+    """Mirror of `vptr_gemm_desc` (include/vptr_hip.h)."""
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p), ("D", c_void_p), ("Dpre", c_void_p),
+        ("lda", c_int64), ("ldb", c_int64), ("ldd", c_int64),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("a_mode", c_int), ("b_mode", c_int),
+        ("precision", c_int), ("split_k", c_int), ("atomic", c_int),
+        ("colscale", c_void_p), ("bias", c_void_p),
+        ("alpha", c_float), ("act", c_int),
+        ("rowscale", c_void_p), ("rs_div", c_int), ("rs_mod", c_int),
+        ("dropout_p", c_float), ("seed_dev", c_void_p), ("site", c_uint32),
+        ("residual", c_void_p), ("ldr", c_int64),
+        ("act_after", c_int),
+        ("conv_IH", c_int), ("conv_IW", c_int), ("conv_Cin", c_int), ("conv_OH", c_int), ("conv_OW", c_int),
+        ("conv_KH", c_int), ("conv_KW", c_int), ("conv_stride", c_int), ("conv_pad", c_int), ("conv_pad_mode", c_int),
+        ("conv_transposed", c_int),
+    ]
+
+
+P, I, F, L, U = c_void_p, c_int, c_float, c_int64, c_uint32
+# name -> argument types (every function returns int and takes the stream last)
+SIGNATURES = {
+    "vptr_gemm": [ctypes.POINTER(GemmDesc), P],
+    "vptr_layernorm_fwd": [P, P, P, P, P, P, I, I, P, P, I, I, F, P],
+    "vptr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, I, P],
+    "vptr_rowmod_sum": [P, P, I, I, I, I, P],
+    "vptr_colsum": [P, P, I, I, P],
+    "vptr_add_rowtab": [P, P, P, I, I, I, I, P],
+    "vptr_winattn_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, P],
+    "vptr_winattn_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, P],
+    "vptr_tattn_fwd": [P, P, P, P, I, I, I, I, I, I, I, F, P, U, P],
+    "vptr_tattn_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, P, U, P],
+    "vptr_colstats": [P, P, P, P, I, I, P],
+    "vptr_groupstats": [P, P, P, I, I, P],
+    "vptr_norm_act_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, P, U, P, I, I, P, P],
+    "vptr_norm_act_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, P, I, I, P],
+    "vptr_dwconv3x3_fwd": [P, P, P, P, I, I, I, I, P],
+    "vptr_dwconv3x3_bwd": [P, P, P, P, P, P, I, I, I, I, P],
+    "vptr_nchw_to_tokens": [P, P, I, I, I, P],
+    "vptr_tokens_to_nchw": [P, P, I, I, I, I, P],
+    "vptr_nchw_to_tokens_masked": [P, P, P, I, I, I, P],
+    "vptr_act_bwd": [P, P, P, I, I, I, F, P, I, I, F, P, U, P],
+    "vptr_dropout": [P, P, L, F, P, U, P],
+    "vptr_rowscale": [P, P, P, I, I, I, I, P],
+    "vptr_conv7_in_fwd": [P, P, P, P, P, I, I, I, I, I, P],
+    "vptr_conv7_out_fwd": [P, P, P, P, I, I, I, I, I, I, P],
+    "vptr_conv7_out_bwd_data": [P, P, P, P, I, I, I, I, I, I, P],
+    "vptr_conv7_out_bwd_weight": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "vptr_bnrelu_bwd": [P, P, P, P, L, I, P],
+    "vptr_sumsq": [P, L, P, P],
+    "vptr_adamw": [P, P, P, P, L, F, F, F, F, F, P, P, F, F, P],
+}
+EXPORTS = sorted(list(SIGNATURES) + ["vptr_abi_version", "vptr_last_error"])
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "vptr_amd: %s is missing. Build it with `python -m vptr_amd.build` (needs hipcc, gfx950). "
+            "There is no CPU / PyTorch fallback for the VPTR hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argt in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.argtypes = argt
+        fn.restype = c_int
+    lib.vptr_abi_version.restype = c_int
+    lib.vptr_last_error.restype = ctypes.c_char_p
+    if lib.vptr_abi_version() != 1:
+        raise ImportError("vptr_amd: ABI version mismatch in %s" % LIB_PATH)
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, lib.vptr_last_error().decode()))
+
+
+def ptr(t):
+    """Raw device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("vptr_amd ops run on the MI355X only (got a %s tensor); there is no CPU fallback" % t.device)

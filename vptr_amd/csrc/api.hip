@@ -1,0 +1,16 @@
+// Error reporting and ABI version for libvptr_hip.so.
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void vptr_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* vptr_last_error(void) { return g_err; }
+extern "C" int vptr_abi_version(void) { return 1; }

@@ -1,0 +1,391 @@
+// Attention cores of the VidHRFormer blocks (gfx950): local-window attention with relative-position bias and
+// per-pixel temporal attention.  Problems are tiny (16x16 or 64x64 windows, T<=50 time steps, head_dim 66), i.e.
+// 0.4 % of the model FLOPs, so they run in exact fp32 on the vector ALUs with every tile staged once through LDS;
+// the window partition / (T, N*HW, C) permutes of the reference are pure index arithmetic here.
+#include "common.h"
+
+#define ATT_MAXL 64   // max tokens per window (ws <= 8)
+#define ATT_MAXT 64   // max time steps
+
+// ------------------------------------------------------------------------------------------------------------
+// window attention forward: block per (window, head)
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int win_row(int win, int l, int H, int W, int ws, int nqh, int nqw) {
+  const int b = win / (nqh * nqw), r = win - b * (nqh * nqw);
+  const int qh = r / nqw, qw = r - qh * nqw;
+  const int ph = l / ws, pw = l - ph * ws;
+  return (b * H + qh * ws + ph) * W + qw * ws + pw;
+}
+
+__global__ __launch_bounds__(256) void winattn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                          const float* __restrict__ v, const float* __restrict__ table,
+                                                          const int64_t* __restrict__ rel_index, float* __restrict__ o, int H,
+                                                          int W, int C, int nh, int ws, float p, const uint64_t* seed_dev,
+                                                          uint32_t site) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int L = ws * ws, hd = C / nh, hp = hd + 1, Lp = L + 1;
+  float* sq = smem;            // [L][hp]
+  float* sk = sq + L * hp;     // [L][hp]
+  float* sv = sk + L * hp;     // [L][hp]
+  float* ss = sv + L * hp;     // [L][Lp]
+  __shared__ int srow[ATT_MAXL];
+  const int win = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  const int nqh = H / ws, nqw = W / ws;
+  if (tid < L) srow[tid] = win_row(win, tid, H, W, ws, nqh, nqw);
+  __syncthreads();
+  for (int i = tid; i < L * hd; i += 256) {
+    const int l = i / hd, d = i - l * hd;
+    const int64_t g = (int64_t)srow[l] * C + h * hd + d;
+    sq[l * hp + d] = q[g];
+    sk[l * hp + d] = k[g];
+    sv[l * hp + d] = v[g];
+  }
+  __syncthreads();
+  for (int e = tid; e < L * L; e += 256) {
+    const int i = e / L, j = e - i * L;
+    float a = 0.f;
+    for (int d = 0; d < hd; ++d) a += sq[i * hp + d] * sk[j * hp + d];
+    if (table) a += table[rel_index[e] * nh + h];
+    ss[i * Lp + j] = a;
+  }
+  __syncthreads();
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  if (tid < L) {
+    float m = -INFINITY;
+    for (int j = 0; j < L; ++j) m = fmaxf(m, ss[tid * Lp + j]);
+    float s = 0.f;
+    for (int j = 0; j < L; ++j) { const float e = __expf(ss[tid * Lp + j] - m); ss[tid * Lp + j] = e; s += e; }
+    const float inv = 1.f / s;
+    for (int j = 0; j < L; ++j) {
+      float pr = ss[tid * Lp + j] * inv;
+      if (p > 0.f) pr *= vptr_drop_scale(seed, site, ((uint64_t)(win * nh + h) * L + tid) * L + j, p);
+      ss[tid * Lp + j] = pr;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < L * hd; e += 256) {
+    const int i = e / hd, d = e - i * hd;
+    float a = 0.f;
+    for (int j = 0; j < L; ++j) a += ss[i * Lp + j] * sv[j * hp + d];
+    o[(int64_t)srow[i] * C + h * hd + d] = a;
+  }
+}
+
+extern "C" int vptr_winattn_fwd(const float* q, const float* k, const float* v, const float* bias_table,
+                                const int64_t* rel_index, float* o, int B, int H, int W, int C, int nh, int ws,
+                                float dropout_p, const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream) {
+  VPTR_CHECK(B > 0 && H > 0 && W > 0 && C > 0 && nh > 0 && ws > 0, "winattn_fwd: bad arguments");
+  VPTR_CHECK(C % nh == 0, "winattn_fwd: embed_dim must be divisible by num_heads");
+  VPTR_CHECK(H % ws == 0 && W % ws == 0, "winattn_fwd: H, W must be multiples of the window size (pad on the host)");
+  VPTR_CHECK(ws * ws <= ATT_MAXL, "winattn_fwd: window too large (ws*ws <= %d)", ATT_MAXL);
+  if (bias_table) VPTR_CHECK(rel_index != nullptr, "winattn_fwd: bias table needs rel_index");
+  if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "winattn_fwd: dropout needs seed_dev");
+  const int L = ws * ws, hd = C / nh;
+  const size_t lds = sizeof(float) * (3 * L * (hd + 1) + L * (L + 1));
+  VPTR_CHECK(lds <= 160 * 1024, "winattn_fwd: LDS budget exceeded (%zu B)", lds);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)winattn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  dim3 grid(B * (H / ws) * (W / ws), nh);
+  winattn_fwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(q, k, v, bias_table, rel_index, o, H, W, C, nh, ws, dropout_p,
+                                                             seed_dev, site);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// window attention backward: block per (chunk of windows, head); bias-table gradient reduced in LDS first.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void winattn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                          const float* __restrict__ v, const float* __restrict__ table,
+                                                          const int64_t* __restrict__ rel_index, const float* __restrict__ dout,
+                                                          float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+                                                          float* __restrict__ dtable, int nwin, int H, int W, int C, int nh,
+                                                          int ws, float p, const uint64_t* seed_dev, uint32_t site, int wpb) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int L = ws * ws, hd = C / nh, hp = hd + 1, Lp = L + 1;
+  const int ntab = (2 * ws - 1) * (2 * ws - 1);
+  float* sq = smem;
+  float* sk = sq + L * hp;
+  float* sv = sk + L * hp;
+  float* sdo = sv + L * hp;   // [L][hp]
+  float* sp = sdo + L * hp;   // [L][Lp]  probabilities (incl. dropout scale)
+  float* sds = sp + L * Lp;   // [L][Lp]  dP then dS
+  float* stab = sds + L * Lp; // [ntab]
+  __shared__ int srow[ATT_MAXL];
+  const int h = blockIdx.y, tid = threadIdx.x;
+  const int nqh = H / ws, nqw = W / ws;
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  for (int i = tid; i < ntab; i += 256) stab[i] = 0.f;
+  const int w0 = blockIdx.x * wpb, w1 = min(nwin, w0 + wpb);
+  for (int win = w0; win < w1; ++win) {
+    __syncthreads();
+    if (tid < L) srow[tid] = win_row(win, tid, H, W, ws, nqh, nqw);
+    __syncthreads();
+    for (int i = tid; i < L * hd; i += 256) {
+      const int l = i / hd, d = i - l * hd;
+      const int64_t g = (int64_t)srow[l] * C + h * hd + d;
+      sq[l * hp + d] = q[g];
+      sk[l * hp + d] = k[g];
+      sv[l * hp + d] = v[g];
+      sdo[l * hp + d] = dout[g];
+    }
+    __syncthreads();
+    for (int e = tid; e < L * L; e += 256) {
+      const int i = e / L, j = e - i * L;
+      float a = 0.f, b = 0.f;
+      for (int d = 0; d < hd; ++d) {
+        a += sq[i * hp + d] * sk[j * hp + d];
+        b += sdo[i * hp + d] * sv[j * hp + d];
+      }
+      if (table) a += table[rel_index[e] * nh + h];
+      sp[i * Lp + j] = a;
+      sds[i * Lp + j] = b;  // dP (w.r.t. the dropped probabilities)
+    }
+    __syncthreads();
+    if (tid < L) {
+      float m = -INFINITY;
+      for (int j = 0; j < L; ++j) m = fmaxf(m, sp[tid * Lp + j]);
+      float s = 0.f;
+      for (int j = 0; j < L; ++j) { const float e = __expf(sp[tid * Lp + j] - m); sp[tid * Lp + j] = e; s += e; }
+      const float inv = 1.f / s;
+      float dot = 0.f;
+      for (int j = 0; j < L; ++j) {
+        const float pr = sp[tid * Lp + j] * inv;  // softmax prob
+        float sc = 1.f;
+        if (p > 0.f) sc = vptr_drop_scale(seed, site, ((uint64_t)(win * nh + h) * L + tid) * L + j, p);
+        const float dpr = sds[tid * Lp + j] * sc;  // grad wrt softmax prob
+        dot += dpr * pr;
+        sds[tid * Lp + j] = dpr;
+        sp[tid * Lp + j] = pr;
+      }
+      for (int j = 0; j < L; ++j) {
+        const float pr = sp[tid * Lp + j];
+        float sc = 1.f;
+        if (p > 0.f) sc = vptr_drop_scale(seed, site, ((uint64_t)(win * nh + h) * L + tid) * L + j, p);
+        sds[tid * Lp + j] = pr * (sds[tid * Lp + j] - dot);  // dS
+        sp[tid * Lp + j] = pr * sc;                          // dropped prob for dV
+      }
+    }
+    __syncthreads();
+    if (dtable)
+      for (int e = tid; e < L * L; e += 256) atomicAdd(&stab[(int)rel_index[e]], sds[(e / L) * Lp + (e % L)]);
+    for (int e = tid; e < L * hd; e += 256) {
+      const int i = e / hd, d = e - i * hd;
+      float aq = 0.f, ak = 0.f, av = 0.f;
+      for (int j = 0; j < L; ++j) {
+        aq += sds[i * Lp + j] * sk[j * hp + d];
+        ak += sds[j * Lp + i] * sq[j * hp + d];
+        av += sp[j * Lp + i] * sdo[j * hp + d];
+      }
+      const int64_t g = (int64_t)srow[i] * C + h * hd + d;
+      dq[g] = aq;
+      dk[g] = ak;
+      dv[g] = av;
+    }
+  }
+  __syncthreads();
+  if (dtable)
+    for (int i = tid; i < ntab; i += 256) unsafeAtomicAdd(dtable + (int64_t)i * nh + h, stab[i]);
+}
+
+extern "C" int vptr_winattn_bwd(const float* q, const float* k, const float* v, const float* bias_table,
+                                const int64_t* rel_index, const float* dout, float* dq, float* dk, float* dv,
+                                float* dbias_table, int B, int H, int W, int C, int nh, int ws, float dropout_p,
+                                const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream) {
+  VPTR_CHECK(B > 0 && H > 0 && W > 0 && C > 0 && nh > 0 && ws > 0, "winattn_bwd: bad arguments");
+  VPTR_CHECK(C % nh == 0 && H % ws == 0 && W % ws == 0 && ws * ws <= ATT_MAXL, "winattn_bwd: unsupported geometry");
+  if (bias_table || dbias_table) VPTR_CHECK(rel_index != nullptr, "winattn_bwd: bias table needs rel_index");
+  if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "winattn_bwd: dropout needs seed_dev");
+  const int L = ws * ws, hd = C / nh, ntab = (2 * ws - 1) * (2 * ws - 1);
+  const size_t lds = sizeof(float) * (4 * L * (hd + 1) + 2 * L * (L + 1) + ntab);
+  VPTR_CHECK(lds <= 160 * 1024, "winattn_bwd: LDS budget exceeded (%zu B)", lds);
+  const int nwin = B * (H / ws) * (W / ws);
+  const int wpb = nwin >= 2048 ? 4 : 1;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)winattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  winattn_bwd_kernel<<<dim3(cdiv(nwin, wpb), nh), 256, lds, (hipStream_t)stream>>>(q, k, v, bias_table, rel_index, dout, dq, dk, dv,
+                                                                                 dbias_table, nwin, H, W, C, nh, ws, dropout_p,
+                                                                                 seed_dev, site, wpb);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// temporal attention: one wave per (n, pixel, head); rows of (n, t, pixel) are (n*T + t)*HW + pixel.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void tattn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, float* __restrict__ o, int Tq, int Tk,
+                                                       int HW, int C, int nh, int causal, float p, const uint64_t* seed_dev,
+                                                       uint32_t site) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int hd = C / nh, hp = hd + 1, Tp = Tk + 1;
+  float* sq = smem;             // [Tq][hp]
+  float* sk = sq + Tq * hp;     // [Tk][hp]
+  float* sv = sk + Tk * hp;     // [Tk][hp]
+  float* ss = sv + Tk * hp;     // [Tq][Tp]
+  const int np = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+  const int n = np / HW, pix = np - n * HW;
+  for (int i = lane; i < Tq * hd; i += 64) {
+    const int t = i / hd, d = i - t * hd;
+    sq[t * hp + d] = q[((int64_t)(n * Tq + t) * HW + pix) * C + h * hd + d];
+  }
+  for (int i = lane; i < Tk * hd; i += 64) {
+    const int t = i / hd, d = i - t * hd;
+    const int64_t g = ((int64_t)(n * Tk + t) * HW + pix) * C + h * hd + d;
+    sk[t * hp + d] = k[g];
+    sv[t * hp + d] = v[g];
+  }
+  __syncthreads();
+  for (int e = lane; e < Tq * Tk; e += 64) {
+    const int i = e / Tk, j = e - i * Tk;
+    float a = 0.f;
+    for (int d = 0; d < hd; ++d) a += sq[i * hp + d] * sk[j * hp + d];
+    if (causal && j > i) a = -INFINITY;
+    ss[i * Tp + j] = a;
+  }
+  __syncthreads();
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  for (int i = lane; i < Tq; i += 64) {
+    float m = -INFINITY;
+    for (int j = 0; j < Tk; ++j) m = fmaxf(m, ss[i * Tp + j]);
+    float s = 0.f;
+    for (int j = 0; j < Tk; ++j) { const float e = __expf(ss[i * Tp + j] - m); ss[i * Tp + j] = e; s += e; }
+    const float inv = 1.f / s;
+    for (int j = 0; j < Tk; ++j) {
+      float pr = ss[i * Tp + j] * inv;
+      if (p > 0.f) pr *= vptr_drop_scale(seed, site, (((uint64_t)np * nh + h) * Tq + i) * Tk + j, p);
+      ss[i * Tp + j] = pr;
+    }
+  }
+  __syncthreads();
+  for (int e = lane; e < Tq * hd; e += 64) {
+    const int i = e / hd, d = e - i * hd;
+    float a = 0.f;
+    for (int j = 0; j < Tk; ++j) a += ss[i * Tp + j] * sv[j * hp + d];
+    o[((int64_t)(n * Tq + i) * HW + pix) * C + h * hd + d] = a;
+  }
+}
+
+extern "C" int vptr_tattn_fwd(const float* q, const float* k, const float* v, float* o, int Nb, int Tq, int Tk, int HW, int C,
+                              int nh, int causal, float dropout_p, const uint64_t* seed_dev, uint32_t site,
+                              vptr_stream_t stream) {
+  VPTR_CHECK(Nb > 0 && Tq > 0 && Tk > 0 && HW > 0 && C > 0 && nh > 0, "tattn_fwd: bad arguments");
+  VPTR_CHECK(C % nh == 0, "tattn_fwd: embed_dim must be divisible by num_heads");
+  VPTR_CHECK(Tq <= ATT_MAXT && Tk <= ATT_MAXT, "tattn_fwd: T must be <= %d", ATT_MAXT);
+  if (causal) VPTR_CHECK(Tq == Tk, "tattn_fwd: causal mask needs Tq == Tk");
+  if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "tattn_fwd: dropout needs seed_dev");
+  const int hd = C / nh;
+  const size_t lds = sizeof(float) * ((Tq + 2 * Tk) * (hd + 1) + Tq * (Tk + 1));
+  VPTR_CHECK(lds <= 64 * 1024, "tattn_fwd: LDS budget exceeded (%zu B)", lds);
+  tattn_fwd_kernel<<<dim3(Nb * HW, nh), 64, lds, (hipStream_t)stream>>>(q, k, v, o, Tq, Tk, HW, C, nh, causal, dropout_p, seed_dev,
+                                                                       site);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(64) void tattn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, const float* __restrict__ dout,
+                                                       float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+                                                       int Tq, int Tk, int HW, int C, int nh, int causal, float p,
+                                                       const uint64_t* seed_dev, uint32_t site) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int hd = C / nh, hp = hd + 1, Tp = Tk + 1;
+  float* sq = smem;              // [Tq][hp]
+  float* sdo = sq + Tq * hp;     // [Tq][hp]
+  float* sk = sdo + Tq * hp;     // [Tk][hp]
+  float* sv = sk + Tk * hp;      // [Tk][hp]
+  float* sp = sv + Tk * hp;      // [Tq][Tp]
+  float* sds = sp + Tq * Tp;     // [Tq][Tp]
+  const int np = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+  const int n = np / HW, pix = np - n * HW;
+  for (int i = lane; i < Tq * hd; i += 64) {
+    const int t = i / hd, d = i - t * hd;
+    const int64_t g = ((int64_t)(n * Tq + t) * HW + pix) * C + h * hd + d;
+    sq[t * hp + d] = q[g];
+    sdo[t * hp + d] = dout[g];
+  }
+  for (int i = lane; i < Tk * hd; i += 64) {
+    const int t = i / hd, d = i - t * hd;
+    const int64_t g = ((int64_t)(n * Tk + t) * HW + pix) * C + h * hd + d;
+    sk[t * hp + d] = k[g];
+    sv[t * hp + d] = v[g];
+  }
+  __syncthreads();
+  for (int e = lane; e < Tq * Tk; e += 64) {
+    const int i = e / Tk, j = e - i * Tk;
+    float a = 0.f, b = 0.f;
+    for (int d = 0; d < hd; ++d) {
+      a += sq[i * hp + d] * sk[j * hp + d];
+      b += sdo[i * hp + d] * sv[j * hp + d];
+    }
+    if (causal && j > i) a = -INFINITY;
+    sp[i * Tp + j] = a;
+    sds[i * Tp + j] = b;
+  }
+  __syncthreads();
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  for (int i = lane; i < Tq; i += 64) {
+    float m = -INFINITY;
+    for (int j = 0; j < Tk; ++j) m = fmaxf(m, sp[i * Tp + j]);
+    float s = 0.f;
+    for (int j = 0; j < Tk; ++j) { const float e = __expf(sp[i * Tp + j] - m); sp[i * Tp + j] = e; s += e; }
+    const float inv = 1.f / s;
+    float dot = 0.f;
+    for (int j = 0; j < Tk; ++j) {
+      const float pr = sp[i * Tp + j] * inv;
+      float sc = 1.f;
+      if (p > 0.f) sc = vptr_drop_scale(seed, site, (((uint64_t)np * nh + h) * Tq + i) * Tk + j, p);
+      const float dpr = sds[i * Tp + j] * sc;
+      dot += dpr * pr;
+      sds[i * Tp + j] = dpr;
+      sp[i * Tp + j] = pr;
+    }
+    for (int j = 0; j < Tk; ++j) {
+      const float pr = sp[i * Tp + j];
+      float sc = 1.f;
+      if (p > 0.f) sc = vptr_drop_scale(seed, site, (((uint64_t)np * nh + h) * Tq + i) * Tk + j, p);
+      sds[i * Tp + j] = pr * (sds[i * Tp + j] - dot);
+      sp[i * Tp + j] = pr * sc;
+    }
+  }
+  __syncthreads();
+  for (int e = lane; e < Tq * hd; e += 64) {
+    const int i = e / hd, d = e - i * hd;
+    float a = 0.f;
+    for (int j = 0; j < Tk; ++j) a += sds[i * Tp + j] * sk[j * hp + d];
+    dq[((int64_t)(n * Tq + i) * HW + pix) * C + h * hd + d] = a;
+  }
+  for (int e = lane; e < Tk * hd; e += 64) {
+    const int j = e / hd, d = e - j * hd;
+    float ak = 0.f, av = 0.f;
+    for (int i = 0; i < Tq; ++i) {
+      ak += sds[i * Tp + j] * sq[i * hp + d];
+      av += sp[i * Tp + j] * sdo[i * hp + d];
+    }
+    const int64_t g = ((int64_t)(n * Tk + j) * HW + pix) * C + h * hd + d;
+    dk[g] = ak;
+    dv[g] = av;
+  }
+}
+
+extern "C" int vptr_tattn_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,
+                              float* dv, int Nb, int Tq, int Tk, int HW, int C, int nh, int causal, float dropout_p,
+                              const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream) {
+  VPTR_CHECK(Nb > 0 && Tq > 0 && Tk > 0 && HW > 0 && C > 0 && nh > 0, "tattn_bwd: bad arguments");
+  VPTR_CHECK(C % nh == 0 && Tq <= ATT_MAXT && Tk <= ATT_MAXT, "tattn_bwd: unsupported geometry");
+  if (causal) VPTR_CHECK(Tq == Tk, "tattn_bwd: causal mask needs Tq == Tk");
+  if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "tattn_bwd: dropout needs seed_dev");
+  const int hd = C / nh;
+  const size_t lds = sizeof(float) * (2 * (Tq + Tk) * (hd + 1) + 2 * Tq * (Tk + 1));
+  VPTR_CHECK(lds <= 160 * 1024, "tattn_bwd: LDS budget exceeded (%zu B)", lds);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)tattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  tattn_bwd_kernel<<<dim3(Nb * HW, nh), 64, lds, (hipStream_t)stream>>>(q, k, v, dout, dq, dk, dv, Tq, Tk, HW, C, nh, causal,
+                                                                       dropout_p, seed_dev, site);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,86 @@
+// Shared device helpers for the VPTR HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/vptr_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+void vptr_set_error(const char* fmt, ...);
+
+#define VPTR_CHECK(cond, ...)       \
+  do {                              \
+    if (!(cond)) {                  \
+      vptr_set_error(__VA_ARGS__);  \
+      return -1;                    \
+    }                               \
+  } while (0)
+
+#define VPTR_LAUNCH_CHECK()                                                      \
+  do {                                                                           \
+    hipError_t e_ = hipGetLastError();                                           \
+    if (e_ != hipSuccess) {                                                      \
+      vptr_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return -2;                                                                 \
+    }                                                                            \
+  } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int64_t hmin64(int64_t a, int64_t b) { return a < b ? a : b; }
+
+// ---- counter-based dropout mask: one 32-bit hash per element ------------------------------------
+__device__ __forceinline__ uint32_t vptr_hash3(uint64_t seed, uint32_t site, uint64_t idx) {
+  uint64_t x = seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(site + 1)) ^ (idx * 0xD1B54A32D192ED03ull);
+  x ^= x >> 32;
+  x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  return (uint32_t)x;
+}
+// returns 1/keep if kept, 0 if dropped
+__device__ __forceinline__ float vptr_drop_scale(uint64_t seed, uint32_t site, uint64_t idx, float p) {
+  uint32_t h = vptr_hash3(seed, site, idx);
+  uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+  return (h >= thr) ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+// ---- activations --------------------------------------------------------------------------------
+__device__ __forceinline__ float vptr_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float vptr_gelu_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float vptr_act(float v, int act) {
+  if (act == VPTR_ACT_GELU) return vptr_gelu(v);
+  if (act == VPTR_ACT_RELU) return v > 0.f ? v : 0.f;
+  return v;
+}
+
+// ---- wave / block reductions (wave = 64) ----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` is >= 16 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}

@@ -1,0 +1,269 @@
+// Direct 7x7 convolutions at the two ends of the ResNet auto-encoder (gfx950).
+//   conv7_in : ReflectionPad2d(3) + Conv7x7(Cimg -> Cout) + folded BN + ReLU    (ResNetAutoEncoder.py:26-29)
+//   conv7_out: ReflectionPad2d(3) + Conv7x7(Cin -> Cimg) + bias + Tanh/Sigmoid  (ResNetAutoEncoder.py:89-96)
+// K is tiny on one side (Cimg = 1 or 3), so these are not MFMA-shaped: they run on the vector ALUs with the filter
+// bank staged in LDS and channel-last (NHWC) stores/loads arranged so that a wave touches contiguous 1-4 KB runs.
+#include "common.h"
+
+__device__ __forceinline__ int reflect_idx(int c, int n) { return c < 0 ? -c : (c >= n ? 2 * n - 2 - c : c); }
+
+// thread = (pixel, group of 16 output channels); block = 64 pixels x 4 groups (Cout must be 64)
+__global__ __launch_bounds__(256) void conv7_in_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           float* __restrict__ y, int B, int Cimg, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [Cimg*49][64]
+  const int tid = threadIdx.x;
+  const int K = Cimg * 49;
+  for (int i = tid; i < K * 64; i += 256) {
+    const int kk = i >> 6, co = i & 63;
+    sw[i] = w[co * K + kk];
+  }
+  __syncthreads();
+  const int cg = tid & 3;
+  const int64_t pix = (int64_t)blockIdx.x * 64 + (tid >> 2);
+  const int64_t npix = (int64_t)B * H * W;
+  if (pix >= npix) return;
+  const int ox = (int)(pix % W), oy = (int)((pix / W) % H);
+  const int b = (int)(pix / ((int64_t)W * H));
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int ci = 0; ci < Cimg; ++ci) {
+    const float* xp = x + ((int64_t)b * Cimg + ci) * H * W;
+    for (int ky = 0; ky < 7; ++ky) {
+      const int iy = reflect_idx(oy + ky - 3, H);
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        const int ix = reflect_idx(ox + kx - 3, W);
+        const float xv = xp[iy * W + ix];
+        const float4* wp = reinterpret_cast<const float4*>(sw + ((ci * 49 + ky * 7 + kx) << 6) + cg * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 wv = wp[j];
+          acc[j * 4 + 0] += xv * wv.x; acc[j * 4 + 1] += xv * wv.y;
+          acc[j * 4 + 2] += xv * wv.z; acc[j * 4 + 3] += xv * wv.w;
+        }
+      }
+    }
+  }
+  float4* yp = reinterpret_cast<float4*>(y + pix * 64 + cg * 16);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = cg * 16 + j * 4;
+    float4 o;
+    o.x = fmaxf(acc[j * 4 + 0] * scale[c + 0] + shift[c + 0], 0.f);
+    o.y = fmaxf(acc[j * 4 + 1] * scale[c + 1] + shift[c + 1], 0.f);
+    o.z = fmaxf(acc[j * 4 + 2] * scale[c + 2] + shift[c + 2], 0.f);
+    o.w = fmaxf(acc[j * 4 + 3] * scale[c + 3] + shift[c + 3], 0.f);
+    yp[j] = o;
+  }
+}
+
+extern "C" int vptr_conv7_in_fwd(const float* x, const float* w, const float* scale, const float* shift, float* y, int B,
+                                 int Cimg, int H, int W, int Cout, vptr_stream_t stream) {
+  VPTR_CHECK(B > 0 && Cimg > 0 && H > 3 && W > 3, "conv7_in_fwd: bad arguments");
+  VPTR_CHECK(Cout == 64, "conv7_in_fwd: Cout must be 64 (ngf of the reference encoder), got %d", Cout);
+  const size_t lds = sizeof(float) * Cimg * 49 * 64;
+  VPTR_CHECK(lds <= 64 * 1024, "conv7_in_fwd: too many image channels");
+  const int64_t npix = (int64_t)B * H * W;
+  conv7_in_fwd_kernel<<<cdiv(npix, 64), 256, lds, (hipStream_t)stream>>>(x, w, scale, shift, y, B, Cimg, H, W);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// thread per output pixel; filter [Cimg][49][Cin] in LDS, broadcast float4 reads
+__global__ __launch_bounds__(256) void conv7_out_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                            int Cin, int H, int W, int Cimg, int out_act) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [Cimg][49][Cin]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < Cimg * 49 * Cin; i += 256) {
+    const int ci = i % Cin, tap = (i / Cin) % 49, co = i / (Cin * 49);
+    sw[i] = w[(co * Cin + ci) * 49 + tap];
+  }
+  __syncthreads();
+  const int64_t pix = (int64_t)blockIdx.x * 256 + tid;
+  const int64_t npix = (int64_t)B * H * W;
+  if (pix >= npix) return;
+  const int ox = (int)(pix % W), oy = (int)((pix / W) % H);
+  const int b = (int)(pix / ((int64_t)W * H));
+  const int C4 = Cin >> 2;
+  for (int co = 0; co < Cimg; ++co) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int ky = 0; ky < 7; ++ky) {
+      const int iy = reflect_idx(oy + ky - 3, H);
+      for (int kx = 0; kx < 7; ++kx) {
+        const int ix = reflect_idx(ox + kx - 3, W);
+        const float4* xp = reinterpret_cast<const float4*>(x + (((int64_t)b * H + iy) * W + ix) * Cin);
+        const float4* wp = reinterpret_cast<const float4*>(sw + (co * 49 + ky * 7 + kx) * Cin);
+        for (int c = 0; c < C4; ++c) {
+          const float4 xv = xp[c], wv = wp[c];
+          a0 += xv.x * wv.x; a1 += xv.y * wv.y; a2 += xv.z * wv.z; a3 += xv.w * wv.w;
+        }
+      }
+    }
+    float v = (a0 + a1) + (a2 + a3) + bias[co];
+    if (out_act == 1) v = tanhf(v);
+    else if (out_act == 2) v = 1.f / (1.f + __expf(-v));
+    y[(((int64_t)b * Cimg + co) * H + oy) * W + ox] = v;
+  }
+}
+
+extern "C" int vptr_conv7_out_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
+                                  int Cimg, int out_act, vptr_stream_t stream) {
+  VPTR_CHECK(B > 0 && Cin > 0 && Cin % 4 == 0 && H > 3 && W > 3 && Cimg > 0, "conv7_out_fwd: bad arguments");
+  const size_t lds = sizeof(float) * Cimg * 49 * Cin;
+  VPTR_CHECK(lds <= 64 * 1024, "conv7_out_fwd: filter bank too large for LDS");
+  const int64_t npix = (int64_t)B * H * W;
+  conv7_out_fwd_kernel<<<cdiv(npix, 256), 256, lds, (hipStream_t)stream>>>(x, w, bias, y, B, Cin, H, W, Cimg, out_act);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+__device__ __forceinline__ float out_act_grad(float dy, float y, int out_act) {
+  if (out_act == 1) return dy * (1.f - y * y);
+  if (out_act == 2) return dy * y * (1.f - y);
+  return dy;
+}
+
+// backward-data of conv7_out: thread = (input pixel, 16-channel group).  With reflection padding an input pixel
+// (iy, ix) is the image of up to 2x2 padded positions; each padded position py feeds outputs oy = py + 3 - ky.
+__global__ __launch_bounds__(256) void conv7_out_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                 const float* __restrict__ w, float* __restrict__ dx, int B,
+                                                                 int Cin, int H, int W, int Cimg, int out_act) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [Cimg][49][Cin]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < Cimg * 49 * Cin; i += 256) {
+    const int ci = i % Cin, tap = (i / Cin) % 49, co = i / (Cin * 49);
+    sw[i] = w[(co * Cin + ci) * 49 + tap];
+  }
+  __syncthreads();
+  const int ngrp = Cin >> 4;
+  const int cg = tid % ngrp;
+  const int64_t pix = (int64_t)blockIdx.x * (256 / ngrp) + tid / ngrp;
+  const int64_t npix = (int64_t)B * H * W;
+  if (pix >= npix || tid / ngrp >= 256 / ngrp) return;
+  const int ix = (int)(pix % W), iy = (int)((pix / W) % H);
+  const int b = (int)(pix / ((int64_t)W * H));
+  int pys[3], pxs[3], npy = 1, npx = 1;
+  pys[0] = iy; pxs[0] = ix;
+  if (iy >= 1 && iy <= 3) pys[npy++] = -iy;
+  if (iy <= H - 2 && iy >= H - 4) pys[npy++] = 2 * (H - 1) - iy;
+  if (ix >= 1 && ix <= 3) pxs[npx++] = -ix;
+  if (ix <= W - 2 && ix >= W - 4) pxs[npx++] = 2 * (W - 1) - ix;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int co = 0; co < Cimg; ++co) {
+    const float* dyp = dy + ((int64_t)b * Cimg + co) * H * W;
+    const float* yp = y + ((int64_t)b * Cimg + co) * H * W;
+    for (int a = 0; a < npy; ++a)
+      for (int ky = 0; ky < 7; ++ky) {
+        const int oy = pys[a] + 3 - ky;
+        if (oy < 0 || oy >= H) continue;
+        for (int c = 0; c < npx; ++c)
+          for (int kx = 0; kx < 7; ++kx) {
+            const int ox = pxs[c] + 3 - kx;
+            if (ox < 0 || ox >= W) continue;
+            const float g = out_act_grad(dyp[oy * W + ox], yp[oy * W + ox], out_act);
+            const float4* wp = reinterpret_cast<const float4*>(sw + (co * 49 + ky * 7 + kx) * Cin + cg * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float4 wv = wp[j];
+              acc[j * 4 + 0] += g * wv.x; acc[j * 4 + 1] += g * wv.y;
+              acc[j * 4 + 2] += g * wv.z; acc[j * 4 + 3] += g * wv.w;
+            }
+          }
+      }
+  }
+  float4* dp = reinterpret_cast<float4*>(dx + pix * Cin + cg * 16);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dp[j] = make_float4(acc[j * 4 + 0], acc[j * 4 + 1], acc[j * 4 + 2], acc[j * 4 + 3]);
+}
+
+extern "C" int vptr_conv7_out_bwd_data(const float* dy, const float* y, const float* w, float* dx, int B, int Cin, int H, int W,
+                                       int Cimg, int out_act, vptr_stream_t stream) {
+  VPTR_CHECK(B > 0 && Cin > 0 && Cin % 16 == 0 && 256 % (Cin / 16) == 0 && H > 6 && W > 6 && Cimg > 0,
+             "conv7_out_bwd_data: bad arguments");
+  const size_t lds = sizeof(float) * Cimg * 49 * Cin;
+  VPTR_CHECK(lds <= 64 * 1024, "conv7_out_bwd_data: filter bank too large for LDS");
+  const int64_t npix = (int64_t)B * H * W;
+  const int ppb = 256 / (Cin / 16);
+  conv7_out_bwd_data_kernel<<<cdiv(npix, ppb), 256, lds, (hipStream_t)stream>>>(dy, y, w, dx, B, Cin, H, W, Cimg, out_act);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// backward-weight of conv7_out: block = (8x8 output tile sweep over a chunk of frames); thread = (ci, tap group).
+// The x tile with its 3-pixel reflected halo and the activation-gradient tile are staged in LDS.
+__global__ __launch_bounds__(256) void conv7_out_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                   const float* __restrict__ x, float* __restrict__ dw,
+                                                                   float* __restrict__ db, int B, int Cin, int H, int W,
+                                                                   int Cimg, int out_act, int frames_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sx = smem;                    // [14*14][Cin]
+  float* sg = sx + 14 * 14 * Cin;      // [Cimg][64]
+  __shared__ float red[16];
+  const int tid = threadIdx.x;
+  const int ci = tid % Cin;
+  const int tg = tid / Cin, ntg = 256 / Cin;  // tap groups
+  const int tiles_x = W / 8, tiles_y = H / 8;
+  const int ty = (blockIdx.x / tiles_x) % tiles_y, tx = blockIdx.x % tiles_x;
+  const int b0 = blockIdx.y * frames_per_block, b1 = min(B, b0 + frames_per_block);
+  constexpr int MAXT = 13;  // taps per thread when ntg = 4 (49 / 4 rounded up)
+  float acc[3][MAXT];
+#pragma unroll
+  for (int co = 0; co < 3; ++co)
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[co][t] = 0.f;
+  float bsum[3] = {0.f, 0.f, 0.f};
+  for (int b = b0; b < b1; ++b) {
+    __syncthreads();
+    for (int i = tid; i < 14 * 14 * Cin; i += 256) {
+      const int c = i % Cin, p = i / Cin;
+      const int iy = reflect_idx(ty * 8 + p / 14 - 3, H), ix = reflect_idx(tx * 8 + p % 14 - 3, W);
+      sx[i] = x[(((int64_t)b * H + iy) * W + ix) * Cin + c];
+    }
+    for (int i = tid; i < Cimg * 64; i += 256) {
+      const int co = i >> 6, p = i & 63;
+      const int64_t o = (((int64_t)b * Cimg + co) * H + ty * 8 + (p >> 3)) * W + tx * 8 + (p & 7);
+      sg[i] = out_act_grad(dy[o], y[o], out_act);
+    }
+    __syncthreads();
+    for (int co = 0; co < Cimg; ++co) {
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        const int tap = tg + t * ntg;
+        if (tap < 49 && tg < ntg) {
+          const int ky = tap / 7, kx = tap - ky * 7;
+          float a = 0.f;
+          for (int p = 0; p < 64; ++p) a += sg[co * 64 + p] * sx[(((p >> 3) + ky) * 14 + (p & 7) + kx) * Cin + ci];
+          acc[co][t] += a;
+        }
+      }
+      float gs = 0.f;
+      if (tid < 64) gs = sg[co * 64 + tid];
+      gs = block_sum(gs, red);
+      bsum[co] += gs;
+    }
+  }
+  for (int co = 0; co < Cimg; ++co) {
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int tap = tg + t * ntg;
+      if (tap < 49 && tg < ntg) unsafeAtomicAdd(dw + ((int64_t)co * Cin + ci) * 49 + tap, acc[co][t]);
+    }
+    if (tid == 0) unsafeAtomicAdd(db + co, bsum[co]);
+  }
+}
+
+extern "C" int vptr_conv7_out_bwd_weight(const float* dy, const float* y, const float* x, float* dw, float* db, int B, int Cin,
+                                         int H, int W, int Cimg, int out_act, vptr_stream_t stream) {
+  VPTR_CHECK(B > 0 && Cin == 64 && H % 8 == 0 && W % 8 == 0 && Cimg >= 1 && Cimg <= 3, "conv7_out_bwd_weight: unsupported geometry");
+  const size_t lds = sizeof(float) * (14 * 14 * Cin + Cimg * 64);
+  const int fpb = 4;
+  dim3 grid((H / 8) * (W / 8), cdiv(B, fpb));
+  conv7_out_bwd_weight_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(dy, y, x, dw, db, B, Cin, H, W, Cimg, out_act, fpb);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,198 @@
+// Layout and elementwise helpers (gfx950): NCHW <-> token-major transposes through LDS, activation backward,
+// standalone dropout, row scaling, folded-BN/ReLU backward, and the clip + AdamW optimizer step.  All HBM-bound.
+#include "common.h"
+
+// [B, R, S] -> [B, S, R] tiled transpose, 32x32 tiles via LDS (+1 pad), 256 threads.
+// mode 0: plain; 1: relu on output; 2: mask by (aux > 0) where aux has the SOURCE layout.
+template <int MODE>
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, const float* __restrict__ aux,
+                                                        float* __restrict__ dst, int R, int S) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, s0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* sb = src + (int64_t)b * R * S;
+  const float* ab = (MODE == 2) ? aux + (int64_t)b * R * S : nullptr;
+  float* db = dst + (int64_t)b * R * S;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + i * 8, s = s0 + tx;
+    float v = 0.f;
+    if (r < R && s < S) {
+      v = sb[(int64_t)r * S + s];
+      if (MODE == 2) v = ab[(int64_t)r * S + s] > 0.f ? v : 0.f;
+    }
+    tile[ty + i * 8][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int s = s0 + ty + i * 8, r = r0 + tx;
+    if (r < R && s < S) {
+      float v = tile[tx][ty + i * 8];
+      if (MODE == 1) v = v > 0.f ? v : 0.f;
+      db[(int64_t)s * R + r] = v;
+    }
+  }
+}
+
+static void launch_transpose(const float* src, const float* aux, float* dst, int B, int R, int S, int mode, hipStream_t st) {
+  dim3 grid(cdiv(S, 32), cdiv(R, 32), B);
+  if (mode == 0) transpose_kernel<0><<<grid, 256, 0, st>>>(src, aux, dst, R, S);
+  else if (mode == 1) transpose_kernel<1><<<grid, 256, 0, st>>>(src, aux, dst, R, S);
+  else transpose_kernel<2><<<grid, 256, 0, st>>>(src, aux, dst, R, S);
+}
+
+extern "C" int vptr_nchw_to_tokens(const float* src, float* dst, int B, int C, int HW, vptr_stream_t stream) {
+  VPTR_CHECK(B > 0 && C > 0 && HW > 0, "nchw_to_tokens: bad arguments");
+  launch_transpose(src, nullptr, dst, B, C, HW, 0, (hipStream_t)stream);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vptr_tokens_to_nchw(const float* src, float* dst, int B, int C, int HW, int relu, vptr_stream_t stream) {
+  VPTR_CHECK(B > 0 && C > 0 && HW > 0, "tokens_to_nchw: bad arguments");
+  launch_transpose(src, nullptr, dst, B, HW, C, relu ? 1 : 0, (hipStream_t)stream);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vptr_nchw_to_tokens_masked(const float* dout, const float* out, float* dtok, int B, int C, int HW,
+                                          vptr_stream_t stream) {
+  VPTR_CHECK(B > 0 && C > 0 && HW > 0, "nchw_to_tokens_masked: bad arguments");
+  launch_transpose(dout, out, dtok, B, C, HW, 2, (hipStream_t)stream);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ h,
+                                                      float* __restrict__ dx, int rows, int C, int act, float alpha,
+                                                      const float* __restrict__ rowscale, int rs_div, int rs_mod, float p,
+                                                      const uint64_t* seed_dev, uint32_t site) {
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  const int64_t n = (int64_t)rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float g = dy[i] * alpha;
+    if (p > 0.f) g *= vptr_drop_scale(seed, site, (uint64_t)i, p);
+    if (rowscale) g *= rowscale[((int)(i / C) / rs_div) % rs_mod];
+    if (act == VPTR_ACT_GELU) g *= vptr_gelu_grad(h[i]);
+    else if (act == VPTR_ACT_RELU) g = h[i] > 0.f ? g : 0.f;
+    dx[i] = g;
+  }
+}
+extern "C" int vptr_act_bwd(const float* dy, const float* h, float* dx, int rows, int C, int act, float alpha,
+                            const float* rowscale, int rs_div, int rs_mod, float dropout_p, const uint64_t* seed_dev,
+                            uint32_t site, vptr_stream_t stream) {
+  VPTR_CHECK(rows > 0 && C > 0, "act_bwd: empty input");
+  if (act != VPTR_ACT_NONE) VPTR_CHECK(h != nullptr, "act_bwd: activation backward needs the saved pre-activation");
+  if (rowscale) VPTR_CHECK(rs_div >= 1 && rs_mod >= 1, "act_bwd: rowscale needs rs_div, rs_mod >= 1");
+  if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "act_bwd: dropout needs seed_dev");
+  const int64_t n = (int64_t)rows * C;
+  const int blocks = (int)hmin64((n + 255) / 256, 8192);
+  act_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dy, h, dx, rows, C, act, alpha, rowscale, rs_div, rs_mod, dropout_p,
+                                                         seed_dev, site);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p,
+                                                      const uint64_t* seed_dev, uint32_t site) {
+  const uint64_t seed = *seed_dev;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = x[i] * vptr_drop_scale(seed, site, (uint64_t)i, p);
+}
+extern "C" int vptr_dropout(const float* x, float* y, int64_t n, float dropout_p, const uint64_t* seed_dev, uint32_t site,
+                            vptr_stream_t stream) {
+  VPTR_CHECK(n > 0 && seed_dev && dropout_p > 0.f && dropout_p < 1.f, "dropout: bad arguments");
+  const int blocks = (int)hmin64((n + 255) / 256, 8192);
+  dropout_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(x, y, n, dropout_p, seed_dev, site);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ dy, const float* __restrict__ rs,
+                                                       float* __restrict__ dx, int rows, int C, int div, int mod) {
+  const int64_t total = (int64_t)rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int row = (int)(i / C);
+    dx[i] = dy[i] * rs[(row / div) % mod];
+  }
+}
+extern "C" int vptr_rowscale(const float* dy, const float* rowscale, float* dx, int rows, int C, int div, int mod,
+                             vptr_stream_t stream) {
+  VPTR_CHECK(rows > 0 && C > 0 && div >= 1 && mod >= 1, "rowscale: bad arguments");
+  const int64_t total = (int64_t)rows * C;
+  const int blocks = (int)hmin64((total + 255) / 256, 8192);
+  rowscale_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dy, rowscale, dx, rows, C, div, mod);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const float* __restrict__ scale, float* __restrict__ dx, int64_t rows,
+                                                         int C) {
+  const int64_t total = rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    dx[i] = y[i] > 0.f ? dy[i] * scale[c] : 0.f;
+  }
+}
+extern "C" int vptr_bnrelu_bwd(const float* dy, const float* y, const float* scale, float* dx, int64_t rows, int C,
+                               vptr_stream_t stream) {
+  VPTR_CHECK(rows > 0 && C > 0, "bnrelu_bwd: bad arguments");
+  const int64_t total = rows * C;
+  const int blocks = (int)hmin64((total + 255) / 256, 8192);
+  bnrelu_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dy, y, scale, dx, rows, C);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- optimizer -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += g[i] * g[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, s);
+}
+extern "C" int vptr_sumsq(const float* g, int64_t n, float* sumsq_dev, vptr_stream_t stream) {
+  VPTR_CHECK(n > 0 && sumsq_dev, "sumsq: bad arguments");
+  const int blocks = (int)hmin64((n + 255) / 256, 2048);
+  sumsq_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(g, n, sumsq_dev);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// torch.optim.AdamW semantics (decoupled weight decay, bias correction), clip_grad_norm_ coefficient folded in.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                    float wd, const float* __restrict__ step_dev,
+                                                    const float* __restrict__ sumsq_dev, float max_norm, float grad_scale) {
+  const float step = *step_dev;
+  float coef = grad_scale;
+  if (sumsq_dev) {
+    const float total = sqrtf(*sumsq_dev) * grad_scale;
+    coef *= fminf(1.f, max_norm / (total + 1e-6f));
+  }
+  const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+  const float step_size = lr / bc1;
+  const float inv_sqrt_bc2 = rsqrtf(bc2);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * coef;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    pi -= step_size * mi / denom;
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+extern "C" int vptr_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, const float* step_dev, const float* sumsq_dev, float max_norm, float grad_scale,
+                          vptr_stream_t stream) {
+  VPTR_CHECK(n > 0 && p && g && m && v && step_dev, "adamw: bad arguments");
+  const int blocks = (int)hmin64((n + 255) / 256, 4096);
+  adamw_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step_dev, sumsq_dev,
+                                                       max_norm, grad_scale);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,579 @@
+// LayerNorm(C) forward/backward, row/column reductions and the conv-FFN normalisation kernels (gfx950).
+// All kernels here are HBM-bound: float4 accesses, one wave per row for row-wise ops, thread-per-column sweeps with
+// coalesced row reads for column reductions (partials combined with fp32 atomics).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim: one wave per row, 4 rows per 256-thread block.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ y2, const float* __restrict__ tab, int tab_div,
+                                                     int tab_mod, float* __restrict__ mean, float* __restrict__ rstd,
+                                                     int rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (int64_t)row * C;
+  const int C4 = C >> 2;
+  float s = 0.f;
+  for (int i = lane; i < C4; i += 64) {
+    const float4 v = reinterpret_cast<const float4*>(xr)[i];
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  for (int i = (C4 << 2) + lane; i < C; i += 64) s += xr[i];
+  const float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int i = lane; i < C4; i += 64) {
+    const float4 v = reinterpret_cast<const float4*>(xr)[i];
+    const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
+    q += (a * a + b * b) + (c * c + d * d);
+  }
+  for (int i = (C4 << 2) + lane; i < C; i += 64) { const float a = xr[i] - mu; q += a * a; }
+  const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  float* yr = y + (int64_t)row * C;
+  float* y2r = y2 ? y2 + (int64_t)row * C : nullptr;
+  const float* tr = tab ? tab + (int64_t)((row / tab_div) % tab_mod) * C : nullptr;
+  for (int i = lane; i < C4; i += 64) {
+    const float4 v = reinterpret_cast<const float4*>(xr)[i];
+    const float4 g = reinterpret_cast<const float4*>(gamma)[i];
+    const float4 b = reinterpret_cast<const float4*>(beta)[i];
+    float4 o;
+    o.x = (v.x - mu) * rs * g.x + b.x; o.y = (v.y - mu) * rs * g.y + b.y;
+    o.z = (v.z - mu) * rs * g.z + b.z; o.w = (v.w - mu) * rs * g.w + b.w;
+    reinterpret_cast<float4*>(yr)[i] = o;
+    if (y2r) {
+      const float4 t = reinterpret_cast<const float4*>(tr)[i];
+      o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+      reinterpret_cast<float4*>(y2r)[i] = o;
+    }
+  }
+  for (int i = (C4 << 2) + lane; i < C; i += 64) {
+    const float o = (xr[i] - mu) * rs * gamma[i] + beta[i];
+    yr[i] = o;
+    if (y2r) y2r[i] = o + tr[i];
+  }
+}
+
+extern "C" int vptr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* y2,
+                                  const float* tab, int tab_div, int tab_mod, float* mean, float* rstd, int rows, int C,
+                                  float eps, vptr_stream_t stream) {
+  VPTR_CHECK(rows > 0 && C > 0, "layernorm_fwd: empty input");
+  VPTR_CHECK(C % 4 == 0, "layernorm_fwd: C must be a multiple of 4 (got %d)", C);
+  if (y2) VPTR_CHECK(tab && tab_div >= 1 && tab_mod >= 1, "layernorm_fwd: y2 needs tab, tab_div, tab_mod");
+  ln_fwd_kernel<<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(x, gamma, beta, y, y2, y2 ? tab : nullptr, tab_div, tab_mod,
+                                                                mean, rstd, rows, C, eps);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// dx: one wave per row.  g = dy + dy2;  dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat))
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ dy2,
+                                                        const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        float* __restrict__ dx, int rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t off = (int64_t)row * C;
+  const float mu = mean[row], rs = rstd[row];
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = lane; i < C; i += 64) {
+    float g = dy[off + i];
+    if (dy2) g += dy2[off + i];
+    const float gg = g * gamma[i];
+    s1 += gg;
+    s2 += gg * (x[off + i] - mu) * rs;
+  }
+  s1 = wave_sum(s1) / (float)C;
+  s2 = wave_sum(s2) / (float)C;
+  for (int i = lane; i < C; i += 64) {
+    float g = dy[off + i];
+    if (dy2) g += dy2[off + i];
+    const float xh = (x[off + i] - mu) * rs;
+    dx[off + i] = rs * (g * gamma[i] - s1 - xh * s2);
+  }
+}
+
+// dgamma/dbeta: thread per column, block sweeps a chunk of rows; coalesced across threads.
+__global__ __launch_bounds__(256) void ln_bwd_param_kernel(const float* __restrict__ dy, const float* __restrict__ dy2,
+                                                           const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int rows, int C, int rows_per_block) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float ag = 0.f, ab = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    float g = dy[(int64_t)r * C + c];
+    if (dy2) g += dy2[(int64_t)r * C + c];
+    ag += g * (x[(int64_t)r * C + c] - mean[r]) * rstd[r];
+    ab += g;
+  }
+  unsafeAtomicAdd(dgamma + c, ag);
+  unsafeAtomicAdd(dbeta + c, ab);
+}
+
+extern "C" int vptr_layernorm_bwd(const float* dy, const float* dy2, const float* x, const float* gamma, const float* mean,
+                                  const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int C,
+                                  vptr_stream_t stream) {
+  VPTR_CHECK(rows > 0 && C > 0, "layernorm_bwd: empty input");
+  hipStream_t st = (hipStream_t)stream;
+  if (dx) ln_bwd_dx_kernel<<<cdiv(rows, 4), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, rows, C);
+  if (dgamma && dbeta) {
+    const int rpb = 64;
+    dim3 grid(cdiv(C, 256), cdiv(rows, rpb));
+    ln_bwd_param_kernel<<<grid, 256, 0, st>>>(dy, dy2, x, mean, rstd, dgamma, dbeta, rows, C, rpb);
+  }
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// small reductions / broadcasts
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rowmod_sum_kernel(const float* __restrict__ src, float* __restrict__ out, int rows,
+                                                         int C, int div, int mod, int groups_per_block) {
+  // out row j = sum over all rows r with (r / div) % mod == j.  Rows come in runs of `div` rows with the same j,
+  // repeating with period div*mod.  Thread per column; blockIdx.y = j; blockIdx.z = chunk of periods.
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int j = blockIdx.y;
+  const int period = div * mod;
+  const int nper = (rows + period - 1) / period;
+  const int p0 = blockIdx.z * groups_per_block, p1 = min(nper, p0 + groups_per_block);
+  float a = 0.f;
+  for (int p = p0; p < p1; ++p) {
+    const int rbase = p * period + j * div;
+    for (int d = 0; d < div; ++d) {
+      const int r = rbase + d;
+      if (r < rows) a += src[(int64_t)r * C + c];
+    }
+  }
+  unsafeAtomicAdd(out + (int64_t)j * C + c, a);
+}
+
+extern "C" int vptr_rowmod_sum(const float* src, float* out, int rows, int C, int div, int mod, vptr_stream_t stream) {
+  VPTR_CHECK(rows > 0 && C > 0 && div >= 1 && mod >= 1, "rowmod_sum: bad arguments");
+  const int period = div * mod;
+  const int nper = (rows + period - 1) / period;
+  const int gpb = 8;
+  dim3 grid(cdiv(C, 256), mod, cdiv(nper, gpb));
+  rowmod_sum_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, out, rows, C, div, mod, gpb);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vptr_colsum(const float* src, float* out, int rows, int C, vptr_stream_t stream) {
+  // column sum == rowmod_sum with one output row: use runs of 64 rows per block
+  VPTR_CHECK(rows > 0 && C > 0, "colsum: empty input");
+  dim3 grid(cdiv(C, 256), 1, cdiv(rows, 64));
+  rowmod_sum_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, out, rows, C, 64, 1, 1);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void add_rowtab_kernel(const float* __restrict__ x, const float* __restrict__ tab,
+                                                         float* __restrict__ y, int rows, int C4, int div, int mod) {
+  const int64_t total = (int64_t)rows * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int row = (int)(i / C4), c4 = (int)(i - (int64_t)row * C4);
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 t = reinterpret_cast<const float4*>(tab)[(int64_t)((row / div) % mod) * C4 + c4];
+    reinterpret_cast<float4*>(y)[i] = make_float4(v.x + t.x, v.y + t.y, v.z + t.z, v.w + t.w);
+  }
+}
+
+extern "C" int vptr_add_rowtab(const float* x, const float* tab, float* y, int rows, int C, int div, int mod,
+                               vptr_stream_t stream) {
+  VPTR_CHECK(rows > 0 && C > 0 && C % 4 == 0 && div >= 1 && mod >= 1, "add_rowtab: bad arguments");
+  const int64_t total = (int64_t)rows * (C / 4);
+  const int blocks = (int)hmin64((total + 255) / 256, 4096);
+  add_rowtab_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(x, tab, y, rows, C / 4, div, mod);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv-FFN statistics.  colstats: per-channel mean / biased variance over all rows (BatchNorm2d batch stats).
+// Pass 1: each block reduces 256 rows per column to (mean, M2); pass 2 merges the partials with Chan's formula.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colstats_partial_kernel(const float* __restrict__ x, float* __restrict__ scratch,
+                                                               int rows, int F) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= F) return;
+  const int r0 = blockIdx.y * 256, r1 = min(rows, r0 + 256);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += x[(int64_t)r * F + c];
+  const float mu = s / (float)(r1 - r0);
+  float m2 = 0.f;
+  for (int r = r0; r < r1; ++r) { const float d = x[(int64_t)r * F + c] - mu; m2 += d * d; }
+  scratch[((int64_t)blockIdx.y * F + c) * 2 + 0] = mu;
+  scratch[((int64_t)blockIdx.y * F + c) * 2 + 1] = m2;
+}
+__global__ __launch_bounds__(256) void colstats_final_kernel(const float* __restrict__ scratch, float* __restrict__ mean,
+                                                             float* __restrict__ var, int rows, int F, int nchunk) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= F) return;
+  float n = 0.f, mu = 0.f, m2 = 0.f;
+  for (int k = 0; k < nchunk; ++k) {
+    const float nb = (float)min(256, rows - k * 256);
+    const float mb = scratch[((int64_t)k * F + c) * 2 + 0], m2b = scratch[((int64_t)k * F + c) * 2 + 1];
+    const float d = mb - mu, nt = n + nb;
+    mu += d * nb / nt;
+    m2 += m2b + d * d * n * nb / nt;
+    n = nt;
+  }
+  mean[c] = mu;
+  var[c] = m2 / n;
+}
+
+extern "C" int vptr_colstats(const float* x, float* mean, float* var, float* scratch, int rows, int F, vptr_stream_t stream) {
+  VPTR_CHECK(rows > 0 && F > 0 && scratch, "colstats: bad arguments");
+  const int nchunk = cdiv(rows, 256);
+  hipStream_t st = (hipStream_t)stream;
+  colstats_partial_kernel<<<dim3(cdiv(F, 256), nchunk), 256, 0, st>>>(x, scratch, rows, F);
+  colstats_final_kernel<<<cdiv(F, 256), 256, 0, st>>>(scratch, mean, var, rows, F, nchunk);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// groupstats: mean / biased variance of each contiguous group of `group_elems` floats (LayerNorm((F,H,W)) per frame).
+__global__ __launch_bounds__(1024) void groupstats_kernel(const float* __restrict__ x, float* __restrict__ mean,
+                                                          float* __restrict__ var, int group_elems) {
+  __shared__ float red[16];
+  const float* g = x + (int64_t)blockIdx.x * group_elems;
+  const int n4 = group_elems >> 2;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n4; i += 1024) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < group_elems; i += 1024) s += g[i];
+  const float mu = block_sum(s, red) / (float)group_elems;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n4; i += 1024) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
+    q += (a * a + b * b) + (c * c + d * d);
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < group_elems; i += 1024) { const float a = g[i] - mu; q += a * a; }
+  const float vv = block_sum(q, red) / (float)group_elems;
+  if (threadIdx.x == 0) { mean[blockIdx.x] = mu; var[blockIdx.x] = vv; }
+}
+
+extern "C" int vptr_groupstats(const float* x, float* mean, float* var, int groups, int group_elems, vptr_stream_t stream) {
+  VPTR_CHECK(groups > 0 && group_elems > 0 && group_elems % 4 == 0, "groupstats: bad arguments");
+  groupstats_kernel<<<groups, 1024, 0, (hipStream_t)stream>>>(x, mean, var, group_elems);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// y = act((x - mean) * rstd * w + b) [* dropout]; stats per column (BN) or per frame (LN over (F,H,W)); affine is
+// [F] (per_col) or channel-last [HW, F].
+// ---------------------------------------------------------------------------------------------------------------
+template <bool PER_COL>
+__global__ __launch_bounds__(256) void norm_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ y, int rows,
+                                                           int F4, int HW, int act, float p, const uint64_t* seed_dev,
+                                                           uint32_t site, const float* __restrict__ rowscale, int rs_div,
+                                                           int rs_mod, const float* __restrict__ residual) {
+  const int64_t total = (int64_t)rows * F4;
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int row = (int)(i / F4), c4 = (int)(i - (int64_t)row * F4);
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    float4 mu, rs, ww, bb;
+    if (PER_COL) {
+      mu = reinterpret_cast<const float4*>(mean)[c4];
+      rs = reinterpret_cast<const float4*>(rstd)[c4];
+      ww = reinterpret_cast<const float4*>(w)[c4];
+      bb = reinterpret_cast<const float4*>(b)[c4];
+    } else {
+      const int f = row / HW, hw = row - f * HW;
+      const float m = mean[f], r = rstd[f];
+      mu = make_float4(m, m, m, m);
+      rs = make_float4(r, r, r, r);
+      ww = reinterpret_cast<const float4*>(w)[(int64_t)hw * F4 + c4];
+      bb = reinterpret_cast<const float4*>(b)[(int64_t)hw * F4 + c4];
+    }
+    float4 o;
+    o.x = vptr_act((v.x - mu.x) * rs.x * ww.x + bb.x, act);
+    o.y = vptr_act((v.y - mu.y) * rs.y * ww.y + bb.y, act);
+    o.z = vptr_act((v.z - mu.z) * rs.z * ww.z + bb.z, act);
+    o.w = vptr_act((v.w - mu.w) * rs.w * ww.w + bb.w, act);
+    if (p > 0.f) {
+      o.x *= vptr_drop_scale(seed, site, (uint64_t)i * 4 + 0, p);
+      o.y *= vptr_drop_scale(seed, site, (uint64_t)i * 4 + 1, p);
+      o.z *= vptr_drop_scale(seed, site, (uint64_t)i * 4 + 2, p);
+      o.w *= vptr_drop_scale(seed, site, (uint64_t)i * 4 + 3, p);
+    }
+    if (rowscale) {
+      const float r = rowscale[(row / rs_div) % rs_mod];
+      o.x *= r; o.y *= r; o.z *= r; o.w *= r;
+    }
+    if (residual) {
+      const float4 rv = reinterpret_cast<const float4*>(residual)[i];
+      o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+    }
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+}
+
+extern "C" int vptr_norm_act_fwd(const float* x, const float* mean, const float* rstd, const float* w, const float* b,
+                                 float* y, int rows, int F, int HW, int per_col, int act, float dropout_p,
+                                 const uint64_t* seed_dev, uint32_t site, const float* rowscale, int rs_div, int rs_mod,
+                                 const float* residual, vptr_stream_t stream) {
+  VPTR_CHECK(rows > 0 && F > 0 && F % 4 == 0 && HW >= 1, "norm_act_fwd: bad arguments");
+  if (!per_col) VPTR_CHECK(rows % HW == 0, "norm_act_fwd: rows must be a multiple of HW");
+  if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "norm_act_fwd: dropout needs seed_dev");
+  const int64_t total = (int64_t)rows * (F / 4);
+  const int blocks = (int)hmin64((total + 255) / 256, 8192);
+  hipStream_t st = (hipStream_t)stream;
+  if (rowscale) VPTR_CHECK(rs_div >= 1 && rs_mod >= 1, "norm_act_fwd: rowscale needs rs_div, rs_mod >= 1");
+  if (per_col) norm_act_fwd_kernel<true><<<blocks, 256, 0, st>>>(x, mean, rstd, w, b, y, rows, F / 4, HW, act, dropout_p, seed_dev, site, rowscale, rs_div, rs_mod, residual);
+  else norm_act_fwd_kernel<false><<<blocks, 256, 0, st>>>(x, mean, rstd, w, b, y, rows, F / 4, HW, act, dropout_p, seed_dev, site, rowscale, rs_div, rs_mod, residual);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// backward helper: g = dy * drop * act'(z), z = xhat*w + b
+__device__ __forceinline__ float norm_act_g(float dy, float xh, float w, float b, int act, float dscale) {
+  const float z = xh * w + b;
+  float g = dy * dscale;
+  if (act == VPTR_ACT_GELU) g *= vptr_gelu_grad(z);
+  else if (act == VPTR_ACT_RELU) g = z > 0.f ? g : 0.f;
+  return g;
+}
+
+// phase 1, per-column statistics (BN): dw[c] += sum g*xhat, db[c] += sum g.  (s1 = w*db, s2 = w*dw afterwards.)
+__global__ __launch_bounds__(256) void norm_act_bwd_col_reduce(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ w, const float* __restrict__ b,
+                                                               float* __restrict__ acc /* [2,F] */, int rows, int F, int act,
+                                                               float p, const uint64_t* seed_dev, uint32_t site, int rpb,
+                                                               const float* __restrict__ rowscale, int rs_div, int rs_mod) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= F) return;
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  const int r0 = blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
+  const float mu = mean[c], rs = rstd[c], ww = w[c], bb = b[c];
+  float aw = 0.f, ab = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const int64_t i = (int64_t)r * F + c;
+    const float xh = (x[i] - mu) * rs;
+    float ds = p > 0.f ? vptr_drop_scale(seed, site, (uint64_t)i, p) : 1.f;
+    if (rowscale) ds *= rowscale[(r / rs_div) % rs_mod];
+    const float g = norm_act_g(dy[i], xh, ww, bb, act, ds);
+    aw += g * xh;
+    ab += g;
+  }
+  unsafeAtomicAdd(acc + c, aw);
+  unsafeAtomicAdd(acc + F + c, ab);
+}
+// phase 1, per-frame (LN over (F,H,W)): block per (frame, column slab): frame sums s1 = sum g*w, s2 = sum g*w*xhat and
+// the affine gradients dw[hw,c] += g*xhat, db[hw,c] += g.
+__global__ __launch_bounds__(256) void norm_act_bwd_frame_reduce(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 const float* __restrict__ w, const float* __restrict__ b,
+                                                                 float* __restrict__ fsum /* [2,frames] */,
+                                                                 float* __restrict__ dw, float* __restrict__ db, int F, int HW,
+                                                                 int act, float p, const uint64_t* seed_dev, uint32_t site,
+                                                                 int frames, int fpb, const float* __restrict__ rowscale,
+                                                                 int rs_div, int rs_mod) {
+  __shared__ float red[16];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = c < F;
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  const int f0 = blockIdx.y * fpb, f1 = min(frames, f0 + fpb);
+  for (int hw = 0; hw < HW; ++hw) {
+    float aw = 0.f, ab = 0.f;
+    const float ww = valid ? w[(int64_t)hw * F + c] : 0.f, bb = valid ? b[(int64_t)hw * F + c] : 0.f;
+    for (int f = f0; f < f1; ++f) {
+      float g = 0.f, xh = 0.f;
+      if (valid) {
+        const int64_t i = ((int64_t)f * HW + hw) * F + c;
+        xh = (x[i] - mean[f]) * rstd[f];
+        float ds = p > 0.f ? vptr_drop_scale(seed, site, (uint64_t)i, p) : 1.f;
+        if (rowscale) ds *= rowscale[((f * HW + hw) / rs_div) % rs_mod];
+        g = norm_act_g(dy[i], xh, ww, bb, act, ds);
+      }
+      aw += g * xh;
+      ab += g;
+      const float t1 = block_sum(g * ww, red);
+      const float t2 = block_sum(g * ww * xh, red);
+      if (threadIdx.x == 0) {
+        unsafeAtomicAdd(fsum + f, t1);
+        unsafeAtomicAdd(fsum + frames + f, t2);
+      }
+    }
+    if (valid) {
+      unsafeAtomicAdd(dw + (int64_t)hw * F + c, aw);
+      unsafeAtomicAdd(db + (int64_t)hw * F + c, ab);
+    }
+  }
+}
+// phase 2: dx = rstd * (g*w - S1/n - xhat*S2/n)
+template <bool PER_COL>
+__global__ __launch_bounds__(256) void norm_act_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ w, const float* __restrict__ b,
+                                                              const float* __restrict__ acc, float* __restrict__ dx, int rows,
+                                                              int F, int HW, int act, float p, const uint64_t* seed_dev,
+                                                              uint32_t site, int nacc, int const_stats,
+                                                              const float* __restrict__ rowscale, int rs_div, int rs_mod) {
+  const int64_t total = (int64_t)rows * F;
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  const float inv_n = PER_COL ? 1.f / (float)rows : 1.f / (float)((int64_t)HW * F);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int row = (int)(i / F), c = (int)(i - (int64_t)row * F);
+    float mu, rs, ww, bb, s1, s2;
+    if (PER_COL) {
+      mu = mean[c]; rs = rstd[c]; ww = w[c]; bb = b[c];
+      s1 = ww * acc[nacc + c];  // w * sum g
+      s2 = ww * acc[c];         // w * sum g*xhat
+    } else {
+      const int f = row / HW, hw = row - f * HW;
+      mu = mean[f]; rs = rstd[f];
+      ww = w[(int64_t)hw * F + c]; bb = b[(int64_t)hw * F + c];
+      s1 = acc[f]; s2 = acc[nacc + f];
+    }
+    const float xh = (x[i] - mu) * rs;
+    float ds = p > 0.f ? vptr_drop_scale(seed, site, (uint64_t)i, p) : 1.f;
+    if (rowscale) ds *= rowscale[(row / rs_div) % rs_mod];
+    const float g = norm_act_g(dy[i], xh, ww, bb, act, ds);
+    if (const_stats) { s1 = 0.f; s2 = 0.f; }
+    dx[i] = rs * (g * ww - s1 * inv_n - xh * s2 * inv_n);
+  }
+}
+__global__ void accum2_kernel(const float* __restrict__ acc, float* __restrict__ dw, float* __restrict__ db, int F) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < F) { dw[c] += acc[c]; db[c] += acc[F + c]; }
+}
+
+extern "C" int vptr_norm_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
+                                 const float* b, float* dx, float* dw, float* db, float* scratch, int rows, int F, int HW,
+                                 int per_col, int act, int const_stats, float dropout_p, const uint64_t* seed_dev,
+                                 uint32_t site, const float* rowscale, int rs_div, int rs_mod, vptr_stream_t stream) {
+  VPTR_CHECK(rows > 0 && F > 0 && HW >= 1 && scratch && dx && dw && db, "norm_act_bwd: bad arguments");
+  if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "norm_act_bwd: dropout needs seed_dev");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)rows * F;
+  const int blocks = (int)hmin64((total + 255) / 256, 8192);
+  if (per_col) {
+    (void)hipMemsetAsync(scratch, 0, sizeof(float) * 2 * F, st);
+    const int rpb = 64;
+    norm_act_bwd_col_reduce<<<dim3(cdiv(F, 256), cdiv(rows, rpb)), 256, 0, st>>>(dy, x, mean, rstd, w, b, scratch, rows, F, act,
+                                                                                 dropout_p, seed_dev, site, rpb, rowscale, rs_div, rs_mod);
+    norm_act_bwd_dx_kernel<true><<<blocks, 256, 0, st>>>(dy, x, mean, rstd, w, b, scratch, dx, rows, F, HW, act, dropout_p,
+                                                         seed_dev, site, F, const_stats, rowscale, rs_div, rs_mod);
+    accum2_kernel<<<cdiv(F, 256), 256, 0, st>>>(scratch, dw, db, F);
+  } else {
+    VPTR_CHECK(rows % HW == 0, "norm_act_bwd: rows must be a multiple of HW");
+    const int frames = rows / HW;
+    (void)hipMemsetAsync(scratch, 0, sizeof(float) * 2 * frames, st);
+    const int fpb = 8;
+    norm_act_bwd_frame_reduce<<<dim3(cdiv(F, 256), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, mean, rstd, w, b, scratch, dw, db, F,
+                                                                                    HW, act, dropout_p, seed_dev, site, frames, fpb, rowscale, rs_div, rs_mod);
+    norm_act_bwd_dx_kernel<false><<<blocks, 256, 0, st>>>(dy, x, mean, rstd, w, b, scratch, dx, rows, F, HW, act, dropout_p,
+                                                          seed_dev, site, frames, const_stats, rowscale, rs_div, rs_mod);
+  }
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// depthwise 3x3, padding 1, channel-last [frames, H, W, F]; weights tap-major [9, F].
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w9,
+                                                         const float* __restrict__ b, float* __restrict__ y, int frames, int H,
+                                                         int W, int F4, int flip) {
+  const int64_t total = (int64_t)frames * H * W * F4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % F4);
+    const int64_t pix = i / F4;
+    const int xw = (int)(pix % W);
+    const int yh = (int)((pix / W) % H);
+    const int64_t f = pix / ((int64_t)W * H);
+    float4 a = b ? reinterpret_cast<const float4*>(b)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = yh + ky - 1;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = xw + kx - 1;
+        if (ix < 0 || ix >= W) continue;
+        const int tap = flip ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx;
+        const float4 wv = reinterpret_cast<const float4*>(w9)[(int64_t)tap * F4 + c4];
+        const float4 xv = reinterpret_cast<const float4*>(x)[((f * H + iy) * W + ix) * F4 + c4];
+        a.x += wv.x * xv.x; a.y += wv.y * xv.y; a.z += wv.z * xv.z; a.w += wv.w * xv.w;
+      }
+    }
+    reinterpret_cast<float4*>(y)[i] = a;
+  }
+}
+// dw9[tap, c] += sum_{f,y,x} dy[f,y,x,c] * x[f,y+ky-1,x+kx-1,c];  db[c] += sum dy.  Thread per channel.
+__global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           float* __restrict__ dw9, float* __restrict__ db, int frames, int H,
+                                                           int W, int F, int fpb) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= F) return;
+  const int f0 = blockIdx.y * fpb, f1 = min(frames, f0 + fpb);
+  float a[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) a[t] = 0.f;
+  float ab = 0.f;
+  for (int f = f0; f < f1; ++f)
+    for (int yh = 0; yh < H; ++yh)
+      for (int xw = 0; xw < W; ++xw) {
+        const float g = dy[(((int64_t)f * H + yh) * W + xw) * F + c];
+        ab += g;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int iy = yh + ky - 1;
+          if (iy < 0 || iy >= H) continue;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int ix = xw + kx - 1;
+            if (ix < 0 || ix >= W) continue;
+            a[ky * 3 + kx] += g * x[(((int64_t)f * H + iy) * W + ix) * F + c];
+          }
+        }
+      }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) unsafeAtomicAdd(dw9 + (int64_t)t * F + c, a[t]);
+  unsafeAtomicAdd(db + c, ab);
+}
+
+extern "C" int vptr_dwconv3x3_fwd(const float* x, const float* w9, const float* b, float* y, int frames, int H, int W, int F,
+                                  vptr_stream_t stream) {
+  VPTR_CHECK(frames > 0 && H > 0 && W > 0 && F > 0 && F % 4 == 0, "dwconv3x3_fwd: bad arguments");
+  const int64_t total = (int64_t)frames * H * W * (F / 4);
+  const int blocks = (int)hmin64((total + 255) / 256, 8192);
+  dwconv_fwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(x, w9, b, y, frames, H, W, F / 4, 0);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vptr_dwconv3x3_bwd(const float* dy, const float* x, const float* w9, float* dx, float* dw9, float* db,
+                                  int frames, int H, int W, int F, vptr_stream_t stream) {
+  VPTR_CHECK(frames > 0 && H > 0 && W > 0 && F > 0 && F % 4 == 0, "dwconv3x3_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)frames * H * W * (F / 4);
+  const int blocks = (int)hmin64((total + 255) / 256, 8192);
+  if (dx) dwconv_fwd_kernel<<<blocks, 256, 0, st>>>(dy, w9, nullptr, dx, frames, H, W, F / 4, 1);
+  if (dw9 && db) {
+    const int fpb = 4;
+    dwconv_bwd_w_kernel<<<dim3(cdiv(F, 256), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F, fpb);
+  }
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,251 @@
+"""ResNet auto-encoder of VPTR (stage 1) on the MI355X HIP kernels.
+
+Mirrors the module tree / state_dict keys of the reference (model/ResNetAutoEncoder.py:8-51 ResnetEncoder,
+:53-101 ResnetDecoder, :104-158 ResnetBlock, :160-189 init_weights): `self.model` is an nn.Sequential whose
+indices hold the same parameterised leaves (nn.Conv2d / nn.BatchNorm2d / nn.ConvTranspose2d), used here as
+parameter containers.  The forward pass runs NHWC implicit-GEMM convolutions on the matrix cores with BatchNorm
+folded into the GEMM epilogue (eval mode), ReLU / residual fused, and direct 7x7 kernels at the image ends.
+
+Scope of the HIP path: eval-mode BatchNorm (stage-2 training and inference, train_NAR.py:190-191): encoder forward,
+decoder forward and decoder backward w.r.t. its input (and optionally its weights).  Train-mode BatchNorm of the
+stage-1 script is a 'next' row and raises NotImplementedError.
+"""
+import functools
+
+import torch
+import torch.nn as nn
+from torch.nn import init
+
+from .. import ops
+from .._lib import check, lib, ptr, stream
+
+
+def _use_bias(norm_layer):
+    if type(norm_layer) == functools.partial:
+        return norm_layer.func == nn.InstanceNorm2d
+    return norm_layer == nn.InstanceNorm2d
+
+
+def _pad_layers(padding_type):
+    if padding_type == "reflect":
+        return [nn.ReflectionPad2d(1)], 0
+    if padding_type == "replicate":
+        return [nn.ReplicationPad2d(1)], 0
+    if padding_type == "zero":
+        return [], 1
+    raise NotImplementedError("padding [%s] is not implemented" % padding_type)
+
+
+class ResnetBlock(nn.Module):
+    """x + BN(conv3x3(pad(ReLU(BN(conv3x3(pad(x)))))))  (ResNetAutoEncoder.py:104-158)."""
+
+    def __init__(self, dim, padding_type, norm_layer, use_dropout, use_bias):
+        super().__init__()
+        if use_dropout:
+            raise NotImplementedError("ResnetBlock dropout is never enabled by the reference scripts")
+        block = []
+        pads, p = _pad_layers(padding_type)
+        block += pads + [nn.Conv2d(dim, dim, kernel_size=3, padding=p, bias=use_bias), norm_layer(dim), nn.ReLU(True)]
+        pads, p = _pad_layers(padding_type)
+        block += pads + [nn.Conv2d(dim, dim, kernel_size=3, padding=p, bias=use_bias), norm_layer(dim)]
+        self.conv_block = nn.Sequential(*block)
+        self.padding_type = padding_type
+
+    def _layers(self):
+        convs = [m for m in self.conv_block if isinstance(m, nn.Conv2d)]
+        bns = [m for m in self.conv_block if isinstance(m, nn.BatchNorm2d)]
+        return convs, bns
+
+
+def _bn_eval(bn):
+    if bn.training:
+        raise NotImplementedError("HIP auto-encoder path supports eval-mode BatchNorm only (stage-2 / inference); "
+                                  "stage-1 AE training is a 'next' row (SURVEY.md section 8f)")
+    return ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+
+
+class ResnetEncoder(nn.Module):
+    def __init__(self, input_nc, ngf=64, out_dim=528, n_downsampling=2, norm_layer=nn.BatchNorm2d, use_dropout=False,
+                 padding_type="reflect"):
+        super().__init__()
+        use_bias = _use_bias(norm_layer)
+        model = [nn.ReflectionPad2d(3), nn.Conv2d(input_nc, ngf, kernel_size=7, padding=0, bias=use_bias), norm_layer(ngf),
+                 nn.ReLU(True)]
+        for i in range(n_downsampling - 1):
+            mult = 2 ** i
+            model += [nn.Conv2d(ngf * mult, ngf * mult * 2, kernel_size=3, stride=2, padding=1, bias=use_bias),
+                      norm_layer(ngf * mult * 2), nn.ReLU(True)]
+        mult = 2 ** (n_downsampling - 1)
+        model += [nn.Conv2d(ngf * mult, out_dim, kernel_size=3, stride=2, padding=1, bias=use_bias), norm_layer(out_dim),
+                  nn.ReLU(True)]
+        for _ in range(9):
+            model += [ResnetBlock(out_dim, padding_type=padding_type, norm_layer=norm_layer, use_dropout=use_dropout,
+                                  use_bias=use_bias)]
+        model += [nn.ReLU()]
+        self.model = nn.Sequential(*model)
+        self.padding_type = padding_type
+        self.n_downsampling = n_downsampling
+
+    def forward(self, x):
+        """x (B, Cimg, H, W) NCHW -> (B, out_dim, H/2^n, W/2^n)."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # stage 2 runs the encoder under no_grad (train_NAR.py:54-56)
+            if x.requires_grad:
+                raise NotImplementedError("backward through VPTREnc is not on the HIP path yet (stage-1 AE training)")
+        with torch.no_grad():
+            return self._forward_impl(x)
+
+    def _forward_impl(self, x):
+        B, Cimg, H, W = x.shape
+        m = self.model
+        x = x.contiguous().float()
+        scale, shift = _bn_eval(m[2])
+        ngf = m[1].weight.shape[0]
+        y = torch.empty((B * H * W, ngf), device=x.device, dtype=torch.float32)
+        check(lib.vptr_conv7_in_fwd(ptr(x), ptr(m[1].weight.contiguous()), ptr(scale.contiguous()), ptr(shift.contiguous()),
+                                    ptr(y), B, Cimg, H, W, ngf, stream()), "vptr_conv7_in_fwd")
+        h, w, cin = H, W, ngf
+        idx = 4
+        for _ in range(self.n_downsampling):
+            conv, bn = m[idx], m[idx + 1]
+            cout = conv.weight.shape[0]
+            oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+            scale, shift = _bn_eval(bn)
+            y = ops.conv_nhwc(y, ops.conv_weight_as_gemm_b(conv.weight, False), B, h, w, cin, oh, ow, 3, 3, 2, 1, "zero", False,
+                              cout, colscale=scale, bias=shift, act=ops.ACT_RELU)
+            h, w, cin = oh, ow, cout
+            idx += 3
+        pad_mode = self.padding_type
+        for bi in range(9):
+            blk = m[idx + bi]
+            convs, bns = blk._layers()
+            s1, b1 = _bn_eval(bns[0])
+            s2, b2 = _bn_eval(bns[1])
+            t = ops.conv_nhwc(y, ops.conv_weight_as_gemm_b(convs[0].weight, False), B, h, w, cin, h, w, 3, 3, 1, 1, pad_mode,
+                              False, cin, colscale=s1, bias=b1, act=ops.ACT_RELU)
+            y = ops.conv_nhwc(t, ops.conv_weight_as_gemm_b(convs[1].weight, False), B, h, w, cin, h, w, 3, 3, 1, 1, pad_mode,
+                              False, cin, colscale=s2, bias=b2, residual=y, act_after=(bi == 8))
+        out = torch.empty((B, cin, h, w), device=x.device, dtype=torch.float32)
+        check(lib.vptr_tokens_to_nchw(ptr(y), ptr(out), B, cin, h * w, 0, stream()), "vptr_tokens_to_nchw")
+        return out
+
+
+class _DecoderFn(torch.autograd.Function):
+    """Whole ResnetDecoder as one autograd node: forward keeps the NHWC activations, backward walks the layers in
+    reverse (7x7 data-gradient kernel, then folded-BN/ReLU mask + strided-conv dgrad GEMM per up-sampling layer)."""
+
+    @staticmethod
+    def forward(ctx, feat, dec, *params):
+        B, C, h, w = feat.shape
+        m = dec.model
+        n_up = dec.n_upsampling
+        x = torch.empty((B * h * w, C), device=feat.device, dtype=torch.float32)
+        check(lib.vptr_nchw_to_tokens(ptr(feat.contiguous()), ptr(x), B, C, h * w, stream()), "vptr_nchw_to_tokens")
+        acts, scales, geoms = [], [], []
+        cin = C
+        for i in range(n_up):
+            convt, bn = m[3 * i], m[3 * i + 1]
+            cout = convt.weight.shape[1]
+            scale, shift = _bn_eval(bn)
+            oh, ow = 2 * h, 2 * w
+            y = ops.conv_nhwc(x, ops.conv_weight_as_gemm_b(convt.weight, True), B, h, w, cin, oh, ow, 3, 3, 2, 1, "zero", True,
+                              cout, colscale=scale, bias=shift, act=ops.ACT_RELU)
+            acts.append(y)
+            scales.append(scale)
+            geoms.append((h, w, cin, oh, ow, cout))
+            x, h, w, cin = y, oh, ow, cout
+        conv = m[3 * n_up + 1]
+        cimg = conv.weight.shape[0]
+        out = torch.empty((B, cimg, h, w), device=feat.device, dtype=torch.float32)
+        check(lib.vptr_conv7_out_fwd(ptr(x), ptr(conv.weight.contiguous()), ptr(conv.bias.contiguous()), ptr(out), B, cin, h, w,
+                                     cimg, dec.out_act, stream()), "vptr_conv7_out_fwd")
+        ctx.dec, ctx.acts, ctx.scales, ctx.geoms, ctx.B = dec, acts, scales, geoms, B
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        dec, acts, scales, geoms, B = ctx.dec, ctx.acts, ctx.scales, ctx.geoms, ctx.B
+        m = dec.model
+        n_up = dec.n_upsampling
+        conv = m[3 * n_up + 1]
+        dout = dout.contiguous()
+        h, w, cin = geoms[-1][3], geoms[-1][4], geoms[-1][5]
+        cimg = conv.weight.shape[0]
+        g = torch.empty((B * h * w, cin), device=dout.device, dtype=torch.float32)
+        check(lib.vptr_conv7_out_bwd_data(ptr(dout), ptr(out), ptr(conv.weight.contiguous()), ptr(g), B, cin, h, w, cimg,
+                                          dec.out_act, stream()), "vptr_conv7_out_bwd_data")
+        for i in reversed(range(n_up)):
+            ih, iw, ic, oh, ow, oc = geoms[i]
+            gm = torch.empty_like(g)
+            check(lib.vptr_bnrelu_bwd(ptr(g), ptr(acts[i]), ptr(scales[i].contiguous()), ptr(gm), B * oh * ow, oc, stream()),
+                  "vptr_bnrelu_bwd")
+            # dgrad of ConvTranspose2d(3x3, s2, p1, op1) = Conv2d(3x3, s2, p1) of the output gradient with
+            # B[ci][(ky,kx,co)] = W[ci][co][ky][kx]
+            wt = m[3 * i].weight
+            Bm = wt.permute(0, 2, 3, 1).reshape(wt.shape[0], -1).contiguous()
+            g = ops.conv_nhwc(gm, Bm, B, oh, ow, oc, ih, iw, 3, 3, 2, 1, "zero", False, ic)
+        h0, w0, c0 = geoms[0][0], geoms[0][1], geoms[0][2]
+        dfeat = torch.empty((B, c0, h0, w0), device=dout.device, dtype=torch.float32)
+        check(lib.vptr_tokens_to_nchw(ptr(g), ptr(dfeat), B, c0, h0 * w0, 0, stream()), "vptr_tokens_to_nchw")
+        return (dfeat, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class ResnetDecoder(nn.Module):
+    def __init__(self, output_nc, ngf=64, feat_dim=528, n_downsampling=2, norm_layer=nn.BatchNorm2d, use_dropout=False,
+                 padding_type="reflect", out_layer="Tanh"):
+        super().__init__()
+        use_bias = _use_bias(norm_layer)
+        model = []
+        mult = 2 ** n_downsampling
+        model += [nn.ConvTranspose2d(feat_dim, int(ngf * mult / 2), kernel_size=3, stride=2, padding=1, output_padding=1,
+                                     bias=use_bias), norm_layer(int(ngf * mult / 2)), nn.ReLU(True)]
+        for i in range(1, n_downsampling):
+            mult = 2 ** (n_downsampling - i)
+            model += [nn.ConvTranspose2d(ngf * mult, int(ngf * mult / 2), kernel_size=3, stride=2, padding=1,
+                                         output_padding=1, bias=use_bias), norm_layer(int(ngf * mult / 2)), nn.ReLU(True)]
+        model += [nn.ReflectionPad2d(3)]
+        model += [nn.Conv2d(ngf, output_nc, kernel_size=7, padding=0)]
+        if out_layer == "Tanh":
+            model += [nn.Tanh()]
+            self.out_act = 1
+        elif out_layer == "Sigmoid":
+            model += [nn.Sigmoid()]
+            self.out_act = 2
+        else:
+            raise ValueError("Unsupported output layer")
+        self.model = nn.Sequential(*model)
+        self.n_upsampling = n_downsampling
+
+    def forward(self, x):
+        """x (B, feat_dim, h, w) -> (B, output_nc, h*2^n, w*2^n); differentiable w.r.t. x (decoder weights are frozen
+        in stage 2: the reference never steps them, train_NAR.py:205)."""
+        return _DecoderFn.apply(x, self, *[p for p in self.parameters()])
+
+
+def init_weights(net, init_type="normal", init_gain=0.02):
+    """N(0, gain) on every Conv*/Linear* weight (bias 0), N(1, gain) on BatchNorm2d weights -- matched by class-name
+    substring exactly like the reference (ResNetAutoEncoder.py:160-189)."""
+
+    def init_func(m):
+        classname = m.__class__.__name__
+        if hasattr(m, "weight") and (classname.find("Conv") != -1 or classname.find("Linear") != -1):
+            if init_type == "normal":
+                init.normal_(m.weight.data, 0.0, init_gain)
+            elif init_type == "xavier":
+                init.xavier_normal_(m.weight.data, gain=init_gain)
+            elif init_type == "kaiming":
+                init.kaiming_normal_(m.weight.data, a=0, mode="fan_in")
+            elif init_type == "orthogonal":
+                init.orthogonal_(m.weight.data, gain=init_gain)
+            else:
+                raise NotImplementedError("initialization method [%s] is not implemented" % init_type)
+            if hasattr(m, "bias") and m.bias is not None:
+                init.constant_(m.bias.data, 0.0)
+        elif classname.find("BatchNorm2d") != -1:
+            init.normal_(m.weight.data, 1.0, init_gain)
+            init.constant_(m.bias.data, 0.0)
+
+    print("initialize network with %s" % init_type)
+    net.apply(init_func)

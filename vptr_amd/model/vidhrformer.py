@@ -1,0 +1,385 @@
+"""VidHRFormer blocks of VPTR on the MI355X HIP kernels.
+
+Module tree, attribute names, constructor signatures and state_dict keys mirror the reference
+(model/VidHRFormer_modules.py, model/VidHRFormer.py, model/MultiHeadAttentionRPE.py) so checkpoints and
+training scripts drop in; leaf modules (nn.Linear, nn.LayerNorm, nn.Conv2d, nn.BatchNorm2d,
+nn.MultiheadAttention) are used as *parameter containers* only -- every forward below runs through
+vptr_amd.ops (C-ABI HIP kernels) on token-major [rows = (n,t,h,w), C] activations.  The reference's window
+partition, (T, N*HW, C) permutes and NCHW<->NHWC permutes are index arithmetic inside the kernels.
+"""
+import copy
+from collections import namedtuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .position_encoding import relative_position_index
+
+Geom = namedtuple("Geom", "N T H W")
+
+
+def _get_clones(module, n):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+
+
+def _droppath_scale(p, training, count, device):
+    """Per-index stochastic-depth scale floor(keep + U)/keep (VidHRFormer_modules.py:563-575); None when inactive."""
+    if p == 0.0 or not training:
+        return None
+    keep = 1.0 - p
+    return torch.floor(keep + torch.rand(count, device=device, dtype=torch.float32)) / keep
+
+
+class DropPath(nn.Module):
+    """Parameter-free marker kept for module-tree parity (the scale is fused into the producing kernel's epilogue)."""
+
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def extra_repr(self):
+        return "drop_prob={}".format(self.drop_prob)
+
+
+class MultiheadAttentionRPE(nn.Module):
+    """Container of the window-attention parameters (MultiHeadAttentionRPE.py:22-53, 359-388): separate q/k/v/out
+    Linears plus the Swin-style relative-position bias table and its index buffer."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0, rpe=True, window_size=7):
+        super().__init__()
+        assert embed_dim % num_heads == 0, "embed_dim must be divisible by num_heads"
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.head_dim = embed_dim // num_heads
+        self.k_proj = nn.Linear(embed_dim, embed_dim)
+        self.v_proj = nn.Linear(embed_dim, embed_dim)
+        self.q_proj = nn.Linear(embed_dim, embed_dim)
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self.rpe = rpe
+        if rpe:
+            self.window_size = [window_size] * 2
+            self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * window_size - 1) ** 2, num_heads))
+            self.register_buffer("relative_position_index", relative_position_index(window_size))
+            nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+
+
+class SpatialLocalMultiheadAttention(nn.Module):
+    """Local-window multi-head self-attention (VidHRFormer_modules.py:287-357)."""
+
+    def __init__(self, embed_dim, num_heads, window_size=7, dropout=0.0, rpe=False):
+        super().__init__()
+        self.dim, self.num_heads, self.window_size, self.dropout, self.rpe = embed_dim, num_heads, window_size, dropout, rpe
+        if rpe:
+            self.attn = MultiheadAttentionRPE(embed_dim, num_heads, dropout=dropout, rpe=True, window_size=window_size)
+        else:
+            self.attn = nn.MultiheadAttention(embed_dim, num_heads, dropout=dropout)
+        self._lw_tab = {}
+
+    def _window_pos_table(self, lw_pos, H, W):
+        key = (H, W, lw_pos.device)
+        if key not in self._lw_tab:
+            ws = self.window_size
+            hh = torch.arange(H, device=lw_pos.device) % ws
+            ww = torch.arange(W, device=lw_pos.device) % ws
+            self._lw_tab[key] = lw_pos[hh[:, None], ww[None, :]].reshape(H * W, -1).contiguous()
+        return self._lw_tab[key]
+
+    def forward_tokens(self, xqk, xv, residual, g, lw_pos, site, rowscale=None, rs_div=1, rs_mod=1):
+        C, nh, ws = self.dim, self.num_heads, self.window_size
+        if g.H % ws or g.W % ws:
+            raise NotImplementedError("window attention on the HIP path needs H and W to be multiples of window_size "
+                                      "(got %dx%d, ws %d); the centre-pad variant is not on the measured path" % (g.H, g.W, ws))
+        p = self.dropout if self.training else 0.0
+        scale = float(C // nh) ** -0.5
+        a = self.attn
+        if self.rpe:
+            q = ops.linear(xqk, a.q_proj.weight, a.q_proj.bias, alpha=scale)
+            k = ops.linear(xqk, a.k_proj.weight, a.k_proj.bias)
+            v = ops.linear(xv, a.v_proj.weight, a.v_proj.bias)
+            table, index = a.relative_position_bias_table, a.relative_position_index
+        else:
+            xin = ops.add_rowtab(xqk, self._window_pos_table(lw_pos, g.H, g.W), 1, g.H * g.W)
+            Wq, Wk, Wv = a.in_proj_weight[:C], a.in_proj_weight[C:2 * C], a.in_proj_weight[2 * C:]
+            bq, bk, bv = a.in_proj_bias[:C], a.in_proj_bias[C:2 * C], a.in_proj_bias[2 * C:]
+            q = ops.linear(xin, Wq, bq, alpha=scale)
+            k = ops.linear(xin, Wk, bk)
+            v = ops.linear(xv, Wv, bv)
+            table, index = None, None
+        o = ops.window_attention(q, k, v, table, index, g.N * g.T, g.H, g.W, nh, ws, p, site)
+        return ops.linear(o, a.out_proj.weight, a.out_proj.bias, residual=residual, rowscale=rowscale, rs_div=rs_div,
+                          rs_mod=rs_mod)
+
+    def extra_repr(self):
+        return f"dim={self.dim}, window_size={self.window_size}, num_heads={self.num_heads}"
+
+
+class MlpDWBN(nn.Module):
+    """Conv feed-forward 1x1 -> DW3x3 -> 1x1, each followed by norm + GELU (VidHRFormer_modules.py:376-442).
+    AR_model=True (the constructor default, used by FAR and by every NAR *decoder* block) normalises with
+    LayerNorm((ch,H,W)); AR_model=False (NAR encoder blocks) with BatchNorm2d."""
+
+    def __init__(self, encH, encW, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU,
+                 dw_act_layer=nn.GELU, drop=0.0, AR_model=True):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Conv2d(in_features, hidden_features, kernel_size=1)
+        self.act1 = act_layer()
+        self.norm1 = nn.LayerNorm((hidden_features, encH, encW)) if AR_model else nn.BatchNorm2d(hidden_features)
+        self.dw3x3 = nn.Conv2d(hidden_features, hidden_features, kernel_size=3, stride=1, groups=hidden_features, padding=1)
+        self.act2 = dw_act_layer()
+        self.norm2 = nn.LayerNorm((hidden_features, encH, encW)) if AR_model else nn.BatchNorm2d(hidden_features)
+        self.fc2 = nn.Conv2d(hidden_features, out_features, kernel_size=1)
+        self.act3 = act_layer()
+        self.norm3 = nn.LayerNorm((out_features, encH, encW)) if AR_model else nn.BatchNorm2d(out_features)
+        self.drop = nn.Dropout(drop)
+        self.out_features = out_features
+        self.layer_norm = AR_model
+        self.drop_p = drop
+
+    def _norm_act(self, h, norm, g, **kw):
+        HW = g.H * g.W
+        if self.layer_norm:
+            if tuple(norm.normalized_shape[1:]) != (g.H, g.W):
+                raise RuntimeError("LayerNorm((C,H,W)) was built for %s but the feature map is %dx%d"
+                                   % (tuple(norm.normalized_shape), g.H, g.W))
+            F = norm.weight.shape[0]
+            w = norm.weight.reshape(F, HW).t().contiguous()  # channel-last affine [HW, F]
+            b = norm.bias.reshape(F, HW).t().contiguous()
+            return ops.norm_act(h, w, b, "ln", HW, self.training, eps=norm.eps, **kw)
+        if self.training and norm.track_running_stats:
+            norm.num_batches_tracked.add_(1)
+        return ops.norm_act(h, norm.weight, norm.bias, "bn", HW, self.training, norm.running_mean, norm.running_var,
+                            eps=norm.eps, momentum=norm.momentum, **kw)
+
+    def forward_tokens(self, u, residual, g, site, rowscale=None, rs_div=1, rs_mod=1):
+        p = self.drop_p if self.training else 0.0
+        F, C = self.fc1.weight.shape[0], self.fc1.weight.shape[1]
+        h = ops.linear(u, self.fc1.weight.view(F, C), self.fc1.bias)
+        h = self._norm_act(h, self.norm1, g)
+        h = ops.dwconv3x3(h, self.dw3x3.weight, self.dw3x3.bias, g.N * g.T, g.H, g.W)
+        h = self._norm_act(h, self.norm2, g, dropout_p=p, site=site)
+        h = ops.linear(h, self.fc2.weight.view(self.out_features, F), self.fc2.bias)
+        return self._norm_act(h, self.norm3, g, dropout_p=p, site=site + 1, rowscale=rowscale, rs_div=rs_div, rs_mod=rs_mod,
+                              residual=residual)
+
+
+def _mha_tokens(mha, q_in, k_in, v_in, residual, Nb, Tq, Tk, HW, causal, p_attn, site, out_dropout=0.0, out_site=0,
+                rowscale=None, rs_div=1, rs_mod=1):
+    """Stock nn.MultiheadAttention (packed in_proj) over time on token-major inputs (VidHRFormer_modules.py:79-84)."""
+    C, nh = mha.embed_dim, mha.num_heads
+    w, b = mha.in_proj_weight, mha.in_proj_bias
+    q = ops.linear(q_in, w[:C], b[:C], alpha=float(C // nh) ** -0.5)
+    k = ops.linear(k_in, w[C:2 * C], b[C:2 * C])
+    v = ops.linear(v_in, w[2 * C:], b[2 * C:])
+    o = ops.temporal_attention(q, k, v, Nb, Tq, Tk, HW, nh, causal, p_attn, site)
+    return ops.linear(o, mha.out_proj.weight, mha.out_proj.bias, residual=residual, dropout_p=out_dropout, site=out_site,
+                      rowscale=rowscale, rs_div=rs_div, rs_mod=rs_mod)
+
+
+class VidHRFormerBlockEnc(nn.Module):
+    """Encoder block (VidHRFormer_modules.py:30-93): window MHSA -> conv-FFN -> temporal MHSA -> MLP, pre-norm."""
+
+    def __init__(self, encH, encW, embed_dim, num_heads, window_size=7, dropout=0.0, drop_path=0.0,
+                 Spatial_FFN_hidden_ratio=4, dim_feedforward=1024, far=False, rpe=True):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.window_size, self.dropout = embed_dim, num_heads, window_size, dropout
+        self.Spatial_FFN_hidden_ratio = Spatial_FFN_hidden_ratio
+        self.SLMHSA = SpatialLocalMultiheadAttention(embed_dim, num_heads, window_size, dropout, rpe)
+        self.SpatialFFN = MlpDWBN(encH, encW, embed_dim, hidden_features=int(Spatial_FFN_hidden_ratio * embed_dim),
+                                  out_features=embed_dim, drop=dropout, AR_model=bool(far))
+        self.norm1 = nn.LayerNorm(embed_dim)
+        self.norm2 = nn.LayerNorm(embed_dim)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm3 = nn.LayerNorm(embed_dim)
+        self.temporal_MHSA = nn.MultiheadAttention(embed_dim, num_heads, dropout=dropout)
+        self.linear1 = nn.Linear(embed_dim, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, embed_dim)
+        self.activation = nn.GELU()
+        self.drop1 = nn.Dropout(dropout) if dropout > 0.0 else nn.Identity()
+        self.drop2 = nn.Dropout(dropout) if dropout > 0.0 else nn.Identity()
+        self.drop3 = nn.Dropout(dropout) if dropout > 0.0 else nn.Identity()
+        self.norm4 = nn.LayerNorm(embed_dim)
+        self.far = far
+        self.drop_path_p = drop_path
+        self._site = 0
+
+    def forward_tokens(self, x, g, lw_pos, tpos):
+        """x [N*T*H*W, C]; tpos (T, C)."""
+        HW = g.H * g.W
+        p = self.dropout if self.training else 0.0
+        s = self._site
+        dp = _droppath_scale(self.drop_path_p, self.training, g.N, x.device)
+        per_n = g.T * HW
+        u = ops.layernorm(x, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps)
+        x = self.SLMHSA.forward_tokens(u, u, x, g, lw_pos, s + 0, rowscale=dp, rs_div=per_n, rs_mod=g.N)
+        dp = _droppath_scale(self.drop_path_p, self.training, g.N, x.device)
+        u = ops.layernorm(x, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps)
+        x = self.SpatialFFN.forward_tokens(u, x, g, s + 1, rowscale=dp, rs_div=per_n, rs_mod=g.N)
+        u, uq = ops.layernorm(x, self.norm3.weight, self.norm3.bias, tab=tpos, tab_div=HW, tab_mod=g.T, eps=self.norm3.eps)
+        x = _mha_tokens(self.temporal_MHSA, uq, uq, u, x, g.N, g.T, g.T, HW, self.far, p, s + 3, out_dropout=p, out_site=s + 4)
+        u = ops.layernorm(x, self.norm4.weight, self.norm4.bias, eps=self.norm4.eps)
+        h = ops.linear(u, self.linear1.weight, self.linear1.bias, act=ops.ACT_GELU, dropout_p=p, site=s + 5)
+        return ops.linear(h, self.linear2.weight, self.linear2.bias, residual=x, dropout_p=p, site=s + 6)
+
+
+class VidHRFormerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers, norm=None):
+        super().__init__()
+        self.layers = _get_clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+
+    def forward_tokens(self, x, g, lw_pos, tpos):
+        for layer in self.layers:
+            x = layer.forward_tokens(x, g, lw_pos, tpos)
+        if self.norm is not None:
+            x = ops.layernorm(x, self.norm.weight, self.norm.bias, eps=self.norm.eps)
+        return x
+
+
+class VidHRFormerBlockDecNAR(nn.Module):
+    """NAR decoder block (VidHRFormer_modules.py:125-211): query window MHSA, conv-FFN, temporal self-attention, MLP,
+    encoder-decoder temporal attention, second conv-FFN."""
+
+    def __init__(self, encH, encW, embed_dim, num_heads, window_size=7, dropout=0.0, drop_path=0.0,
+                 Spatial_FFN_hidden_ratio=4, dim_feedforward=1024, TSLMA_flag=False, rpe=True):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.window_size, self.dropout = embed_dim, num_heads, window_size, dropout
+        self.Spatial_FFN_hidden_ratio = Spatial_FFN_hidden_ratio
+        hidden = int(Spatial_FFN_hidden_ratio * embed_dim)
+        self.SLMHSA = SpatialLocalMultiheadAttention(embed_dim, num_heads, window_size, dropout, rpe)
+        self.SpatialFFN = MlpDWBN(encH, encW, embed_dim, hidden_features=hidden, out_features=embed_dim, drop=dropout)
+        self.norm1 = nn.LayerNorm(embed_dim)
+        self.norm2 = nn.LayerNorm(embed_dim)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm3 = nn.LayerNorm(embed_dim)
+        self.temporal_MHSA = nn.MultiheadAttention(embed_dim, num_heads, dropout=dropout)
+        self.drop1 = nn.Dropout(dropout) if dropout > 0.0 else nn.Identity()
+        self.linear1 = nn.Linear(embed_dim, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, embed_dim)
+        self.activation = nn.GELU()
+        self.drop2 = nn.Dropout(dropout) if dropout > 0.0 else nn.Identity()
+        self.drop3 = nn.Dropout(dropout) if dropout > 0.0 else nn.Identity()
+        self.norm4 = nn.LayerNorm(embed_dim)
+        self.TSLMA_flag = TSLMA_flag
+        if TSLMA_flag:
+            raise NotImplementedError("TSLMA_flag=True (TemporalSpatialLocalMultiheadAttention) is a 'next' item "
+                                      "(SURVEY.md section 8f); every reference script uses TSLMA_flag=False")
+        self.EncDecAttn = nn.MultiheadAttention(embed_dim, num_heads, dropout=dropout)
+        self.SpatialFFN1 = MlpDWBN(encH, encW, embed_dim, hidden_features=hidden, out_features=embed_dim, drop=dropout)
+        self.norm5 = nn.LayerNorm(embed_dim)
+        self.norm6 = nn.LayerNorm(embed_dim)
+        self.drop_path1 = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.drop_path_p = drop_path
+        self._site = 0
+
+    def forward_tokens(self, tgt, g, qpos_tab, qpos_tpos_tab, mem, mem_k, T1, lw_pos, tpos_f):
+        """tgt [N*T2*HW, C]; qpos_tab = frame_queries as [T2*HW, C]; qpos_tpos_tab = frame_queries + tpos_f per (t, pixel);
+        mem, mem_k = memory and memory + past temporal pos, [N*T1*HW, C]; tpos_f (T2, C)."""
+        HW = g.H * g.W
+        T2 = g.T
+        p = self.dropout if self.training else 0.0
+        s = self._site
+        per_n = T2 * HW
+        dp = _droppath_scale(self.drop_path_p, self.training, g.N, tgt.device)
+        t, tq = ops.layernorm(tgt, self.norm1.weight, self.norm1.bias, tab=qpos_tab, tab_div=1, tab_mod=per_n, eps=self.norm1.eps)
+        x = self.SLMHSA.forward_tokens(tq, t, tgt, g, lw_pos, s + 0, rowscale=dp, rs_div=per_n, rs_mod=g.N)
+        dp = _droppath_scale(self.drop_path_p, self.training, g.N, tgt.device)
+        u = ops.layernorm(x, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps)
+        x = self.SpatialFFN.forward_tokens(u, x, g, s + 1, rowscale=dp, rs_div=per_n, rs_mod=g.N)
+        u, uq = ops.layernorm(x, self.norm3.weight, self.norm3.bias, tab=tpos_f, tab_div=HW, tab_mod=T2, eps=self.norm3.eps)
+        x = _mha_tokens(self.temporal_MHSA, uq, uq, u, x, g.N, T2, T2, HW, False, p, s + 3, out_dropout=p, out_site=s + 4)
+        u = ops.layernorm(x, self.norm4.weight, self.norm4.bias, eps=self.norm4.eps)
+        h = ops.linear(u, self.linear1.weight, self.linear1.bias, act=ops.ACT_GELU, dropout_p=p, site=s + 5)
+        x = ops.linear(h, self.linear2.weight, self.linear2.bias, residual=x, dropout_p=p, site=s + 6)
+        # encoder-decoder attention; the reference applies drop_path1 to a (T2, N*HW, C) tensor, i.e. along TIME
+        # (VidHRFormer_modules.py:204) -- reproduced: scale indexed by t = (row // HW) % T2
+        dpt = _droppath_scale(self.drop_path_p, self.training, T2, tgt.device)
+        _, uq = ops.layernorm(x, self.norm5.weight, self.norm5.bias, tab=qpos_tpos_tab, tab_div=1, tab_mod=per_n, eps=self.norm5.eps)
+        x = _mha_tokens(self.EncDecAttn, uq, mem_k, mem, x, g.N, T2, T1, HW, False, p, s + 7, rowscale=dpt, rs_div=HW, rs_mod=T2)
+        dp = _droppath_scale(self.drop_path_p, self.training, g.N, tgt.device)
+        u = ops.layernorm(x, self.norm6.weight, self.norm6.bias, eps=self.norm6.eps)
+        return self.SpatialFFN1.forward_tokens(u, x, g, s + 8, rowscale=dp, rs_div=per_n, rs_mod=g.N)
+
+
+class VidHRformerDecoderNAR(nn.Module):
+    def __init__(self, decoder_layer, num_layers, norm=None, return_intermediate=False):
+        super().__init__()
+        self.layers = _get_clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+        self.return_intermediate = return_intermediate
+
+    def forward_tokens(self, tgt, g, frame_queries, mem, T1, lw_pos, tpos_f, tpos_p):
+        HW, C = g.H * g.W, tgt.shape[1]
+        qpos_tab = frame_queries.reshape(g.T * HW, C)
+        qpos_tpos_tab = (frame_queries.reshape(g.T, HW, C) + tpos_f[:, None, :]).reshape(g.T * HW, C)
+        mem_k = ops.add_rowtab(mem, tpos_p, HW, T1)
+        x = tgt
+        for layer in self.layers:
+            x = layer.forward_tokens(x, g, qpos_tab, qpos_tpos_tab, mem, mem_k, T1, lw_pos, tpos_f)
+        if self.norm is not None:
+            x = ops.layernorm(x, self.norm.weight, self.norm.bias, eps=self.norm.eps)
+        return x
+
+
+def _assign_sites(module, base=0):
+    for m in module.modules():
+        if isinstance(m, (VidHRFormerBlockEnc, VidHRFormerBlockDecNAR)):
+            m._site = base
+            base += 16
+    return base
+
+
+class VidHRFormerNAR(nn.Module):
+    """Encoder(L_e) -> memory; decoder(L_d) from a zero target and learned frame queries (VidHRFormer.py:9-53)."""
+
+    def __init__(self, in_feat_shape, num_encoder_layer, num_decoder_layer, num_past_frames, num_future_frames, embed_dim,
+                 num_heads, window_size=7, dropout=0.0, drop_path=0.0, Spatial_FFN_hidden_ratio=4, dim_feedforward=512,
+                 TSLMA_flag=False, rpe=True):
+        super().__init__()
+        self.in_C, self.H, self.W = in_feat_shape
+        self.embed_dim = embed_dim
+        self.num_encoder_layer, self.num_decoder_layer, self.num_heads = num_encoder_layer, num_decoder_layer, num_heads
+        self.encoder = VidHRFormerEncoder(
+            VidHRFormerBlockEnc(self.H, self.W, embed_dim, num_heads, window_size, dropout, drop_path, Spatial_FFN_hidden_ratio,
+                                dim_feedforward, rpe=rpe), num_encoder_layer, nn.LayerNorm(embed_dim))
+        self.decoder = VidHRformerDecoderNAR(
+            VidHRFormerBlockDecNAR(self.H, self.W, embed_dim, num_heads, window_size, dropout, drop_path,
+                                   Spatial_FFN_hidden_ratio, dim_feedforward, TSLMA_flag, rpe=rpe),
+            num_decoder_layer, nn.LayerNorm(embed_dim), return_intermediate=False)
+        _assign_sites(self)
+
+    def forward(self, src, local_window_pos_embed, temporal_pos_embed, TS_local_pos_embed, query_pos, init_tgt=None):
+        """src (N,Tp,C,H,W) -> (out (N,Tf,C,H,W) post-ReLU, memory (N,Tp,H,W,C))."""
+        N, Tp, C, H, W = src.shape
+        Tf = query_pos.shape[0]
+        x = ops.nchw_to_tokens(src.reshape(N * Tp, C, H, W))
+        mem = self.encoder.forward_tokens(x, Geom(N, Tp, H, W), local_window_pos_embed, temporal_pos_embed[:Tp])
+        tgt = torch.zeros((N * Tf * H * W, C), device=src.device, dtype=torch.float32)
+        out = self.decoder.forward_tokens(tgt, Geom(N, Tf, H, W), query_pos, mem, Tp, local_window_pos_embed,
+                                          temporal_pos_embed[Tp:], temporal_pos_embed[:Tp])
+        out = ops.tokens_to_nchw(out, N * Tf, C, H, W, relu=True).reshape(N, Tf, C, H, W)
+        return out, mem.reshape(N, Tp, H, W, C)
+
+
+class VidHRFormerFAR(nn.Module):
+    """Encoder-only stack with causal temporal attention and LayerNorm conv-FFNs (VidHRFormer.py:56-88)."""
+
+    def __init__(self, in_feat_shape, num_encoder_layer, num_past_frames, num_future_frames, embed_dim, num_heads,
+                 window_size=7, dropout=0.0, drop_path=0.0, Spatial_FFN_hidden_ratio=4, dim_feedforward=512, rpe=True):
+        super().__init__()
+        self.in_C, self.H, self.W = in_feat_shape
+        self.embed_dim = embed_dim
+        self.num_encoder_layer, self.num_heads = num_encoder_layer, num_heads
+        self.encoder = VidHRFormerEncoder(
+            VidHRFormerBlockEnc(self.H, self.W, embed_dim, num_heads, window_size, dropout, drop_path, Spatial_FFN_hidden_ratio,
+                                dim_feedforward, far=True, rpe=rpe), num_encoder_layer, nn.LayerNorm(embed_dim))
+        _assign_sites(self)
+
+    def forward(self, input_feat, local_window_pos_embed, temporal_pos_embed):
+        N, T, C, H, W = input_feat.shape
+        x = ops.nchw_to_tokens(input_feat.reshape(N * T, C, H, W))
+        x = self.encoder.forward_tokens(x, Geom(N, T, H, W), local_window_pos_embed, temporal_pos_embed[:T])
+        return ops.tokens_to_nchw(x, N * T, C, H, W, relu=True).reshape(N, T, C, H, W)
