@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py -- predicted frames/sec of the VPTR-NAR train step (KTH 10->10 @ 64x64) on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = `single_iter` of the reference's stage-2 trainer (train_NAR.py:49-107): 2x VPTREnc (no grad), VPTRFormerNAR
+(4 enc + 8 dec layers, dropout 0.1), VPTRDec, MSE + GDL + 0.1*BiPatchNCE, backward, clip_grad_norm_(1.0), AdamW(1e-4);
+data parallel = all-reduce (mean) of the transformer gradients over RCCL.  Inputs are synthetic KTH-shaped batches that
+are already resident in HBM when the timed region starts.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PER_GPU_BATCH = 16          # train_NAR.py:165
+TP, TF = 10, 10
+GF_PER_SAMPLE = 554.0       # algorithmic GFLOP of one train step per sample
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
+
+
+def build_models(dev, dropout):
+    import vptr_amd.model as M
+    torch.manual_seed(3407)  # train_NAR_mp.py:278
+    enc = M.VPTREnc(1, feat_dim=528, n_downsampling=3, padding_type="reflect")
+    dec = M.VPTRDec(1, feat_dim=528, n_downsampling=3, out_layer="Tanh", padding_type="reflect")
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        M.init_weights(enc)
+        M.init_weights(dec)
+    T = M.VPTRFormerNAR(TP, TF, 8, 8, 528, 8, 4, 8, dropout, 4, 4, False, True)
+    return enc.to(dev), dec.to(dev), T.to(dev)
+
+
+def synth_batch(n, rank, dev):
+    rs = np.random.RandomState(2021 + rank)
+    past = (rs.uniform(0, 1, size=(n, TP, 1, 64, 64)).astype(np.float32) - 0.6013795) / 2.7570653  # utils/dataset.py:23
+    fut = (rs.uniform(0, 1, size=(n, TF, 1, 64, 64)).astype(np.float32) - 0.6013795) / 2.7570653
+    return torch.from_numpy(past).to(dev), torch.from_numpy(fut).to(dev)
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """The oracle (oracle/vptr_oracle.py: CPU restatement of the reference, parity-pinned by tests/golden) timed on the host
+    cores of this box, on a bounded sample of the same workload: N=2 KTH-shaped clips, 1 warm-up + timed steps."""
+    from oracle import fill, vptr_oracle as O
+    import vptr_amd.model as M
+    torch.manual_seed(3407)
+    n = 2
+    cfg = dict(Tp=TP, Tf=TF, H=8, W=8, C=528, nhead=8, window_size=4, num_encoder_layers=4, num_decoder_layers=8, rpe=True)
+    enc = M.VPTREnc(1, 528, 3, "reflect")
+    dec = M.VPTRDec(1, 528, 3, "Tanh", "reflect")
+    T = M.VPTRFormerNAR(TP, TF, 8, 8, 528, 8, 4, 8, 0.0, 4, 4, False, True)
+    st = O.NARStep(dict(enc.state_dict()), dict(dec.state_dict()), dict(T.state_dict()), cfg)
+    past, fut = synth_batch(n, 0, "cpu")
+    st.step(past, fut)
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        st.step(past, fut)
+        k += 1
+        if time.perf_counter() - t0 > seconds_budget * 0.5 or k >= 3:
+            break
+    dt = (time.perf_counter() - t0) / k
+    return {"value": n * TF / dt, "unit": "predicted frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle NAR train step (fp32 torch CPU), batch %d x 10->10 @64x64, 1 warm-up + %d timed steps, %.2f s/step"
+                      % (n, k, dt)}
+
+
+def gemm_roofline(trainer, past, fut, precision):
+    """Per-launch HIP-event timing of every GEMM launch of one train step (instrumented pass, outside the timed region):
+    returns the roofline entry of the dominant MFMA kernel instantiation and the GEMM-wide aggregate."""
+    import vptr_amd.ops as ops
+    recs = []
+    ops._gemm_prof = recs
+    trainer.step(past, fut)
+    torch.cuda.synchronize()
+    ops._gemm_prof = None
+    by = {}
+    for key, flops, e0, e1 in recs:
+        ms = e0.elapsed_time(e1)
+        d = by.setdefault(key, [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += flops
+        d[2] += ms
+    tot_f = sum(d[1] for d in by.values())
+    tot_ms = sum(d[2] for d in by.values())
+    dom = max(by.items(), key=lambda kv: kv[1][2])
+    (nfn, prec, am, bm), (cnt, fl, ms) = dom
+    peak = MFMA_PEAK_TFLOPS
+    ach = fl / (ms * 1e-3) / 1e12
+    return {
+        "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+        "kernel": "vptr_gemm_kernel<NFN=%d,NPASS=%d,A=%d,B=%d>" % (nfn, prec, am, bm),
+        "launches_per_step": cnt, "avg_launch_us": round(ms * 1e3 / cnt, 2), "alg_gflop_per_launch": round(fl / cnt / 1e9, 3),
+        "all_gemm": {"launches_per_step": sum(d[0] for d in by.values()), "ms_per_step": round(tot_ms, 3),
+                     "achieved": round(tot_f / (tot_ms * 1e-3) / 1e12, 2), "alg_gflop_per_step": round(tot_f / 1e9, 1)},
+        "note": "algorithmic FLOPs = 2*M*N*K per launch; NPASS=3 issues 3 bf16 MFMA passes per algorithmic FLOP "
+                "(split-bf16, fp32-class accuracy), so its ceiling is peak/3",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--precision", type=int, default=int(os.environ.get("VPTR_GEMM_PRECISION", "3")), choices=[1, 3],
+                    help="3 = split-bf16 MFMA (meets the 1e-3 parity bar, default); 1 = single-pass bf16")
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("VPTR_GRAPH", "1")), help="capture the step in a hipGraph (1 GPU)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        pg = torch.distributed.group.WORLD
+
+    import vptr_amd.ops as ops
+    from vptr_amd.train import NARTrainer
+    ops.config.gemm_precision = args.precision
+    enc, dec, T = build_models(dev, args.dropout)
+    if world > 1:  # identical replicas: broadcast rank 0's parameters and buffers (what the DDP constructor does)
+        for t in list(T.state_dict().values()) + list(enc.state_dict().values()) + list(dec.state_dict().values()):
+            torch.distributed.broadcast(t, 0)
+    trainer = NARTrainer(enc, dec, T, batch_size=args.batch, lr=1e-4, max_grad_norm=1.0, lam_pc=0.1, process_group=pg)
+    past, fut = synth_batch(args.batch, rank, dev)
+
+    use_graph = bool(args.graph) and world == 1
+    graph_note = "eager"
+    if use_graph:
+        try:
+            trainer.capture(past, fut, warmup=2)
+            graph_note = "hipGraph"
+        except Exception as e:  # noqa: keep the bench alive, report eager numbers
+            trainer._graph = None
+            graph_note = "eager (graph capture failed: %s)" % str(e).split("\n")[0][:120]
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = trainer.step(past, fut)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.step(past, fut)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(out["T_total"])
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * args.batch * TF * args.steps / dt
+        res = {
+            "metric": "predicted frames/sec (train step) NAR KTH 10->10 @64x64",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate/storage)" if args.precision == 3 else "bf16 (1-pass MFMA, fp32 accumulate/storage)",
+            "data": "synthetic",
+            "config": {"workload": "K64: KTH 64x64x1 10->10, VPTREnc/Dec(528, Tanh, reflect) + VPTRFormerNAR(4 enc + 8 dec, d=528, 8 heads, "
+                                   "ws 4, dropout %.2f), single_iter of train_NAR.py, random-init weights" % args.dropout,
+                       "per_gpu_batch": args.batch, "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                       "launch": graph_note, "dec_weight_grads": False,
+                       "alg_tflop_per_step_per_gpu": round(GF_PER_SAMPLE * args.batch / 1e3, 2),
+                       "step_tflops_per_gpu": round(GF_PER_SAMPLE * args.batch / 1e3 / (ms * 1e-3), 1)},
+            "final_loss": round(loss, 5),
+        }
+        if not args.no_roofline:
+            try:
+                trainer._graph = None  # instrumented eager pass
+                res["roofline"] = gemm_roofline(trainer, past, fut, args.precision)
+            except Exception as e:  # noqa
+                res["roofline"] = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                                   "traffic": None, "error": str(e)[:200]}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -94,5 +94,5 @@ def sample_index(numel, count, seed):
 def digest(t, count=2048, seed=7):
     """(l2 norm, sampled values) of a tensor, for full-size fixtures."""
     f = t.detach().reshape(-1).to(torch.float64)
-    idx = sample_index(f.numel(), count, seed)
-    return float(f.norm()), f[idx].to(torch.float32).numpy()
+    idx = sample_index(f.numel(), count, seed).to(f.device)
+    return float(f.norm()), f[idx].to(torch.float32).cpu().numpy()

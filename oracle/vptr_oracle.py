@@ -245,11 +245,12 @@ def dec_block(P, pre, tgt, qpos, mem, lw_pos, tpos_f, tpos_p, cfg, training):
     return x
 
 
-def nar_forward(P, feat, cfg, training=False):
+def nar_forward(P, feat, cfg, training=False, return_pre=False):
     """VPTRFormerNAR.forward (VPTR_modules.py:140-147) -> VidHRFormerNAR.forward (VidHRFormer.py:28-53).
 
     feat (N,Tp,C,H,W) -> (N,Tf,C,H,W).  cfg keys: Tp, Tf, nhead, window_size,
-    num_encoder_layers, num_decoder_layers, rpe.
+    num_encoder_layers, num_decoder_layers, rpe.  return_pre: also return the pre-ReLU tensor (fixture generation
+    uses it to keep gradient cotangents away from the ReLU kink).
     """
     Tp = feat.shape[1]
     x = feat.permute(0, 1, 3, 4, 2)
@@ -262,18 +263,18 @@ def nar_forward(P, feat, cfg, training=False):
     out = torch.zeros_like(qpos)
     for i in range(cfg["num_decoder_layers"]):
         out = dec_block(P, f"transformer.decoder.layers.{i}.", out, qpos, mem, lw, tpos[Tp:], tpos[:Tp], cfg, training)
-    out = _ln(P, "transformer.decoder.norm.", out)
-    return F.relu(out.permute(0, 1, 4, 2, 3))
+    out = _ln(P, "transformer.decoder.norm.", out).permute(0, 1, 4, 2, 3)
+    return (F.relu(out), out) if return_pre else F.relu(out)
 
 
-def far_forward(P, feat, cfg, training=False):
+def far_forward(P, feat, cfg, training=False, return_pre=False):
     """VPTRFormerFAR.forward (VPTR_modules.py:186-192) -> VidHRFormerFAR.forward (VidHRFormer.py:71-88)."""
     T = feat.shape[1]
     x = feat.permute(0, 1, 3, 4, 2)
     for i in range(cfg["num_encoder_layers"]):
         x = enc_block(P, f"transformer.encoder.layers.{i}.", x, P["lw_pos"], P["temporal_pos"][:T], cfg, True, training)
-    x = _ln(P, "transformer.encoder.norm.", x)
-    return F.relu(x.permute(0, 1, 4, 2, 3))
+    x = _ln(P, "transformer.encoder.norm.", x).permute(0, 1, 4, 2, 3)
+    return (F.relu(x), x) if return_pre else F.relu(x)
 
 
 def nce_projector(P, feat):

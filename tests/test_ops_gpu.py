@@ -299,8 +299,8 @@ def test_conv7_ends(ops, dev, cimg):
     ref = torch.relu(F.conv2d(F.pad(x.double(), (3, 3, 3, 3), mode="reflect"), w.double()) * sc.double()[None, :, None, None]
                      + sh.double()[None, :, None, None])
     y = torch.empty((B * H * W, 64), device=dev)
-    check(lib.vptr_conv7_in_fwd(ptr(x.to(dev)), ptr(w.to(dev)), ptr(sc.to(dev)), ptr(sh.to(dev)), ptr(y), B, cimg, H, W, 64,
-                                stream()), "conv7_in")
+    xd, wd_, scd, shd = x.to(dev), w.to(dev), sc.to(dev), sh.to(dev)  # keep the device tensors alive across the raw call
+    check(lib.vptr_conv7_in_fwd(ptr(xd), ptr(wd_), ptr(scd), ptr(shd), ptr(y), B, cimg, H, W, 64, stream()), "conv7_in")
     assert rel(y.reshape(B, H, W, 64).permute(0, 3, 1, 2), ref) < TOLV
     # output layer fwd + bwd-data
     for act, fn in ((1, torch.tanh), (2, torch.sigmoid)):
@@ -311,11 +311,11 @@ def test_conv7_ends(ops, dev, cimg):
         (out * go.double()).sum().backward()
         xt = xin.detach().float().permute(0, 2, 3, 1).reshape(-1, 64).contiguous().to(dev)
         yo = torch.empty((B, cimg, H, W), device=dev)
-        check(lib.vptr_conv7_out_fwd(ptr(xt), ptr(w2.to(dev)), ptr(b2.to(dev)), ptr(yo), B, 64, H, W, cimg, act, stream()), "c7o")
+        w2g, b2g, gog = w2.to(dev), b2.to(dev), go.to(dev)
+        check(lib.vptr_conv7_out_fwd(ptr(xt), ptr(w2g), ptr(b2g), ptr(yo), B, 64, H, W, cimg, act, stream()), "c7o")
         assert rel(yo, out) < TOLV
         dx = torch.empty((B * H * W, 64), device=dev)
-        check(lib.vptr_conv7_out_bwd_data(ptr(go.to(dev)), ptr(yo), ptr(w2.to(dev)), ptr(dx), B, 64, H, W, cimg, act, stream()),
-              "c7obd")
+        check(lib.vptr_conv7_out_bwd_data(ptr(gog), ptr(yo), ptr(w2g), ptr(dx), B, 64, H, W, cimg, act, stream()), "c7obd")
         assert rel(dx.reshape(B, H, W, 64).permute(0, 3, 1, 2), xin.grad) < 5e-5
         dw = torch.zeros((cimg, 64, 7, 7), device=dev)
         db = torch.zeros((cimg,), device=dev)
@@ -323,8 +323,8 @@ def test_conv7_ends(ops, dev, cimg):
         b2d = b2.double().clone().requires_grad_(True)
         out2 = fn(F.conv2d(F.pad(xin.detach(), (3, 3, 3, 3), mode="reflect"), w2d, b2d))
         (out2 * go.double()).sum().backward()
-        check(lib.vptr_conv7_out_bwd_weight(ptr(go.to(dev)), ptr(yo), ptr(xt), ptr(dw), ptr(db), B, 64, H, W, cimg, act,
-                                            stream()), "c7obw")
+        check(lib.vptr_conv7_out_bwd_weight(ptr(gog), ptr(yo), ptr(xt), ptr(dw), ptr(db), B, 64, H, W, cimg, act, stream()),
+              "c7obw")
         assert rel(dw, w2d.grad) < 5e-5 and rel(db, b2d.grad) < 5e-5
 
 

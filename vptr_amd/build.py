@@ -17,7 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libvptr_hip.so")
 SOURCES = ["api.hip", "gemm.hip", "norm.hip", "attn.hip", "elementwise.hip", "conv7.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast", "-fno-slp-vectorize",
+         "-Wno-unused-result"]
 
 
 def _hipcc():

@@ -4,196 +4,213 @@
 //   matrix cores, fp32 accumulate.  The fp32 -> bf16 hi/lo split happens in the global->LDS staging path, so no
 //   pre-converted copies of activations or weights exist in HBM (fp32 is as compact as hi+lo).
 //
-// Tiling: workgroup = 256 threads = 4 waves, block tile 128 x (16*NFN) x 32; wave w owns rows [32w, 32w+32) and all
-// NFN column fragments (v_mfma_f32_16x16x32_bf16, 2 x NFN accumulators of 4 VGPRs).  NFN = 11 gives BN = 176, which
-// divides every channel count of the model (528 = 3*176, 1056, 1584, 2112 = 12*176) with no tail waste.
+// Tiling: workgroup = 512 threads = 8 waves in a 4 (M) x 2 (N) grid, block tile 128 x (16*NFN) x 32.  Wave (wm, wn) owns
+// rows [32 wm, 32 wm + 32) and column fragments wn*NFW .. wn*NFW + NFW - 1 (NFW = ceil(NFN/2)) of
+// v_mfma_f32_16x16x32_bf16: 2 x NFW accumulators of 4 VGPRs.  NFN = 11 gives BN = 176, which divides every channel
+// count of the model (528 = 3*176, 1056, 1584, 2112 = 12*176) with no tail waste in HBM traffic (the 12th fragment
+// slot of the odd wave column is computed on padding and never stored).  Two waves per SIMD (and a register budget
+// of <= 128 VGPRs, i.e. two co-resident workgroups when the grid is large enough) cover the LDS and HBM latencies
+// that a single wave per SIMD exposes.
 // LDS image: [row][k] bf16 with a 40-element (80 B) pitch -> ds_read_b128 fragment reads and ds_write_b64 staging
 // writes are at worst 2-way conflicted for both operand orientations.
 // Operand orientations: k-contiguous (nn.Linear forward), k-strided (dgrad's W, wgrad's dY and X; transposed in the
 // staging path), and an implicit-GEMM gather of NHWC images for Conv2d / ConvTranspose2d.
+// The K loop is straight-line code: every global load is unconditional (addresses clamped into the matrix), the K
+// tail is zeroed by an AND mask on the A operand only, and partial staging iterations are executed redundantly by the
+// otherwise idle threads.  (A guarded load, or a select/branch behind one, makes hipcc wait for every load
+// individually; a dynamically indexed accumulator array is demoted to scratch memory.)
 #include "common.h"
 
 #define GBM 128
 #define GBK 32
 #define GLP 40
+#define GNT 512
 
-struct ConvRow {  // per staged A row of the implicit-GEMM gather
-  int64_t base;   // frame offset in floats, -1 if the row is out of range
-  int oy, ox;
-};
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-__device__ __forceinline__ uint2 pack_hi4(const float4 v) {
-  bf16x4 h;
-  h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-  return *reinterpret_cast<uint2*>(&h);
+__device__ __forceinline__ float4 mask4(const float4 v, const unsigned m) {
+  float4 o;
+  o.x = __uint_as_float(__float_as_uint(v.x) & m);
+  o.y = __uint_as_float(__float_as_uint(v.y) & m);
+  o.z = __uint_as_float(__float_as_uint(v.z) & m);
+  o.w = __uint_as_float(__float_as_uint(v.w) & m);
+  return o;
 }
-__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
-  bf16x4 h, l;
-  h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-  l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
-  l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
-  hi = *reinterpret_cast<uint2*>(&h);
-  lo = *reinterpret_cast<uint2*>(&l);
+
+// two fp32 -> one dword of two bf16 (round-to-nearest-even): a single v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pk_bf16(const float a, const float b) {
+  const f32x2 f = {a, b};
+  const bf16x2 h = __builtin_convertvector(f, bf16x2);
+  return *reinterpret_cast<const uint32_t*>(&h);
+}
+// split-bf16: x = hi + lo + O(2^-17 |x|); hi = bf16(x), lo = bf16(x - hi).  6 VALU per pair.
+__device__ __forceinline__ void split2(const float a, const float b, uint32_t& hi, uint32_t& lo) {
+  hi = pk_bf16(a, b);
+  const float fa = __uint_as_float(hi << 16), fb = __uint_as_float(hi & 0xffff0000u);
+  lo = pk_bf16(a - fa, b - fb);
 }
 
 template <int NPASS>
 __device__ __forceinline__ void lds_put4(__bf16* s_hi, __bf16* s_lo, int row, int kc, const float4 v) {
   if constexpr (NPASS == 3) {
     uint2 hi, lo;
-    split4(v, hi, lo);
+    split2(v.x, v.y, hi.x, lo.x);
+    split2(v.z, v.w, hi.y, lo.y);
     *reinterpret_cast<uint2*>(&s_hi[row * GLP + kc]) = hi;
     *reinterpret_cast<uint2*>(&s_lo[row * GLP + kc]) = lo;
   } else {
-    *reinterpret_cast<uint2*>(&s_hi[row * GLP + kc]) = pack_hi4(v);
+    *reinterpret_cast<uint2*>(&s_hi[row * GLP + kc]) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
   }
 }
 
-// k-contiguous operand: ROWS x 32 fp32 tile, thread t loads float4 slots s = t + 256 i, row = s>>3, kc = (s&7)*4
-template <int ROWS>
+// thread -> slot of staging iteration i for a tile of NSLOT slots: full iterations use i*512 + tid; in a partial last
+// iteration (V valid slots) the surplus threads repeat slots of the first ones (same data, same LDS address).
+template <int NSLOT>
+__device__ __forceinline__ int slot_of(const int i, const int tid) {
+  constexpr int NIT = (NSLOT + GNT - 1) / GNT;
+  constexpr int V = NSLOT - GNT * (NIT - 1);
+  if (i < NIT - 1 || V == GNT) return GNT * i + tid;
+  if constexpr ((V & (V - 1)) == 0) return GNT * i + (tid & (V - 1));
+  static_assert((V & (V - 1)) == 0 || 2 * V >= GNT, "unsupported partial staging iteration");
+  return GNT * i + (tid >= V ? tid - V : tid);
+}
+
+// k-contiguous operand: ROWS x 32 fp32 tile, float4 slots, slot s -> row = s>>3, kc = (s&7)*4.
+// Masking policy: rows/columns beyond the matrix edge are never stored by the epilogue, so their (clamped, finite)
+// garbage needs no zeroing; only the K tail must contribute zero, and zeroing it in ONE operand (A: KMASK) is enough.
+template <int ROWS, int LROWS, bool KMASK>
 struct StageKC {
-  static constexpr int NIT = (ROWS * 8 + 255) / 256;
+  static constexpr int LDS_ROWS = LROWS;
+  static constexpr int NSLOT = ROWS * 8;
+  static constexpr int NIT = (NSLOT + GNT - 1) / GNT;
   float4 r[NIT];
+  unsigned kmask;
   __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0, int kend, int tid) {
+    const int kc = (tid & 7) << 2;  // the same in every iteration (slot bases and folds are multiples of 8)
+    const int kk = min(k0 + kc, kend - 4);
+    kmask = (k0 + kc < kend) ? 0xffffffffu : 0u;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int s = tid + 256 * i;
-      const int row = s >> 3, kc = (s & 7) << 2;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < ROWS && row0 + row < nrows && k0 + kc < kend)
-        v = *reinterpret_cast<const float4*>(P + (int64_t)(row0 + row) * ld + k0 + kc);
-      r[i] = v;
+      const int row = slot_of<NSLOT>(i, tid) >> 3;
+      r[i] = *reinterpret_cast<const float4*>(P + (int64_t)min(row0 + row, nrows - 1) * ld + kk);
     }
   }
   template <int NPASS>
   __device__ __forceinline__ void store(__bf16* s_hi, __bf16* s_lo, int tid) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int s = tid + 256 * i;
-      const int row = s >> 3, kc = (s & 7) << 2;
-      if (row < ROWS) lds_put4<NPASS>(s_hi, s_lo, row, kc, r[i]);
+      const int s = slot_of<NSLOT>(i, tid);
+      lds_put4<NPASS>(s_hi, s_lo, s >> 3, (s & 7) << 2, KMASK ? mask4(r[i], kmask) : r[i]);
     }
   }
 };
 
 // k-strided operand stored [K, ld] with the output dim contiguous: 4(k) x 4(out) micro-tiles, slot s -> kb = s&7
 // (k block of 4), ob = s>>3 (out block of 4); transposed in registers, 4 ds_write_b64 per slot.
-template <int ROWS>
+template <int LROWS, bool KMASK>
 struct StageKS {
-  static constexpr int NSLOT = ROWS * 2;
-  static constexpr int NIT = (NSLOT + 255) / 256;
+  static constexpr int LDS_ROWS = LROWS;
+  static constexpr int NSLOT = LROWS * 2;
+  static constexpr int NIT = (NSLOT + GNT - 1) / GNT;
   float4 r[NIT][4];
+  int nvalid;  // number of k rows of this thread's 4-row k block that lie inside the K range (<= 0: none, >= 4: all)
   __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0, int kend, int tid) {
+    const int kb = tid & 7;
+    nvalid = kend - (k0 + kb * 4);
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int s = tid + 256 * i;
-      const int kb = s & 7, ob = s >> 3;
-      const int gm = row0 + ob * 4;
+      const int ob = slot_of<NSLOT>(i, tid) >> 3;
+      const int mm = min(row0 + ob * 4, nrows - 4);  // nrows % 4 == 0 (checked on the host)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int gk = k0 + kb * 4 + j;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s < NSLOT && gk < kend) {
-          const float* src = P + (int64_t)gk * ld + gm;
-          if (gm + 3 < nrows) {
-            v = *reinterpret_cast<const float4*>(src);
-          } else {
-            if (gm < nrows) v.x = src[0];
-            if (gm + 1 < nrows) v.y = src[1];
-            if (gm + 2 < nrows) v.z = src[2];
-          }
-        }
-        r[i][j] = v;
-      }
+      for (int j = 0; j < 4; ++j)
+        r[i][j] = *reinterpret_cast<const float4*>(P + (int64_t)min(k0 + kb * 4 + j, kend - 1) * ld + mm);
     }
   }
   template <int NPASS>
   __device__ __forceinline__ void store(__bf16* s_hi, __bf16* s_lo, int tid) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int s = tid + 256 * i;
+      const int s = slot_of<NSLOT>(i, tid);
       const int kb = s & 7, ob = s >> 3;
-      if (s < NSLOT) {
-        lds_put4<NPASS>(s_hi, s_lo, ob * 4 + 0, kb * 4, make_float4(r[i][0].x, r[i][1].x, r[i][2].x, r[i][3].x));
-        lds_put4<NPASS>(s_hi, s_lo, ob * 4 + 1, kb * 4, make_float4(r[i][0].y, r[i][1].y, r[i][2].y, r[i][3].y));
-        lds_put4<NPASS>(s_hi, s_lo, ob * 4 + 2, kb * 4, make_float4(r[i][0].z, r[i][1].z, r[i][2].z, r[i][3].z));
-        lds_put4<NPASS>(s_hi, s_lo, ob * 4 + 3, kb * 4, make_float4(r[i][0].w, r[i][1].w, r[i][2].w, r[i][3].w));
-      }
+      const unsigned m0 = nvalid > 0 ? ~0u : 0u, m1 = nvalid > 1 ? ~0u : 0u, m2 = nvalid > 2 ? ~0u : 0u, m3 = nvalid > 3 ? ~0u : 0u;
+      const float4 v0 = KMASK ? mask4(r[i][0], m0) : r[i][0], v1 = KMASK ? mask4(r[i][1], m1) : r[i][1];
+      const float4 v2 = KMASK ? mask4(r[i][2], m2) : r[i][2], v3 = KMASK ? mask4(r[i][3], m3) : r[i][3];
+      lds_put4<NPASS>(s_hi, s_lo, ob * 4 + 0, kb * 4, make_float4(v0.x, v1.x, v2.x, v3.x));
+      lds_put4<NPASS>(s_hi, s_lo, ob * 4 + 1, kb * 4, make_float4(v0.y, v1.y, v2.y, v3.y));
+      lds_put4<NPASS>(s_hi, s_lo, ob * 4 + 2, kb * 4, make_float4(v0.z, v1.z, v2.z, v3.z));
+      lds_put4<NPASS>(s_hi, s_lo, ob * 4 + 3, kb * 4, make_float4(v0.w, v1.w, v2.w, v3.w));
     }
   }
 };
 
-// implicit-GEMM gather of an NHWC image (Conv2d / gather-form ConvTranspose2d); same slot map as StageKC
+// implicit-GEMM gather of an NHWC image (Conv2d / gather-form ConvTranspose2d); slot map of StageKC<128>
 struct StageConv {
-  static constexpr int NIT = 4;  // GBM * 8 / 256
+  static constexpr int LDS_ROWS = GBM;
+  static constexpr int NIT = GBM * 8 / GNT;  // 2
   float4 r[NIT];
-  ConvRow cr[NIT];
-  __device__ __forceinline__ void init(const vptr_gemm_desc& p, int row0, int tid) {
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int row = (tid + 256 * i) >> 3;
-      const int gm = row0 + row;
-      if (gm < p.M) {
-        const int per = p.conv_OH * p.conv_OW;
-        const int f = gm / per, rem = gm - f * per;
-        cr[i].oy = rem / p.conv_OW;
-        cr[i].ox = rem - cr[i].oy * p.conv_OW;
-        cr[i].base = (int64_t)f * p.conv_IH * p.conv_IW * p.conv_Cin;
-      } else {
-        cr[i].base = -1; cr[i].oy = 0; cr[i].ox = 0;
-      }
-    }
-  }
-  __device__ __forceinline__ int map_coord(int o, int kk, int I, const vptr_gemm_desc& p) const {
-    if (p.conv_transposed) {
+  unsigned okbits;
+  // source coordinate, or -1 when the tap contributes zero; selects only (no divergent branches)
+  static __device__ __forceinline__ int map_coord(int o, int kk, int I, const vptr_gemm_desc& p) {
+    if (p.conv_transposed) {  // kernel-uniform
       const int num = o + p.conv_pad - kk;
-      if (num < 0) return -1;
-      const int q = num / p.conv_stride;
-      if (q * p.conv_stride != num || q >= I) return -1;
-      return q;
+      const int q = (p.conv_stride == 2) ? (num >> 1) : (num / p.conv_stride);
+      const bool ok = (num >= 0) & (q * p.conv_stride == num) & (q < I);
+      return ok ? q : -1;
     }
-    int c = o * p.conv_stride - p.conv_pad + kk;
-    if (c < 0 || c >= I) {
-      if (p.conv_pad_mode == VPTR_PAD_ZERO) return -1;
-      if (p.conv_pad_mode == VPTR_PAD_REFLECT) c = c < 0 ? -c : 2 * I - 2 - c;
-      else c = c < 0 ? 0 : I - 1;
-    }
-    return c;
+    const int c = o * p.conv_stride - p.conv_pad + kk;
+    const bool inside = (c >= 0) & (c < I);
+    const int refl = c < 0 ? -c : 2 * I - 2 - c;
+    const int repl = c < 0 ? 0 : I - 1;
+    const int outv = p.conv_pad_mode == VPTR_PAD_ZERO ? -1 : (p.conv_pad_mode == VPTR_PAD_REFLECT ? refl : repl);
+    return inside ? c : outv;
   }
-  __device__ __forceinline__ void load(const vptr_gemm_desc& p, int k0, int kend, int tid) {
+  __device__ __forceinline__ void load(const vptr_gemm_desc& p, int row0, int k0, int kend, int tid) {
     const int kc = (tid & 7) << 2;
-    const int gk = k0 + kc;
+    const int gk = min(k0 + kc, kend - 4);
+    const bool okk = (k0 + kc) < kend;
     const int tap = gk / p.conv_Cin, ci = gk - tap * p.conv_Cin;
     const int ky = tap / p.conv_KW, kx = tap - ky * p.conv_KW;
+    const int per = p.conv_OH * p.conv_OW;
+    okbits = 0;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (cr[i].base >= 0 && gk < kend) {
-        const int iy = map_coord(cr[i].oy, ky, p.conv_IH, p);
-        const int ix = map_coord(cr[i].ox, kx, p.conv_IW, p);
-        if (iy >= 0 && ix >= 0)
-          v = *reinterpret_cast<const float4*>(p.A + cr[i].base + ((int64_t)iy * p.conv_IW + ix) * p.conv_Cin + ci);
-      }
-      r[i] = v;
+      const int gm = row0 + ((tid + GNT * i) >> 3);
+      const int gmc = min(gm, p.M - 1);
+      const int f = gmc / per, rem = gmc - f * per;
+      const int oy = rem / p.conv_OW, ox = rem - oy * p.conv_OW;
+      const int iy = map_coord(oy, ky, p.conv_IH, p);
+      const int ix = map_coord(ox, kx, p.conv_IW, p);
+      const bool ok = okk & (iy >= 0) & (ix >= 0);
+      const int64_t off = ((int64_t)(f * p.conv_IH + max(iy, 0)) * p.conv_IW + max(ix, 0)) * p.conv_Cin + ci;
+      r[i] = *reinterpret_cast<const float4*>(p.A + off);
+      okbits |= (ok ? 1u : 0u) << i;
     }
   }
   template <int NPASS>
   __device__ __forceinline__ void store(__bf16* s_hi, __bf16* s_lo, int tid) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int s = tid + 256 * i;
-      lds_put4<NPASS>(s_hi, s_lo, s >> 3, (s & 7) << 2, r[i]);
+      const int s = tid + GNT * i;
+      lds_put4<NPASS>(s_hi, s_lo, s >> 3, (s & 7) << 2, mask4(r[i], 0u - ((okbits >> i) & 1u)));
     }
   }
 };
 
 template <int NFN, int NPASS, int AMODE, int BMODE>
-__global__ __launch_bounds__(256) void vptr_gemm_kernel(const vptr_gemm_desc p, const int k_chunk) {
+__global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc p, const int k_chunk) {
   constexpr int BN = 16 * NFN;
+  constexpr int NFW = (NFN + 1) / 2;     // column fragments per wave
+  constexpr int BROWS = 2 * NFW * 16;    // LDS rows of the B image (>= BN; the surplus rows feed never-stored fragments)
   constexpr int NPL = (NPASS == 3) ? 2 : 1;
+  using StA = typename std::conditional<AMODE == VPTR_A_KCONTIG, StageKC<GBM, GBM, true>,
+                                        typename std::conditional<AMODE == VPTR_A_KSTRIDED, StageKS<GBM, true>, StageConv>::type>::type;
+  using StB = typename std::conditional<BMODE == VPTR_B_KCONTIG, StageKC<BN, BROWS, false>, StageKS<BROWS, false>>::type;
   __shared__ __attribute__((aligned(16))) __bf16 sA[NPL][GBM * GLP];
-  __shared__ __attribute__((aligned(16))) __bf16 sB[NPL][BN * GLP];
+  __shared__ __attribute__((aligned(16))) __bf16 sB[NPL][BROWS * GLP];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 15, lq = lane >> 4;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
@@ -202,42 +219,40 @@ __global__ __launch_bounds__(256) void vptr_gemm_kernel(const vptr_gemm_desc p, 
   const int kend = min(p.K, kbeg + k_chunk);
   const int nkt = (kend - kbeg + GBK - 1) / GBK;
 
-  f32x4 acc[2][NFN];
+  f32x4 acc[2][NFW];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < NFN; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ni = 0; ni < NFW; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  typename std::conditional<AMODE == VPTR_A_KCONTIG, StageKC<GBM>,
-                            typename std::conditional<AMODE == VPTR_A_KSTRIDED, StageKS<GBM>, StageConv>::type>::type stA;
-  typename std::conditional<BMODE == VPTR_B_KCONTIG, StageKC<BN>, StageKS<BN>>::type stB;
-
-  if constexpr (AMODE == VPTR_A_CONV) stA.init(p, m0, tid);
-
-  auto loadA = [&](int k0) {
-    if constexpr (AMODE == VPTR_A_CONV) stA.load(p, k0, kend, tid);
-    else stA.load(p.A, p.lda, m0, p.M, k0, kend, tid);
-  };
-  auto loadB = [&](int k0) { stB.load(p.B, p.ldb, n0, p.N, k0, kend, tid); };
-
-  if (nkt > 0) { loadA(kbeg); loadB(kbeg); }
+  StA stA;
+  StB stB;
+  // K-step j+1 is fetched into registers while step j is multiplied out of LDS (single LDS image, two barriers per step);
+  // the other resident waves of the SIMD cover what is left of the HBM / LDS latencies.
+  if constexpr (AMODE == VPTR_A_CONV) stA.load(p, m0, kbeg, kend, tid);
+  else stA.load(p.A, p.lda, m0, p.M, kbeg, kend, tid);
+  stB.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid);
 
   for (int kt = 0; kt < nkt; ++kt) {
     stA.template store<NPASS>(sA[0], sA[NPL - 1], tid);
     stB.template store<NPASS>(sB[0], sB[NPL - 1], tid);
     __syncthreads();
-    if (kt + 1 < nkt) { loadA(kbeg + (kt + 1) * GBK); loadB(kbeg + (kt + 1) * GBK); }
-
+    {  // unconditional prefetch of the next step (clamped + masked beyond the K range)
+      const int k1 = kbeg + (kt + 1) * GBK;
+      if constexpr (AMODE == VPTR_A_CONV) stA.load(p, m0, k1, kend, tid);
+      else stA.load(p.A, p.lda, m0, p.M, k1, kend, tid);
+      stB.load(p.B, p.ldb, n0, p.N, k1, kend, tid);
+    }
     bf16x8 ah[2], al[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      const int off = (wave * 32 + mi * 16 + lr) * GLP + lq * 8;
+      const int off = (wm * 32 + mi * 16 + lr) * GLP + lq * 8;
       ah[mi] = *reinterpret_cast<const bf16x8*>(&sA[0][off]);
       if constexpr (NPASS == 3) al[mi] = *reinterpret_cast<const bf16x8*>(&sA[NPL - 1][off]);
     }
 #pragma unroll
-    for (int ni = 0; ni < NFN; ++ni) {
-      const int off = (ni * 16 + lr) * GLP + lq * 8;
+    for (int ni = 0; ni < NFW; ++ni) {
+      const int off = ((wn * NFW + ni) * 16 + lr) * GLP + lq * 8;
       const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&sB[0][off]);
       bf16x8 bl;
       if constexpr (NPASS == 3) bl = *reinterpret_cast<const bf16x8*>(&sB[NPL - 1][off]);
@@ -253,34 +268,63 @@ __global__ __launch_bounds__(256) void vptr_gemm_kernel(const vptr_gemm_desc p, 
     __syncthreads();
   }
 
-  // ---- epilogue: C/D fragment layout of v_mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
+  // ---- epilogue: C/D fragment layout of v_mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg.
+  // Every acc index is a compile-time constant (fully unrolled, no `continue`).
   const bool first_split = (blockIdx.z == 0);
   const bool use_atomic = p.atomic || gridDim.z > 1;
-  uint64_t seed = 0;
-  if (p.dropout_p > 0.f) seed = *p.seed_dev;
+  const bool plain = !p.colscale && !p.Dpre && p.act == VPTR_ACT_NONE && !p.rowscale && p.dropout_p == 0.f && !p.act_after &&
+                     p.alpha == 1.f;
+  const int row_base = m0 + wm * 32 + lq * 4;
+  if (plain) {  // kernel-uniform fast path: bias (+ residual), store or atomic accumulate
 #pragma unroll
-  for (int ni = 0; ni < NFN; ++ni) {
-    const int col = n0 + ni * 16 + lr;
-    if (col >= p.N) continue;
-    const float cs = p.colscale ? p.colscale[col] : 1.f;
-    const float bs = (p.bias && first_split) ? p.bias[col] : 0.f;
+    for (int ni = 0; ni < NFW; ++ni) {
+      const int nf = wn * NFW + ni;
+      const int col = n0 + nf * 16 + lr;
+      const bool colok = (nf < NFN) & (col < p.N);
+      const float bs = (p.bias && first_split && colok) ? p.bias[col] : 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+      for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wave * 32 + mi * 16 + lq * 4 + r;
-        if (row >= p.M) continue;
-        float v = acc[mi][ni][r];
-        v = (v * cs + bs) * p.alpha;
-        if (p.Dpre) p.Dpre[(int64_t)row * p.ldd + col] = v;
-        v = vptr_act(v, p.act);
-        if (p.rowscale) v *= p.rowscale[(row / p.rs_div) % p.rs_mod];
-        if (p.dropout_p > 0.f) v *= vptr_drop_scale(seed, p.site, (uint64_t)row * (uint64_t)p.N + col, p.dropout_p);
-        if (p.residual && first_split) v += p.residual[(int64_t)row * p.ldr + col];
-        if (p.act_after) v = v > 0.f ? v : 0.f;
-        float* dst = p.D + (int64_t)row * p.ldd + col;
-        if (use_atomic) unsafeAtomicAdd(dst, v);
-        else *dst = v;
+        for (int r = 0; r < 4; ++r) {
+          const int row = row_base + mi * 16 + r;
+          if (colok && row < p.M) {
+            float v = acc[mi][ni][r] + bs;
+            if (p.residual && first_split) v += p.residual[(int64_t)row * p.ldr + col];
+            float* dst = p.D + (int64_t)row * p.ldd + col;
+            if (use_atomic) unsafeAtomicAdd(dst, v);
+            else *dst = v;
+          }
+        }
+      }
+    }
+  } else {
+    uint64_t seed = 0;
+    if (p.dropout_p > 0.f) seed = *p.seed_dev;
+#pragma unroll
+    for (int ni = 0; ni < NFW; ++ni) {
+      const int nf = wn * NFW + ni;
+      const int col = n0 + nf * 16 + lr;
+      const bool colok = (nf < NFN) & (col < p.N);
+      const float bs = (p.bias && first_split && colok) ? p.bias[col] : 0.f;
+      const float cs = (p.colscale && colok) ? p.colscale[col] : 1.f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row_base + mi * 16 + r;
+          if (colok && row < p.M) {
+            float v = (acc[mi][ni][r] * cs + bs) * p.alpha;
+            if (p.Dpre) p.Dpre[(int64_t)row * p.ldd + col] = v;
+            v = vptr_act(v, p.act);
+            if (p.rowscale) v *= p.rowscale[(row / p.rs_div) % p.rs_mod];
+            if (p.dropout_p > 0.f) v *= vptr_drop_scale(seed, p.site, (uint64_t)row * (uint64_t)p.N + col, p.dropout_p);
+            if (p.residual && first_split) v += p.residual[(int64_t)row * p.ldr + col];
+            if (p.act_after) v = v > 0.f ? v : 0.f;
+            float* dst = p.D + (int64_t)row * p.ldd + col;
+            if (use_atomic) unsafeAtomicAdd(dst, v);
+            else *dst = v;
+          }
+        }
       }
     }
   }
@@ -289,17 +333,15 @@ __global__ __launch_bounds__(256) void vptr_gemm_kernel(const vptr_gemm_desc p, 
 template <int NFN, int NPASS>
 static int launch_modes(const vptr_gemm_desc& d, dim3 grid, int k_chunk, hipStream_t st) {
   if (d.a_mode == VPTR_A_KCONTIG && d.b_mode == VPTR_B_KCONTIG)
-    vptr_gemm_kernel<NFN, NPASS, VPTR_A_KCONTIG, VPTR_B_KCONTIG><<<grid, 256, 0, st>>>(d, k_chunk);
+    vptr_gemm_kernel<NFN, NPASS, VPTR_A_KCONTIG, VPTR_B_KCONTIG><<<grid, GNT, 0, st>>>(d, k_chunk);
   else if (d.a_mode == VPTR_A_KCONTIG && d.b_mode == VPTR_B_KSTRIDED)
-    vptr_gemm_kernel<NFN, NPASS, VPTR_A_KCONTIG, VPTR_B_KSTRIDED><<<grid, 256, 0, st>>>(d, k_chunk);
+    vptr_gemm_kernel<NFN, NPASS, VPTR_A_KCONTIG, VPTR_B_KSTRIDED><<<grid, GNT, 0, st>>>(d, k_chunk);
   else if (d.a_mode == VPTR_A_KSTRIDED && d.b_mode == VPTR_B_KSTRIDED)
-    vptr_gemm_kernel<NFN, NPASS, VPTR_A_KSTRIDED, VPTR_B_KSTRIDED><<<grid, 256, 0, st>>>(d, k_chunk);
+    vptr_gemm_kernel<NFN, NPASS, VPTR_A_KSTRIDED, VPTR_B_KSTRIDED><<<grid, GNT, 0, st>>>(d, k_chunk);
   else if (d.a_mode == VPTR_A_KSTRIDED && d.b_mode == VPTR_B_KCONTIG)
-    vptr_gemm_kernel<NFN, NPASS, VPTR_A_KSTRIDED, VPTR_B_KCONTIG><<<grid, 256, 0, st>>>(d, k_chunk);
+    vptr_gemm_kernel<NFN, NPASS, VPTR_A_KSTRIDED, VPTR_B_KCONTIG><<<grid, GNT, 0, st>>>(d, k_chunk);
   else if (d.a_mode == VPTR_A_CONV && d.b_mode == VPTR_B_KCONTIG)
-    vptr_gemm_kernel<NFN, NPASS, VPTR_A_CONV, VPTR_B_KCONTIG><<<grid, 256, 0, st>>>(d, k_chunk);
-  else if (d.a_mode == VPTR_A_CONV && d.b_mode == VPTR_B_KSTRIDED)
-    vptr_gemm_kernel<NFN, NPASS, VPTR_A_CONV, VPTR_B_KSTRIDED><<<grid, 256, 0, st>>>(d, k_chunk);
+    vptr_gemm_kernel<NFN, NPASS, VPTR_A_CONV, VPTR_B_KCONTIG><<<grid, GNT, 0, st>>>(d, k_chunk);
   else {
     vptr_set_error("vptr_gemm: unsupported operand modes a=%d b=%d", d.a_mode, d.b_mode);
     return -1;
@@ -322,10 +364,12 @@ extern "C" int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream) {
   VPTR_CHECK(d.A && d.B && d.D, "vptr_gemm: null operand");
   VPTR_CHECK(d.precision == 1 || d.precision == 3, "vptr_gemm: precision must be 1 or 3 (got %d)", d.precision);
   VPTR_CHECK(al16(d.A) && al16(d.B), "vptr_gemm: A and B must be 16-byte aligned");
-  if (d.a_mode == VPTR_A_KCONTIG) VPTR_CHECK(d.lda % 4 == 0 && d.K % 4 == 0, "vptr_gemm: k-contiguous A needs lda%%4==0 and K%%4==0");
-  if (d.a_mode == VPTR_A_KSTRIDED) VPTR_CHECK(d.lda % 4 == 0, "vptr_gemm: k-strided A needs lda%%4==0");
-  if (d.b_mode == VPTR_B_KCONTIG) VPTR_CHECK(d.ldb % 4 == 0 && d.K % 4 == 0, "vptr_gemm: k-contiguous B needs ldb%%4==0 and K%%4==0");
-  if (d.b_mode == VPTR_B_KSTRIDED) VPTR_CHECK(d.ldb % 4 == 0, "vptr_gemm: k-strided B needs ldb%%4==0");
+  if (d.a_mode != VPTR_A_KSTRIDED || d.b_mode != VPTR_B_KSTRIDED)
+    VPTR_CHECK(d.K % 4 == 0, "vptr_gemm: K must be a multiple of 4 for k-contiguous operands (got %d)", d.K);
+  if (d.a_mode == VPTR_A_KCONTIG) VPTR_CHECK(d.lda % 4 == 0, "vptr_gemm: k-contiguous A needs lda%%4==0");
+  if (d.a_mode == VPTR_A_KSTRIDED) VPTR_CHECK(d.lda % 4 == 0 && d.M % 4 == 0, "vptr_gemm: k-strided A needs lda%%4==0 and M%%4==0");
+  if (d.b_mode == VPTR_B_KCONTIG) VPTR_CHECK(d.ldb % 4 == 0, "vptr_gemm: k-contiguous B needs ldb%%4==0");
+  if (d.b_mode == VPTR_B_KSTRIDED) VPTR_CHECK(d.ldb % 4 == 0 && d.N % 4 == 0, "vptr_gemm: k-strided B needs ldb%%4==0 and N%%4==0");
   if (d.a_mode == VPTR_A_CONV) {
     VPTR_CHECK(d.conv_Cin % 4 == 0, "vptr_gemm(conv): Cin must be a multiple of 4 (got %d)", d.conv_Cin);
     VPTR_CHECK(d.K == d.conv_KH * d.conv_KW * d.conv_Cin, "vptr_gemm(conv): K != KH*KW*Cin");

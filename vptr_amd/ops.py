@@ -100,8 +100,34 @@ def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None
     if conv is not None:
         (d.conv_IH, d.conv_IW, d.conv_Cin, d.conv_OH, d.conv_OW, d.conv_KH, d.conv_KW, d.conv_stride, d.conv_pad,
          d.conv_pad_mode, d.conv_transposed) = conv
+    prof = _gemm_prof
+    if prof is not None:  # bench.py roofline pass: HIP events on the launch stream around every GEMM launch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib.vptr_gemm(ctypes.byref(d), stream()), "vptr_gemm")
+    if prof is not None:
+        e1.record()
+        prof.append(((gemm_nfn(N), d.precision, a_mode, b_mode), 2.0 * M * N * K, e0, e1))
     return D
+
+
+_gemm_prof = None
+
+
+def gemm_nfn(N):
+    """Column-fragment count of the kernel instantiation vptr_gemm picks for an N-wide output (mirrors csrc/gemm.hip)."""
+    if N % 176 == 0:
+        return 11
+    if N <= 64:
+        return 4
+    if N <= 128:
+        return 8
+    cands = [((N + 175) // 176 * 176, 11), ((N + 127) // 128 * 128, 8), ((N + 63) // 64 * 64, 4)]
+    best = cands[0]
+    for c in cands[1:]:
+        if c[0] < best[0]:
+            best = c
+    return best[1]
 
 
 def _split_k_for(tiles, K):
