@@ -71,51 +71,74 @@ extern "C" int vptr_conv7_in_fwd(const float* x, const float* w, const float* sc
   return 0;
 }
 
-// thread per output pixel; filter [Cimg][49][Cin] in LDS, broadcast float4 reads
+// One wave per 2 x 8 patch of output pixels, lane = input channel (Cin == 64): every input pixel vector is one coalesced
+// 256-B load that feeds up to 7 x 2 outputs from registers; the 49 taps of the lane's channel sit in VGPRs (filter bank
+// staged once per workgroup in LDS as [Cimg][49][64]); each output is finished by a wave reduction.
 __global__ __launch_bounds__(256) void conv7_out_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ y, int B,
-                                                            int Cin, int H, int W, int Cimg, int out_act) {
-  extern __shared__ __attribute__((aligned(16))) float sw[];  // [Cimg][49][Cin]
-  const int tid = threadIdx.x;
-  for (int i = tid; i < Cimg * 49 * Cin; i += 256) {
-    const int ci = i % Cin, tap = (i / Cin) % 49, co = i / (Cin * 49);
-    sw[i] = w[(co * Cin + ci) * 49 + tap];
+                                                            int H, int W, int Cimg, int out_act) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [Cimg][49][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < Cimg * 49 * 64; i += 256) {
+    const int ci = i & 63, tap = (i >> 6) % 49, co = i / (64 * 49);
+    sw[i] = w[(co * 64 + ci) * 49 + tap];
   }
   __syncthreads();
-  const int64_t pix = (int64_t)blockIdx.x * 256 + tid;
-  const int64_t npix = (int64_t)B * H * W;
-  if (pix >= npix) return;
-  const int ox = (int)(pix % W), oy = (int)((pix / W) % H);
-  const int b = (int)(pix / ((int64_t)W * H));
-  const int C4 = Cin >> 2;
+  const int strips_x = (W + 7) / 8, strips_y = (H + 1) / 2;
+  const int64_t patch = (int64_t)blockIdx.x * 4 + (tid >> 6);
+  if (patch >= (int64_t)B * strips_y * strips_x) return;
+  const int sx = (int)(patch % strips_x), sy = (int)((patch / strips_x) % strips_y);
+  const int b = (int)(patch / ((int64_t)strips_x * strips_y));
+  const int x0 = sx * 8, y0 = sy * 2;
   for (int co = 0; co < Cimg; ++co) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int ky = 0; ky < 7; ++ky) {
-      const int iy = reflect_idx(oy + ky - 3, H);
-      for (int kx = 0; kx < 7; ++kx) {
-        const int ix = reflect_idx(ox + kx - 3, W);
-        const float4* xp = reinterpret_cast<const float4*>(x + (((int64_t)b * H + iy) * W + ix) * Cin);
-        const float4* wp = reinterpret_cast<const float4*>(sw + (co * 49 + ky * 7 + kx) * Cin);
-        for (int c = 0; c < C4; ++c) {
-          const float4 xv = xp[c], wv = wp[c];
-          a0 += xv.x * wv.x; a1 += xv.y * wv.y; a2 += xv.z * wv.z; a3 += xv.w * wv.w;
+    float wr[49];
+#pragma unroll
+    for (int t = 0; t < 49; ++t) wr[t] = sw[(co * 49 + t) * 64 + lane];
+    float acc[2][8];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[r][q] = 0.f;
+#pragma unroll
+    for (int ry = 0; ry < 8; ++ry) {      // input rows y0-3 .. y0+4 cover output rows y0 (ky = ry) and y0+1 (ky = ry-1)
+      const int iy = reflect_idx(y0 + ry - 3, H);
+      const float* xrow = x + (((int64_t)b * H + iy) * W) * 64 + lane;
+#pragma unroll
+      for (int cx = 0; cx < 14; ++cx) {   // input cols x0-3 .. x0+10
+        const int ix = reflect_idx(min(x0 + cx - 3, W + 2), W);
+        const float xv = xrow[(int64_t)ix * 64];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int kx = cx - q;
+          if (kx >= 0 && kx < 7) {
+            if (ry < 7) acc[0][q] += xv * wr[ry * 7 + kx];
+            if (ry >= 1) acc[1][q] += xv * wr[(ry - 1) * 7 + kx];
+          }
         }
       }
     }
-    float v = (a0 + a1) + (a2 + a3) + bias[co];
-    if (out_act == 1) v = tanhf(v);
-    else if (out_act == 2) v = 1.f / (1.f + __expf(-v));
-    y[(((int64_t)b * Cimg + co) * H + oy) * W + ox] = v;
+    const float bco = bias[co];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float v = wave_sum(acc[r][q]) + bco;
+        if (out_act == 1) v = tanhf(v);
+        else if (out_act == 2) v = 1.f / (1.f + __expf(-v));
+        const int oy = y0 + r, ox = x0 + q;
+        if (lane == 0 && oy < H && ox < W) y[(((int64_t)b * Cimg + co) * H + oy) * W + ox] = v;
+      }
   }
 }
 
 extern "C" int vptr_conv7_out_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
                                   int Cimg, int out_act, vptr_stream_t stream) {
-  VPTR_CHECK(B > 0 && Cin > 0 && Cin % 4 == 0 && H > 3 && W > 3 && Cimg > 0, "conv7_out_fwd: bad arguments");
-  const size_t lds = sizeof(float) * Cimg * 49 * Cin;
+  VPTR_CHECK(B > 0 && H > 3 && W > 3 && Cimg > 0, "conv7_out_fwd: bad arguments");
+  VPTR_CHECK(Cin == 64, "conv7_out_fwd: Cin must be 64 (ngf of the reference decoder), got %d", Cin);
+  const size_t lds = sizeof(float) * Cimg * 49 * 64;
   VPTR_CHECK(lds <= 64 * 1024, "conv7_out_fwd: filter bank too large for LDS");
-  const int64_t npix = (int64_t)B * H * W;
-  conv7_out_fwd_kernel<<<cdiv(npix, 256), 256, lds, (hipStream_t)stream>>>(x, w, bias, y, B, Cin, H, W, Cimg, out_act);
+  const int64_t patches = (int64_t)B * ((H + 1) / 2) * ((W + 7) / 8);
+  conv7_out_fwd_kernel<<<cdiv(patches, 4), 256, lds, (hipStream_t)stream>>>(x, w, bias, y, B, H, W, Cimg, out_act);
   VPTR_LAUNCH_CHECK();
   return 0;
 }

@@ -376,47 +376,87 @@ __global__ __launch_bounds__(256) void norm_act_bwd_col_reduce(const float* __re
   unsafeAtomicAdd(acc + c, aw);
   unsafeAtomicAdd(acc + F + c, ab);
 }
-// phase 1, per-frame (LN over (F,H,W)): block per (frame, column slab): frame sums s1 = sum g*w, s2 = sum g*w*xhat and
-// the affine gradients dw[hw,c] += g*xhat, db[hw,c] += g.
-__global__ __launch_bounds__(256) void norm_act_bwd_frame_reduce(const float* __restrict__ dy, const float* __restrict__ x,
+// phase 1a, per-frame (LN over (F,H,W)): a frame is one contiguous run of E = HW*F floats and the channel-last affine has
+// the same indexing, so the frame sums s1 = sum g*w, s2 = sum g*w*xhat are flat float4 reductions.  grid (frames, splits).
+__global__ __launch_bounds__(256) void norm_act_bwd_frame_sums(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ w, const float* __restrict__ b,
+                                                               float* __restrict__ fsum /* [2,frames] */, int E4, int F, int HW,
+                                                               int act, float p, const uint64_t* seed_dev, uint32_t site,
+                                                               int frames, const float* __restrict__ rowscale, int rs_div,
+                                                               int rs_mod) {
+  __shared__ float red[16];
+  const int f = blockIdx.x;
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  const float mu = mean[f], rs = rstd[f];
+  const int per = (E4 + gridDim.y - 1) / gridDim.y;
+  const int e0 = blockIdx.y * per, e1 = min(E4, e0 + per);
+  const float4* dyf = reinterpret_cast<const float4*>(dy) + (int64_t)f * E4;
+  const float4* xf = reinterpret_cast<const float4*>(x) + (int64_t)f * E4;
+  float t1 = 0.f, t2 = 0.f;
+  for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+    const float4 d = dyf[e], xv = xf[e];
+    const float4 wv = reinterpret_cast<const float4*>(w)[e], bv = reinterpret_cast<const float4*>(b)[e];
+    const int64_t i = ((int64_t)f * E4 + e) * 4;
+    float rsc = 1.f;
+    if (rowscale) rsc = rowscale[((f * HW + (e * 4) / F) / rs_div) % rs_mod];
+    const float dv[4] = {d.x, d.y, d.z, d.w}, xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    const float ws[4] = {wv.x, wv.y, wv.z, wv.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float xh = (xs[q] - mu) * rs;
+      const float ds = (p > 0.f ? vptr_drop_scale(seed, site, (uint64_t)(i + q), p) : 1.f) * rsc;
+      const float g = norm_act_g(dv[q], xh, ws[q], bs[q], act, ds) * ws[q];
+      t1 += g;
+      t2 += g * xh;
+    }
+  }
+  t1 = block_sum(t1, red);
+  t2 = block_sum(t2, red);
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(fsum + f, t1);
+    unsafeAtomicAdd(fsum + frames + f, t2);
+  }
+}
+// phase 1b: affine gradients dw[e] += sum_f g*xhat, db[e] += sum_f g; thread per float4 of the frame, loop over a frame chunk.
+__global__ __launch_bounds__(256) void norm_act_bwd_frame_affine(const float* __restrict__ dy, const float* __restrict__ x,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ w, const float* __restrict__ b,
-                                                                 float* __restrict__ fsum /* [2,frames] */,
-                                                                 float* __restrict__ dw, float* __restrict__ db, int F, int HW,
-                                                                 int act, float p, const uint64_t* seed_dev, uint32_t site,
-                                                                 int frames, int fpb, const float* __restrict__ rowscale,
-                                                                 int rs_div, int rs_mod) {
-  __shared__ float red[16];
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  const bool valid = c < F;
+                                                                 float* __restrict__ dw, float* __restrict__ db, int E4, int F,
+                                                                 int HW, int act, float p, const uint64_t* seed_dev,
+                                                                 uint32_t site, int frames, int fpb,
+                                                                 const float* __restrict__ rowscale, int rs_div, int rs_mod) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E4) return;
   uint64_t seed = 0;
   if (p > 0.f) seed = *seed_dev;
   const int f0 = blockIdx.y * fpb, f1 = min(frames, f0 + fpb);
-  for (int hw = 0; hw < HW; ++hw) {
-    float aw = 0.f, ab = 0.f;
-    const float ww = valid ? w[(int64_t)hw * F + c] : 0.f, bb = valid ? b[(int64_t)hw * F + c] : 0.f;
-    for (int f = f0; f < f1; ++f) {
-      float g = 0.f, xh = 0.f;
-      if (valid) {
-        const int64_t i = ((int64_t)f * HW + hw) * F + c;
-        xh = (x[i] - mean[f]) * rstd[f];
-        float ds = p > 0.f ? vptr_drop_scale(seed, site, (uint64_t)i, p) : 1.f;
-        if (rowscale) ds *= rowscale[((f * HW + hw) / rs_div) % rs_mod];
-        g = norm_act_g(dy[i], xh, ww, bb, act, ds);
-      }
-      aw += g * xh;
-      ab += g;
-      const float t1 = block_sum(g * ww, red);
-      const float t2 = block_sum(g * ww * xh, red);
-      if (threadIdx.x == 0) {
-        unsafeAtomicAdd(fsum + f, t1);
-        unsafeAtomicAdd(fsum + frames + f, t2);
-      }
+  const float4 wv = reinterpret_cast<const float4*>(w)[e], bv = reinterpret_cast<const float4*>(b)[e];
+  const float ws[4] = {wv.x, wv.y, wv.z, wv.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
+  float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+  const int hw = (e * 4) / F;
+  for (int f = f0; f < f1; ++f) {
+    const float4 d = reinterpret_cast<const float4*>(dy)[(int64_t)f * E4 + e];
+    const float4 xv = reinterpret_cast<const float4*>(x)[(int64_t)f * E4 + e];
+    const float mu = mean[f], rs = rstd[f];
+    const int64_t i = ((int64_t)f * E4 + e) * 4;
+    float rsc = 1.f;
+    if (rowscale) rsc = rowscale[((f * HW + hw) / rs_div) % rs_mod];
+    const float dv[4] = {d.x, d.y, d.z, d.w}, xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float xh = (xs[q] - mu) * rs;
+      const float ds = (p > 0.f ? vptr_drop_scale(seed, site, (uint64_t)(i + q), p) : 1.f) * rsc;
+      const float g = norm_act_g(dv[q], xh, ws[q], bs[q], act, ds);
+      aw[q] += g * xh;
+      ab[q] += g;
     }
-    if (valid) {
-      unsafeAtomicAdd(dw + (int64_t)hw * F + c, aw);
-      unsafeAtomicAdd(db + (int64_t)hw * F + c, ab);
-    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsafeAtomicAdd(dw + (int64_t)e * 4 + q, aw[q]);
+    unsafeAtomicAdd(db + (int64_t)e * 4 + q, ab[q]);
   }
 }
 // phase 2: dx = rstd * (g*w - S1/n - xhat*S2/n)
@@ -479,9 +519,15 @@ extern "C" int vptr_norm_act_bwd(const float* dy, const float* x, const float* m
     VPTR_CHECK(rows % HW == 0, "norm_act_bwd: rows must be a multiple of HW");
     const int frames = rows / HW;
     (void)hipMemsetAsync(scratch, 0, sizeof(float) * 2 * frames, st);
-    const int fpb = 8;
-    norm_act_bwd_frame_reduce<<<dim3(cdiv(F, 256), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, mean, rstd, w, b, scratch, dw, db, F,
-                                                                                    HW, act, dropout_p, seed_dev, site, frames, fpb, rowscale, rs_div, rs_mod);
+    VPTR_CHECK(F % 4 == 0, "norm_act_bwd: F must be a multiple of 4");
+    const int E4 = HW * F / 4;
+    const int splits = frames >= 512 ? 1 : (frames >= 128 ? 4 : 8);
+    norm_act_bwd_frame_sums<<<dim3(frames, splits), 256, 0, st>>>(dy, x, mean, rstd, w, b, scratch, E4, F, HW, act, dropout_p, seed_dev,
+                                                                 site, frames, rowscale, rs_div, rs_mod);
+    const int fpb = frames >= 64 ? (frames + 3) / 4 : frames;
+    norm_act_bwd_frame_affine<<<dim3(cdiv(E4, 256), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, mean, rstd, w, b, dw, db, E4, F, HW, act,
+                                                                                     dropout_p, seed_dev, site, frames, fpb, rowscale,
+                                                                                     rs_div, rs_mod);
     norm_act_bwd_dx_kernel<false><<<blocks, 256, 0, st>>>(dy, x, mean, rstd, w, b, scratch, dx, rows, F, HW, act, dropout_p,
                                                           seed_dev, site, frames, const_stats, rowscale, rs_div, rs_mod);
   }
@@ -571,7 +617,7 @@ extern "C" int vptr_dwconv3x3_bwd(const float* dy, const float* x, const float* 
   const int blocks = (int)hmin64((total + 255) / 256, 8192);
   if (dx) dwconv_fwd_kernel<<<blocks, 256, 0, st>>>(dy, w9, nullptr, dx, frames, H, W, F / 4, 1);
   if (dw9 && db) {
-    const int fpb = 4;
+    const int fpb = 1;
     dwconv_bwd_w_kernel<<<dim3(cdiv(F, 256), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F, fpb);
   }
   VPTR_LAUNCH_CHECK();

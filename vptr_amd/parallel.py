@@ -1,0 +1,50 @@
+"""Data-parallel plumbing for the VPTR train step: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over
+xGMI on the MI355X node; "gloo" for the CPU tests).
+
+The reference wraps its modules in DistributedDataParallel over NCCL (train_NAR_mp.py:94-118, 191-198).  What that
+does for this model is (a) a one-time broadcast of rank 0's parameters and buffers, (b) an all-reduce (mean) of the
+transformer's gradients every step.  Here (b) runs on the flat fp32 gradient slab of `FlatAdamW` in a few large
+buckets -- xGMI is point-to-point (7 links x ~153 GB/s per GPU), so collectives are per-link bound and large
+messages amortise the ring latency; 118 M fp32 gradients = 473.5 MB go out as ceil(473.5 / bucket_mb) calls instead
+of DDP's ~20 x 25 MB buckets over 664 tensors.  The decoder/encoder are frozen in stage 2 and are not reduced (the
+reference reduces decoder gradients nobody steps).  BatchNorm batch statistics stay per rank, like the reference (no
+SyncBN); running statistics are kept identical by broadcasting rank 0's buffers on demand (`broadcast_buffers`).
+"""
+import torch
+import torch.distributed as dist
+
+
+def broadcast_module(module, src=0, group=None):
+    """Make every rank hold rank `src`'s parameters and buffers (DDP constructor semantics)."""
+    with torch.no_grad():
+        for t in module.state_dict().values():
+            if t.is_floating_point() or t.dtype in (torch.int64, torch.int32):
+                dist.broadcast(t, src, group=group)
+
+
+def broadcast_buffers(module, src=0, group=None):
+    """DDP's per-forward buffer broadcast (BatchNorm running statistics of the NAR-encoder conv-FFNs)."""
+    with torch.no_grad():
+        for b in module.buffers():
+            dist.broadcast(b, src, group=group)
+
+
+def allreduce_mean_(flat, group=None, bucket_elems=16 << 20):
+    """In-place mean over ranks of a flat tensor, in buckets of `bucket_elems` elements (64 MB fp32 by default)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return flat
+    n = flat.numel()
+    for off in range(0, n, bucket_elems):
+        dist.all_reduce(flat[off:off + bucket_elems], op=dist.ReduceOp.SUM, group=group)
+    flat.mul_(1.0 / world)
+    return flat
+
+
+def shard_batch(global_batch, rank, world):
+    """The reference's DistributedSampler split: per-rank batch = global // world (utils/dataset.py:71-77).  Raises on
+    the degenerate configuration the reference script ships (batch 2 on 4 ranks -> 0 per rank, train_NAR_mp.py:297,313)."""
+    per = global_batch // world
+    if per < 1:
+        raise ValueError("global batch %d cannot be split over %d ranks" % (global_batch, world))
+    return rank * per, per

@@ -90,10 +90,8 @@ class NARTrainer:
     def _allreduce_grads(self):
         if self.pg is None or self.world == 1:
             return
-        g = self.opt.grad
-        for off in range(0, g.numel(), self.bucket_elems):
-            torch.distributed.all_reduce(g[off:off + self.bucket_elems], op=torch.distributed.ReduceOp.SUM, group=self.pg)
-        g.mul_(1.0 / self.world)
+        from .parallel import allreduce_mean_
+        allreduce_mean_(self.opt.grad, self.pg, self.bucket_elems)
 
     def losses(self, pred_frames, future, pred_feats, future_feats):
         a = self.T.NCE_projector(pred_feats.permute(0, 1, 3, 4, 2)).permute(0, 1, 4, 2, 3)
