@@ -165,11 +165,41 @@ extern "C" int vptr_rowmod_sum(const float* src, float* out, int rows, int C, in
   return 0;
 }
 
+// column sums: block = 32 float4 columns x 8 row lanes over a chunk of 256 rows; 32 independent float4 loads per thread,
+// LDS reduction over the row lanes, one atomic per column per block.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ src, float* __restrict__ out, int rows, int C4) {
+  __shared__ float4 red[8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c4 = blockIdx.x * 32 + tx;
+  const int r0 = blockIdx.y * 256, r1 = min(rows, r0 + 256);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 < C4) {
+#pragma unroll 4
+    for (int r = r0 + ty; r < r1; r += 8) {
+      const float4 v = reinterpret_cast<const float4*>(src)[(int64_t)r * C4 + c4];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  red[ty][tx] = a;
+  __syncthreads();
+  if (ty == 0 && c4 < C4) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { const float4 v = red[k][tx]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    unsafeAtomicAdd(out + c4 * 4 + 0, a.x);
+    unsafeAtomicAdd(out + c4 * 4 + 1, a.y);
+    unsafeAtomicAdd(out + c4 * 4 + 2, a.z);
+    unsafeAtomicAdd(out + c4 * 4 + 3, a.w);
+  }
+}
+
 extern "C" int vptr_colsum(const float* src, float* out, int rows, int C, vptr_stream_t stream) {
-  // column sum == rowmod_sum with one output row: use runs of 64 rows per block
   VPTR_CHECK(rows > 0 && C > 0, "colsum: empty input");
-  dim3 grid(cdiv(C, 256), 1, cdiv(rows, 64));
-  rowmod_sum_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, out, rows, C, 64, 1, 1);
+  if (C % 4 == 0) {
+    colsum_kernel<<<dim3(cdiv(C / 4, 32), cdiv(rows, 256)), 256, 0, (hipStream_t)stream>>>(src, out, rows, C / 4);
+  } else {  // odd widths: one output row of rowmod_sum, runs of 64 rows per block
+    dim3 grid(cdiv(C, 256), 1, cdiv(rows, 64));
+    rowmod_sum_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, out, rows, C, 64, 1, 1);
+  }
   VPTR_LAUNCH_CHECK();
   return 0;
 }

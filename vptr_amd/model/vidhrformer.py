@@ -93,18 +93,18 @@ class SpatialLocalMultiheadAttention(nn.Module):
         scale = float(C // nh) ** -0.5
         a = self.attn
         if self.rpe:
-            q = ops.linear(xqk, a.q_proj.weight, a.q_proj.bias, alpha=scale)
-            k = ops.linear(xqk, a.k_proj.weight, a.k_proj.bias)
-            v = ops.linear(xv, a.v_proj.weight, a.v_proj.bias)
+            Wq, Wk, Wv = a.q_proj.weight, a.k_proj.weight, a.v_proj.weight
+            bq, bk, bv = a.q_proj.bias, a.k_proj.bias, a.v_proj.bias
+            xin = xqk
             table, index = a.relative_position_bias_table, a.relative_position_index
         else:
             xin = ops.add_rowtab(xqk, self._window_pos_table(lw_pos, g.H, g.W), 1, g.H * g.W)
             Wq, Wk, Wv = a.in_proj_weight[:C], a.in_proj_weight[C:2 * C], a.in_proj_weight[2 * C:]
             bq, bk, bv = a.in_proj_bias[:C], a.in_proj_bias[C:2 * C], a.in_proj_bias[2 * C:]
-            q = ops.linear(xin, Wq, bq, alpha=scale)
-            k = ops.linear(xin, Wk, bk)
-            v = ops.linear(xv, Wv, bv)
             table, index = None, None
+        q = ops.linear(xin, Wq, bq, alpha=scale)
+        k = ops.linear(xin, Wk, bk)
+        v = ops.linear(xv, Wv, bv)
         o = ops.window_attention(q, k, v, table, index, g.N * g.T, g.H, g.W, nh, ws, p, site)
         return ops.linear(o, a.out_proj.weight, a.out_proj.bias, residual=residual, rowscale=rowscale, rs_div=rs_div,
                           rs_mod=rs_mod)

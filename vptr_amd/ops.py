@@ -23,7 +23,6 @@ class _Config:
                     1 = single-pass bf16 MFMA (fastest; ~1e-2 end-to-end deviation from the fp32 reference)
     """
     gemm_precision = 3
-    dec_weight_grads = True  # the reference leaves VPTRDec trainable in stage 2 (train_NAR.py:190-191)
 
 
 config = _Config()
@@ -69,6 +68,10 @@ def manual_seed(device, value):
 
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
+
+
+# (Measured and rejected this round: running the q/k/v projections on forked HIP streams -- no gain on the MI355X,
+# 110.9 vs 108.7 ms/step, and the cross-stream gradient accumulation into the flat slab needs extra fencing.)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -137,6 +140,36 @@ def _split_k_for(tiles, K):
     return max(1, min((512 + tiles - 1) // tiles, K // 256))
 
 
+_flat_slabs = []  # (param_base_ptr, nbytes, grad_slab) registered by vptr_amd.train.FlatAdamW
+
+
+def register_flat_slab(param_slab, grad_slab):
+    """Parameters that live inside `param_slab` have their gradient at the same offset of `grad_slab`: backward kernels
+    then accumulate weight gradients straight into the slab (fp32 atomics) instead of materialising a zero-filled
+    temporary that autograd adds to `.grad` (2 extra launches and 3 passes over every parameter per step)."""
+    import weakref
+    _flat_slabs.append((param_slab.data_ptr(), param_slab.numel() * 4, weakref.ref(param_slab), weakref.ref(grad_slab)))
+
+
+def unregister_flat_slabs():
+    del _flat_slabs[:]
+
+
+def flat_grad_for(t):
+    """Gradient-slab view for a parameter tensor (or a contiguous slice of one) that lives in a registered slab."""
+    if t is None or not _flat_slabs or not t.is_contiguous():
+        return None
+    p = t.data_ptr()
+    for base, nbytes, pref, gref in _flat_slabs:
+        if base <= p < base + nbytes:
+            pslab, gslab = pref(), gref()
+            if pslab is None or gslab is None or pslab.data_ptr() != base:
+                continue  # stale registration (the optimizer that owned the slab is gone)
+            off = (p - base) // 4
+            return gslab[off:off + t.numel()].view(t.shape)
+    return None
+
+
 class _LinearFn(torch.autograd.Function):
     """y = dropout(rowscale * act((x W^T + b) * alpha)) + residual   -- one GEMM launch with a fused epilogue.
 
@@ -161,6 +194,7 @@ class _LinearFn(torch.autograd.Function):
                  rs_mod=rs_mod, dropout_p=dropout_p, site=site, residual=res, seed=ctx.seed)
         ctx.save_for_backward(x, W, pre if act == ACT_GELU else (y if act == ACT_RELU else None), rowscale)
         ctx.cfg = (alpha, act, rs_div, rs_mod, dropout_p, site, b is not None, residual is not None)
+        ctx.bias_ref = b.detach() if b is not None else None  # only its address is used (flat gradient slab lookup)
         return y
 
     @staticmethod
@@ -183,12 +217,19 @@ class _LinearFn(torch.autograd.Function):
             dx = torch.empty((M, K), device=dy.device, dtype=torch.float32)
             gemm_raw(g, W, dx, M, K, N, 0, 1)                      # dx[M,K] = g[M,N] . W[N,K]
         if ctx.needs_input_grad[1]:
-            dW = torch.zeros((N, K), device=dy.device, dtype=torch.float32)
+            slab = flat_grad_for(W)          # accumulate straight into the flat gradient slab when there is one
+            dW = slab if slab is not None else torch.zeros((N, K), device=dy.device, dtype=torch.float32)
             tiles = ((N + 127) // 128) * ((K + 175) // 176)
-            gemm_raw(g, x, dW, N, K, M, 1, 1, atomic=True, split_k=_split_k_for(tiles, M))  # dW[N,K] = g^T . x
+            gemm_raw(g, x, dW, N, K, M, 1, 1, atomic=True, split_k=_split_k_for(tiles, M))  # dW[N,K] += g^T . x
+            if slab is not None:
+                dW = None
         if has_b and ctx.needs_input_grad[2]:
-            db = torch.zeros((N,), device=dy.device, dtype=torch.float32)
+            b_t = ctx.bias_ref
+            slab = flat_grad_for(b_t)
+            db = slab if slab is not None else torch.zeros((N,), device=dy.device, dtype=torch.float32)
             check(lib.vptr_colsum(ptr(g), ptr(db), M, N, stream()), "vptr_colsum")
+            if slab is not None:
+                db = None
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
         return dx, dW, db, dres, None, None, None, None, None, None, None
 
@@ -215,6 +256,7 @@ class _LayerNormFn(torch.autograd.Function):
         check(lib.vptr_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(y2), ptr(tab_c), tab_div, tab_mod, ptr(mean),
                                      ptr(rstd), rows, C, eps, stream()), "vptr_layernorm_fwd")
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.beta_ref = beta.detach()
         ctx.tab = (tab is not None, tab_div, tab_mod, tuple(tab.shape) if tab is not None else None)
         if tab is None:
             return y
@@ -233,10 +275,14 @@ class _LayerNormFn(torch.autograd.Function):
         else:
             k1, k2 = _c(dy), dy2
         dx = torch.empty_like(x)
-        dgamma = torch.zeros_like(gamma)
-        dbeta = torch.zeros_like(gamma)
+        sg, sb = flat_grad_for(gamma), flat_grad_for(ctx.beta_ref)
+        in_slab = sg is not None and sb is not None
+        dgamma = sg if in_slab else torch.zeros_like(gamma)
+        dbeta = sb if in_slab else torch.zeros_like(gamma)
         check(lib.vptr_layernorm_bwd(ptr(k1), ptr(k2), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma),
                                      ptr(dbeta), rows, C, stream()), "vptr_layernorm_bwd")
+        if in_slab:
+            dgamma = dbeta = None
         dtab = None
         if has_tab and ctx.needs_input_grad[3] and dy2 is not None:
             dtab = torch.zeros((tab_mod, C), device=x.device, dtype=torch.float32)
@@ -298,10 +344,13 @@ class _WinAttnFn(torch.autograd.Function):
         B, H, W, nh, ws, p, site = ctx.cfg
         do = _c(do)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
-        dtable = torch.zeros_like(table) if table is not None else None
+        slab = flat_grad_for(table)
+        dtable = slab if slab is not None else (torch.zeros_like(table) if table is not None else None)
         check(lib.vptr_winattn_bwd(ptr(q), ptr(k), ptr(v), ptr(table), ptr(rel_index), ptr(do), ptr(dq), ptr(dk), ptr(dv),
                                    ptr(dtable), B, H, W, q.shape[1], nh, ws, p, ptr(ctx.seed), site, stream()),
               "vptr_winattn_bwd")
+        if slab is not None:
+            dtable = None
         return dq, dk, dv, dtable, None, None, None, None, None, None, None, None
 
 

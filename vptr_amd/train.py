@@ -44,6 +44,7 @@ class FlatAdamW:
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.float32)
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
+        ops.register_flat_slab(self.flat, self.grad)  # backward kernels accumulate weight gradients in place
 
     def zero_grad(self):
         p0 = self.params[0]
