@@ -98,8 +98,20 @@ def gemm_roofline(trainer, past, fut, precision):
     (nfn, prec, am, bm), (cnt, fl, ms) = dom
     peak = MFMA_PEAK_TFLOPS
     ach = fl / (ms * 1e-3) / 1e12
+    # HBM-side bytes per launch of that kernel: PMC counters cannot be read in-process, so this is the committed
+    # rocprofv3 measurement of this same command (tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes; KB units;
+    # FETCH_SIZE doubled for 16-B/lane streaming reads on gfx950 as MI355X_MICROARCH.md prescribes).
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        e = pm.get("vptr_gemm_kernel<%d, %d, %d, %d>" % (nfn, prec, am, bm))
+        if e:
+            traffic = round((2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0)
+    except Exception:  # noqa
+        pass
     return {
-        "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+        "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+        "traffic_unit": "HBM-side bytes per launch (profiles/r01_pmc_traffic.json)",
         "kernel": "vptr_gemm_kernel<NFN=%d,NPASS=%d,A=%d,B=%d>" % (nfn, prec, am, bm),
         "launches_per_step": cnt, "avg_launch_us": round(ms * 1e3 / cnt, 2), "alg_gflop_per_launch": round(fl / cnt / 1e9, 3),
         "all_gemm": {"launches_per_step": sum(d[0] for d in by.values()), "ms_per_step": round(tot_ms, 3),
@@ -118,7 +130,8 @@ def main():
     ap.add_argument("--precision", type=int, default=int(os.environ.get("VPTR_GEMM_PRECISION", "3")), choices=[1, 3],
                     help="3 = split-bf16 MFMA (meets the 1e-3 parity bar, default); 1 = single-pass bf16")
     ap.add_argument("--dropout", type=float, default=0.1)
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("VPTR_GRAPH", "1")), help="capture the step in a hipGraph (1 GPU)")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("VPTR_GRAPH", "0")),
+                    help="1: capture the step in a hipGraph (1 GPU). Default 0: the step is GPU-bound, eager == graph speed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -188,7 +201,7 @@ def main():
             "config": {"workload": "K64: KTH 64x64x1 10->10, VPTREnc/Dec(528, Tanh, reflect) + VPTRFormerNAR(4 enc + 8 dec, d=528, 8 heads, "
                                    "ws 4, dropout %.2f), single_iter of train_NAR.py, random-init weights" % args.dropout,
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch, "parallelism": "dp%d" % world,
-                       "launch": graph_note, "dec_weight_grads": False,
+                       "launch": graph_note, "dec_weight_grads": True,
                        "alg_tflop_per_step_per_gpu": round(GF_PER_SAMPLE * args.batch / 1e3, 2),
                        "step_tflops_per_gpu": round(GF_PER_SAMPLE * args.batch / 1e3 / (ms * 1e-3), 1)},
             "final_loss": round(loss, 5),

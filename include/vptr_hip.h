@@ -194,6 +194,14 @@ int vptr_conv7_out_bwd_weight(const float* dy, const float* y, const float* x, f
                               int W, int Cimg, int out_act, vptr_stream_t stream);
 /* dx = dy * (y > 0) * scale[c]   (ReLU + folded-BN backward on channel-last [rows, C]) */
 int vptr_bnrelu_bwd(const float* dy, const float* y, const float* scale, float* dx, int64_t rows, int C, vptr_stream_t stream);
+/* eval-mode BatchNorm2d affine gradients behind the ReLU, from the layer output y = relu(w*xhat + b) (ACCUMULATED):
+ * db[c] += sum_{y>0} dy;  dw[c] += sum_{y>0} dy * (y - b[c]) / w[c]   (ResNetAutoEncoder.py:79-80 in stage 2) */
+int vptr_bnrelu_bwd_params(const float* dy, const float* y, const float* w, const float* b, float* dw, float* db, int64_t rows,
+                           int C, vptr_stream_t stream);
+/* zero-padded im2col on NHWC: out[(b,oy,ox)][(ky,kx,c)] = x[b, oy*stride-pad+ky, ox*stride-pad+kx, c]; the patch matrix
+ * is the k-strided operand of the ConvTranspose2d weight-gradient GEMM (ResNetAutoEncoder.py:74-88 autograd). */
+int vptr_im2col_nhwc(const float* x, float* out, int B, int IH, int IW, int C, int OH, int OW, int KH, int KW, int stride,
+                     int pad, vptr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer: global-norm clip + AdamW on flat fp32 buffers (train_NAR.py:85-86,205).

@@ -290,3 +290,83 @@ extern "C" int vptr_conv7_out_bwd_weight(const float* dy, const float* y, const 
   VPTR_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight-gradient helpers of the decoder's ConvTranspose2d + BatchNorm(eval) + ReLU layers.
+// ---------------------------------------------------------------------------------------------------------------------
+// im2col on NHWC with zero padding: out[(b,oy,ox)][(ky,kx,c)] = x[b, oy*s-p+ky, ox*s-p+kx, c].  The patch matrix is the
+// k-strided B operand of the ConvTranspose2d weight-gradient GEMM  dW[ci][(ky,kx,co)] = sum_pix x[pix][ci] * P[pix][...].
+__global__ __launch_bounds__(256) void im2col_nhwc_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int IH,
+                                                          int IW, int C4, int OH, int OW, int KH, int KW, int stride, int pad) {
+  const int64_t total = (int64_t)B * OH * OW * KH * KW * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    int64_t t = i / C4;
+    const int kx = (int)(t % KW); t /= KW;
+    const int ky = (int)(t % KH); t /= KH;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const int b = (int)(t / OH);
+    const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) v = reinterpret_cast<const float4*>(x)[(((int64_t)b * IH + iy) * IW + ix) * C4 + c4];
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+extern "C" int vptr_im2col_nhwc(const float* x, float* out, int B, int IH, int IW, int C, int OH, int OW, int KH, int KW,
+                                int stride, int pad, vptr_stream_t stream) {
+  VPTR_CHECK(B > 0 && IH > 0 && IW > 0 && C > 0 && C % 4 == 0 && OH > 0 && OW > 0 && KH > 0 && KW > 0 && stride >= 1,
+             "im2col_nhwc: bad arguments");
+  const int64_t total = (int64_t)B * OH * OW * KH * KW * (C / 4);
+  const int blocks = (int)hmin64((total + 255) / 256, 16384);
+  im2col_nhwc_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(x, out, B, IH, IW, C / 4, OH, OW, KH, KW, stride, pad);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// eval-mode BatchNorm affine gradients behind a ReLU, from the layer OUTPUT y = relu(w*xhat + b):
+//   db[c] += sum_{y>0} dy,   dw[c] += sum_{y>0} dy * xhat,  xhat = (y - b)/w.   Channel-last [rows, C]; same tiling as colsum.
+__global__ __launch_bounds__(256) void bnrelu_bwd_params_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                const float* __restrict__ w, const float* __restrict__ b,
+                                                                float* __restrict__ dw, float* __restrict__ db, int64_t rows,
+                                                                int C4) {
+  __shared__ float4 redw[8][32], redb[8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c4 = blockIdx.x * 32 + tx;
+  const int64_t r0 = (int64_t)blockIdx.y * 512, r1 = r0 + 512 < rows ? r0 + 512 : rows;
+  float4 aw = make_float4(0.f, 0.f, 0.f, 0.f), ab = aw;
+  if (c4 < C4) {
+    const float4 wv = reinterpret_cast<const float4*>(w)[c4], bv = reinterpret_cast<const float4*>(b)[c4];
+    const float4 iw = make_float4(1.f / wv.x, 1.f / wv.y, 1.f / wv.z, 1.f / wv.w);
+    for (int64_t r = r0 + ty; r < r1; r += 8) {
+      const float4 d = reinterpret_cast<const float4*>(dy)[r * C4 + c4];
+      const float4 yv = reinterpret_cast<const float4*>(y)[r * C4 + c4];
+      const float gx = yv.x > 0.f ? d.x : 0.f, gy = yv.y > 0.f ? d.y : 0.f, gz = yv.z > 0.f ? d.z : 0.f, gw = yv.w > 0.f ? d.w : 0.f;
+      ab.x += gx; ab.y += gy; ab.z += gz; ab.w += gw;
+      aw.x += gx * (yv.x - bv.x) * iw.x; aw.y += gy * (yv.y - bv.y) * iw.y;
+      aw.z += gz * (yv.z - bv.z) * iw.z; aw.w += gw * (yv.w - bv.w) * iw.w;
+    }
+  }
+  redw[ty][tx] = aw;
+  redb[ty][tx] = ab;
+  __syncthreads();
+  if (ty == 0 && c4 < C4) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const float4 u = redw[k][tx], v = redb[k][tx];
+      aw.x += u.x; aw.y += u.y; aw.z += u.z; aw.w += u.w;
+      ab.x += v.x; ab.y += v.y; ab.z += v.z; ab.w += v.w;
+    }
+    unsafeAtomicAdd(dw + c4 * 4 + 0, aw.x); unsafeAtomicAdd(dw + c4 * 4 + 1, aw.y);
+    unsafeAtomicAdd(dw + c4 * 4 + 2, aw.z); unsafeAtomicAdd(dw + c4 * 4 + 3, aw.w);
+    unsafeAtomicAdd(db + c4 * 4 + 0, ab.x); unsafeAtomicAdd(db + c4 * 4 + 1, ab.y);
+    unsafeAtomicAdd(db + c4 * 4 + 2, ab.z); unsafeAtomicAdd(db + c4 * 4 + 3, ab.w);
+  }
+}
+extern "C" int vptr_bnrelu_bwd_params(const float* dy, const float* y, const float* w, const float* b, float* dw, float* db,
+                                      int64_t rows, int C, vptr_stream_t stream) {
+  VPTR_CHECK(rows > 0 && C > 0 && C % 4 == 0, "bnrelu_bwd_params: bad arguments");
+  bnrelu_bwd_params_kernel<<<dim3(cdiv(C / 4, 32), cdiv(rows, 512)), 256, 0, (hipStream_t)stream>>>(dy, y, w, b, dw, db, rows, C / 4);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}

@@ -528,6 +528,13 @@ __global__ void accum2_kernel(const float* __restrict__ acc, float* __restrict__
   if (c < F) { dw[c] += acc[c]; db[c] += acc[F + c]; }
 }
 
+// scratch buffers are zeroed by an ordinary kernel (a kernel node under stream capture) rather than hipMemsetAsync (a
+// memset node that may be served by a different engine).
+__global__ void zero_fill_kernel(float* __restrict__ p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 extern "C" int vptr_norm_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
                                  const float* b, float* dx, float* dw, float* db, float* scratch, int rows, int F, int HW,
                                  int per_col, int act, int const_stats, float dropout_p, const uint64_t* seed_dev,
@@ -538,7 +545,7 @@ extern "C" int vptr_norm_act_bwd(const float* dy, const float* x, const float* m
   const int64_t total = (int64_t)rows * F;
   const int blocks = (int)hmin64((total + 255) / 256, 8192);
   if (per_col) {
-    (void)hipMemsetAsync(scratch, 0, sizeof(float) * 2 * F, st);
+    zero_fill_kernel<<<cdiv(2 * F, 256), 256, 0, st>>>(scratch, 2 * F);  // a kernel node, not a memset node (see below)
     const int rpb = 64;
     norm_act_bwd_col_reduce<<<dim3(cdiv(F, 256), cdiv(rows, rpb)), 256, 0, st>>>(dy, x, mean, rstd, w, b, scratch, rows, F, act,
                                                                                  dropout_p, seed_dev, site, rpb, rowscale, rs_div, rs_mod);
@@ -548,7 +555,7 @@ extern "C" int vptr_norm_act_bwd(const float* dy, const float* x, const float* m
   } else {
     VPTR_CHECK(rows % HW == 0, "norm_act_bwd: rows must be a multiple of HW");
     const int frames = rows / HW;
-    (void)hipMemsetAsync(scratch, 0, sizeof(float) * 2 * frames, st);
+    zero_fill_kernel<<<cdiv(2 * frames, 256), 256, 0, st>>>(scratch, 2 * frames);
     VPTR_CHECK(F % 4 == 0, "norm_act_bwd: F must be a multiple of 4");
     const int E4 = HW * F / 4;
     const int splits = frames >= 512 ? 1 : (frames >= 128 ? 4 : 8);

@@ -143,6 +143,7 @@ class _DecoderFn(torch.autograd.Function):
         check(lib.vptr_nchw_to_tokens(ptr(feat.contiguous()), ptr(x), B, C, h * w, stream()), "vptr_nchw_to_tokens")
         acts, scales, geoms = [], [], []
         cin = C
+        x0 = x
         for i in range(n_up):
             convt, bn = m[3 * i], m[3 * i + 1]
             cout = convt.weight.shape[1]
@@ -160,6 +161,7 @@ class _DecoderFn(torch.autograd.Function):
         check(lib.vptr_conv7_out_fwd(ptr(x), ptr(conv.weight.contiguous()), ptr(conv.bias.contiguous()), ptr(out), B, cin, h, w,
                                      cimg, dec.out_act, stream()), "vptr_conv7_out_fwd")
         ctx.dec, ctx.acts, ctx.scales, ctx.geoms, ctx.B = dec, acts, scales, geoms, B
+        ctx.x0 = x0 if any(p.requires_grad for p in dec.parameters()) else None
         ctx.save_for_backward(out)
         return out
 
@@ -176,11 +178,37 @@ class _DecoderFn(torch.autograd.Function):
         g = torch.empty((B * h * w, cin), device=dout.device, dtype=torch.float32)
         check(lib.vptr_conv7_out_bwd_data(ptr(dout), ptr(out), ptr(conv.weight.contiguous()), ptr(g), B, cin, h, w, cimg,
                                           dec.out_act, stream()), "vptr_conv7_out_bwd_data")
+        # weight gradients (the reference leaves the decoder trainable in stage 2 and computes them every step although
+        # nothing steps them, train_NAR.py:190-191,205); produced only for parameters that require grad
+        wgrads = {}
+        want_w = ctx.x0 is not None
+        if want_w and conv.weight.requires_grad:
+            dw7 = torch.zeros_like(conv.weight)
+            db7 = torch.zeros_like(conv.bias)
+            check(lib.vptr_conv7_out_bwd_weight(ptr(dout), ptr(out), ptr(acts[-1]), ptr(dw7), ptr(db7), B, cin, h, w, cimg,
+                                                dec.out_act, stream()), "vptr_conv7_out_bwd_weight")
+            wgrads[id(conv.weight)], wgrads[id(conv.bias)] = dw7, db7
         for i in reversed(range(n_up)):
             ih, iw, ic, oh, ow, oc = geoms[i]
             gm = torch.empty_like(g)
             check(lib.vptr_bnrelu_bwd(ptr(g), ptr(acts[i]), ptr(scales[i].contiguous()), ptr(gm), B * oh * ow, oc, stream()),
                   "vptr_bnrelu_bwd")
+            bn, convt = m[3 * i + 1], m[3 * i]
+            if want_w and bn.weight.requires_grad:
+                dbw, dbb = torch.zeros_like(bn.weight), torch.zeros_like(bn.bias)
+                check(lib.vptr_bnrelu_bwd_params(ptr(g), ptr(acts[i]), ptr(bn.weight.contiguous()), ptr(bn.bias.contiguous()),
+                                                 ptr(dbw), ptr(dbb), B * oh * ow, oc, stream()), "vptr_bnrelu_bwd_params")
+                wgrads[id(bn.weight)], wgrads[id(bn.bias)] = dbw, dbb
+            if want_w and convt.weight.requires_grad:
+                # dW[ci][co][ky][kx] = sum_pix x[pix][ci] * gm[(iy*2-1+ky, ix*2-1+kx)][co]: im2col of gm (3x3, s2, p1) and one
+                # split-K GEMM  D[ci][(ky,kx,co)] = x^T . P  with both operands k-strided
+                xin = ctx.x0 if i == 0 else acts[i - 1]
+                P = torch.empty((B * ih * iw, 9 * oc), device=dout.device, dtype=torch.float32)
+                check(lib.vptr_im2col_nhwc(ptr(gm), ptr(P), B, oh, ow, oc, ih, iw, 3, 3, 2, 1, stream()), "vptr_im2col_nhwc")
+                D = torch.zeros((ic, 9 * oc), device=dout.device, dtype=torch.float32)
+                tiles = ((ic + 127) // 128) * ((9 * oc + 175) // 176)
+                ops.gemm_raw(xin, P, D, ic, 9 * oc, B * ih * iw, 1, 1, atomic=True, split_k=ops._split_k_for(tiles, B * ih * iw))
+                wgrads[id(convt.weight)] = D.view(ic, 3, 3, oc).permute(0, 3, 1, 2).contiguous()
             # dgrad of ConvTranspose2d(3x3, s2, p1, op1) = Conv2d(3x3, s2, p1) of the output gradient with
             # B[ci][(ky,kx,co)] = W[ci][co][ky][kx]
             wt = m[3 * i].weight
@@ -189,7 +217,8 @@ class _DecoderFn(torch.autograd.Function):
         h0, w0, c0 = geoms[0][0], geoms[0][1], geoms[0][2]
         dfeat = torch.empty((B, c0, h0, w0), device=dout.device, dtype=torch.float32)
         check(lib.vptr_tokens_to_nchw(ptr(g), ptr(dfeat), B, c0, h0 * w0, 0, stream()), "vptr_tokens_to_nchw")
-        return (dfeat, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+        pgrads = tuple(wgrads.get(id(p)) for p in dec.parameters())
+        return (dfeat, None) + pgrads
 
 
 class ResnetDecoder(nn.Module):
