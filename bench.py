@@ -95,7 +95,8 @@ def gemm_roofline(trainer, past, fut, precision):
     tot_f = sum(d[1] for d in by.values())
     tot_ms = sum(d[2] for d in by.values())
     dom = max(by.items(), key=lambda kv: kv[1][2])
-    (nfn, prec, am, bm), (cnt, fl, ms) = dom
+    (nfn, prec, am, bm), (cnt, fl, ms) = (dom[0][:4], dom[1])
+    kname = "vptr_gemm_grouped_kernel" if len(dom[0]) > 4 else "vptr_gemm_kernel_p"
     peak = MFMA_PEAK_TFLOPS
     ach = fl / (ms * 1e-3) / 1e12
     # HBM-side bytes per launch of that kernel: PMC counters cannot be read in-process, so this is the committed
@@ -104,7 +105,7 @@ def gemm_roofline(trainer, past, fut, precision):
     traffic = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        e = pm.get("vptr_gemm_kernel<%d, %d, %d, %d>" % (nfn, prec, am, bm))
+        e = pm.get("%s<%d, %d, %d, %d>" % (kname, nfn, prec, am, bm))
         if e:
             traffic = round((2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0)
     except Exception:  # noqa
@@ -112,7 +113,7 @@ def gemm_roofline(trainer, past, fut, precision):
     return {
         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
         "traffic_unit": "HBM-side bytes per launch (profiles/r01_pmc_traffic.json)",
-        "kernel": "vptr_gemm_kernel<NFN=%d,NPASS=%d,A=%d,B=%d>" % (nfn, prec, am, bm),
+        "kernel": "%s<NFN=%d,NPASS=%d,A=%d,B=%d>" % (kname, nfn, prec, am, bm),
         "launches_per_step": cnt, "avg_launch_us": round(ms * 1e3 / cnt, 2), "alg_gflop_per_launch": round(fl / cnt / 1e9, 3),
         "all_gemm": {"launches_per_step": sum(d[0] for d in by.values()), "ms_per_step": round(tot_ms, 3),
                      "achieved": round(tot_f / (tot_ms * 1e-3) / 1e12, 2), "alg_gflop_per_step": round(tot_f / 1e9, 1)},

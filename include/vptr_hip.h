@@ -84,6 +84,22 @@ typedef struct vptr_gemm_desc {
 
 int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream);
 
+/* Column width of the output tile vptr_gemm / vptr_gemm_grouped use for an N-column problem (64, 128 or 176);
+ * the row height is always 128.  Host-side helper for building vptr_gemm_grouped's tile table. */
+int vptr_gemm_tile_cols(int N);
+
+/* Grouped GEMM: `count` independent problems in ONE launch, each tile running its problem's full K range (no split-K).
+ * Used for the weight gradients of a whole backward pass (dW = dY^T . X of every nn.Linear, train_NAR.py:101): the
+ * per-layer calls are recorded and flushed together, because each one alone (12-60 output tiles, K = all tokens)
+ * cannot fill 256 CUs without ~30 K-splits that each pay a prologue and an atomic epilogue.
+ *   proto          host copy of any member: a_mode / b_mode (must be k-strided x k-strided), precision and the tile
+ *                  class of N (vptr_gemm_tile_cols) are taken from it and must be common to the group
+ *   descs_dev      DEVICE array [count] of descriptors (split_k ignored; atomic = 1 accumulates into D)
+ *   tile_start_dev DEVICE int[count]: first tile index of problem g; problem g owns
+ *                  ceil(M/128) * ceil(N/tile_cols) consecutive tiles; total_tiles = sum over the group */
+int vptr_gemm_grouped(const vptr_gemm_desc* proto, const vptr_gemm_desc* descs_dev, const int* tile_start_dev, int count,
+                      int total_tiles, vptr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the channel dim (nn.LayerNorm(C), VidHRFormer_modules.py:44-48,56,137-161; VidHRFormer.py:24,26).
  *   y = LN(x); optional y2 = y + tab[((row / tab_div) % tab_mod), :]   (positional adds of :79,176,185,204)

@@ -11,8 +11,10 @@
 // slot of the odd wave column is computed on padding and never stored).  Two waves per SIMD (and a register budget
 // of <= 128 VGPRs, i.e. two co-resident workgroups when the grid is large enough) cover the LDS and HBM latencies
 // that a single wave per SIMD exposes.
-// LDS image: [row][k] bf16 with a 40-element (80 B) pitch -> ds_read_b128 fragment reads and ds_write_b64 staging
-// writes are at worst 2-way conflicted for both operand orientations.
+// LDS image: [row][32 k] bf16, 64-byte rows, XOR-swizzled (lds_off): the 16-byte k chunk kq of row r sits at chunk
+// kq ^ ((-(r >> 2)) & 3) of physical row r ^ ((r >> 2) & 1).  With the lane groups gfx950 uses for ds_read_b128
+// ({0-3,12-15,20-27}, ...) and ds_write_b64 (16 contiguous lanes) this is conflict-free for the fragment reads and
+// for the staging writes of both operand orientations (an 80-byte padded pitch was 2-way conflicted on every read).
 // Operand orientations: k-contiguous (nn.Linear forward), k-strided (dgrad's W, wgrad's dY and X; transposed in the
 // staging path), and an implicit-GEMM gather of NHWC images for Conv2d / ConvTranspose2d.
 // The K loop is straight-line code: every global load is unconditional (addresses clamped into the matrix), the K
@@ -21,9 +23,21 @@
 // individually; a dynamically indexed accumulator array is demoted to scratch memory.)
 #include "common.h"
 
+#ifdef VPTR_GEMM_TIMING  // tools/gemm_probe.hip: per-phase shader-clock stamps of wave 0 of every workgroup
+__device__ long long* vptr_gemm_timing_buf = nullptr;
+#define TS_DECL long long ts_acc[6] = {0, 0, 0, 0, 0, 0}; long long ts_t = clock64(); const long long ts_begin = ts_t;
+#define TS(i) { const long long ts_n = clock64(); ts_acc[i] += ts_n - ts_t; ts_t = ts_n; }
+#define TS_FLUSH { if (threadIdx.x == 0 && vptr_gemm_timing_buf) { for (int q = 0; q < 6; ++q) vptr_gemm_timing_buf[blockIdx.x * 8 + q] = ts_acc[q]; \
+                   vptr_gemm_timing_buf[blockIdx.x * 8 + 6] = ts_begin; vptr_gemm_timing_buf[blockIdx.x * 8 + 7] = clock64(); } }
+#else
+#define TS_DECL
+#define TS(i)
+#define TS_FLUSH
+#endif
+
 #define GBM 128
 #define GBK 32
-#define GLP 40
+#define GLP 32
 #define GNT 512
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -51,16 +65,23 @@ __device__ __forceinline__ void split2(const float a, const float b, uint32_t& h
   lo = pk_bf16(a - fa, b - fb);
 }
 
+// bf16 element offset of k chunk k4 (4 elements = 8 bytes, k4 = 0..7) of tile row `row` in the swizzled LDS image
+__device__ __forceinline__ int lds_off(const int row, const int k4) {
+  const int j = row >> 2;
+  return ((row ^ (j & 1)) << 5) + ((((k4 >> 1) ^ (0 - j)) & 3) << 3) + ((k4 & 1) << 2);
+}
+
 template <int NPASS>
 __device__ __forceinline__ void lds_put4(__bf16* s_hi, __bf16* s_lo, int row, int kc, const float4 v) {
   if constexpr (NPASS == 3) {
     uint2 hi, lo;
     split2(v.x, v.y, hi.x, lo.x);
     split2(v.z, v.w, hi.y, lo.y);
-    *reinterpret_cast<uint2*>(&s_hi[row * GLP + kc]) = hi;
-    *reinterpret_cast<uint2*>(&s_lo[row * GLP + kc]) = lo;
+    const int o = lds_off(row, kc >> 2);
+    *reinterpret_cast<uint2*>(&s_hi[o]) = hi;
+    *reinterpret_cast<uint2*>(&s_lo[o]) = lo;
   } else {
-    *reinterpret_cast<uint2*>(&s_hi[row * GLP + kc]) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+    *reinterpret_cast<uint2*>(&s_hi[lds_off(row, kc >> 2)]) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
   }
 }
 
@@ -96,13 +117,16 @@ struct StageKC {
       r[i] = *reinterpret_cast<const float4*>(P + (int64_t)min(row0 + row, nrows - 1) * ld + kk);
     }
   }
+  static constexpr int NUNIT = NIT;  // store units (one ds_write_b64 per plane each), for interleaving with MFMAs
+  template <int NPASS>
+  __device__ __forceinline__ void store_unit(__bf16* s_hi, __bf16* s_lo, int tid, const int i) {
+    const int s = slot_of<NSLOT>(i, tid);
+    lds_put4<NPASS>(s_hi, s_lo, s >> 3, (s & 7) << 2, KMASK ? mask4(r[i], kmask) : r[i]);
+  }
   template <int NPASS>
   __device__ __forceinline__ void store(__bf16* s_hi, __bf16* s_lo, int tid) {
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int s = slot_of<NSLOT>(i, tid);
-      lds_put4<NPASS>(s_hi, s_lo, s >> 3, (s & 7) << 2, KMASK ? mask4(r[i], kmask) : r[i]);
-    }
+    for (int i = 0; i < NUNIT; ++i) store_unit<NPASS>(s_hi, s_lo, tid, i);
   }
 };
 
@@ -127,20 +151,26 @@ struct StageKS {
         r[i][j] = *reinterpret_cast<const float4*>(P + (int64_t)min(k0 + kb * 4 + j, kend - 1) * ld + mm);
     }
   }
+  static constexpr int NUNIT = NIT * 4;
+  static __device__ __forceinline__ float comp(const float4 v, const int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+  template <int NPASS>
+  __device__ __forceinline__ void store_unit(__bf16* s_hi, __bf16* s_lo, int tid, const int u) {
+    const int i = u >> 2, j = u & 3;  // compile-time constants after unrolling
+    const int s = slot_of<NSLOT>(i, tid);
+    const int kb = s & 7, ob = s >> 3;
+    float4 v = make_float4(comp(r[i][0], j), comp(r[i][1], j), comp(r[i][2], j), comp(r[i][3], j));
+    if constexpr (KMASK) {
+      v.x = __uint_as_float(__float_as_uint(v.x) & (nvalid > 0 ? ~0u : 0u));
+      v.y = __uint_as_float(__float_as_uint(v.y) & (nvalid > 1 ? ~0u : 0u));
+      v.z = __uint_as_float(__float_as_uint(v.z) & (nvalid > 2 ? ~0u : 0u));
+      v.w = __uint_as_float(__float_as_uint(v.w) & (nvalid > 3 ? ~0u : 0u));
+    }
+    lds_put4<NPASS>(s_hi, s_lo, ob * 4 + j, kb * 4, v);
+  }
   template <int NPASS>
   __device__ __forceinline__ void store(__bf16* s_hi, __bf16* s_lo, int tid) {
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int s = slot_of<NSLOT>(i, tid);
-      const int kb = s & 7, ob = s >> 3;
-      const unsigned m0 = nvalid > 0 ? ~0u : 0u, m1 = nvalid > 1 ? ~0u : 0u, m2 = nvalid > 2 ? ~0u : 0u, m3 = nvalid > 3 ? ~0u : 0u;
-      const float4 v0 = KMASK ? mask4(r[i][0], m0) : r[i][0], v1 = KMASK ? mask4(r[i][1], m1) : r[i][1];
-      const float4 v2 = KMASK ? mask4(r[i][2], m2) : r[i][2], v3 = KMASK ? mask4(r[i][3], m3) : r[i][3];
-      lds_put4<NPASS>(s_hi, s_lo, ob * 4 + 0, kb * 4, make_float4(v0.x, v1.x, v2.x, v3.x));
-      lds_put4<NPASS>(s_hi, s_lo, ob * 4 + 1, kb * 4, make_float4(v0.y, v1.y, v2.y, v3.y));
-      lds_put4<NPASS>(s_hi, s_lo, ob * 4 + 2, kb * 4, make_float4(v0.z, v1.z, v2.z, v3.z));
-      lds_put4<NPASS>(s_hi, s_lo, ob * 4 + 3, kb * 4, make_float4(v0.w, v1.w, v2.w, v3.w));
-    }
+    for (int u = 0; u < NUNIT; ++u) store_unit<NPASS>(s_hi, s_lo, tid, u);
   }
 };
 
@@ -187,91 +217,27 @@ struct StageConv {
       okbits |= (ok ? 1u : 0u) << i;
     }
   }
+  static constexpr int NUNIT = NIT;
+  template <int NPASS>
+  __device__ __forceinline__ void store_unit(__bf16* s_hi, __bf16* s_lo, int tid, const int i) {
+    const int s = tid + GNT * i;
+    lds_put4<NPASS>(s_hi, s_lo, s >> 3, (s & 7) << 2, mask4(r[i], 0u - ((okbits >> i) & 1u)));
+  }
   template <int NPASS>
   __device__ __forceinline__ void store(__bf16* s_hi, __bf16* s_lo, int tid) {
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int s = tid + GNT * i;
-      lds_put4<NPASS>(s_hi, s_lo, s >> 3, (s & 7) << 2, mask4(r[i], 0u - ((okbits >> i) & 1u)));
-    }
+    for (int i = 0; i < NUNIT; ++i) store_unit<NPASS>(s_hi, s_lo, tid, i);
   }
 };
 
-template <int NFN, int NPASS, int AMODE, int BMODE>
-__global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc p, const int k_chunk) {
-  constexpr int BN = 16 * NFN;
-  constexpr int NFW = (NFN + 1) / 2;     // column fragments per wave
-  constexpr int BROWS = 2 * NFW * 16;    // LDS rows of the B image (>= BN; the surplus rows feed never-stored fragments)
-  constexpr int NPL = (NPASS == 3) ? 2 : 1;
-  using StA = typename std::conditional<AMODE == VPTR_A_KCONTIG, StageKC<GBM, GBM, true>,
-                                        typename std::conditional<AMODE == VPTR_A_KSTRIDED, StageKS<GBM, true>, StageConv>::type>::type;
-  using StB = typename std::conditional<BMODE == VPTR_B_KCONTIG, StageKC<BN, BROWS, false>, StageKS<BROWS, false>>::type;
-  __shared__ __attribute__((aligned(16))) __bf16 sA[NPL][GBM * GLP];
-  __shared__ __attribute__((aligned(16))) __bf16 sB[NPL][BROWS * GLP];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int lr = lane & 15, lq = lane >> 4;
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
-  const int m0 = tm * GBM, n0 = tn * BN;
-  const int kbeg = blockIdx.z * k_chunk;
-  const int kend = min(p.K, kbeg + k_chunk);
-  const int nkt = (kend - kbeg + GBK - 1) / GBK;
-
-  f32x4 acc[2][NFW];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NFW; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  StA stA;
-  StB stB;
-  // K-step j+1 is fetched into registers while step j is multiplied out of LDS (single LDS image, two barriers per step);
-  // the other resident waves of the SIMD cover what is left of the HBM / LDS latencies.
-  if constexpr (AMODE == VPTR_A_CONV) stA.load(p, m0, kbeg, kend, tid);
-  else stA.load(p.A, p.lda, m0, p.M, kbeg, kend, tid);
-  stB.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid);
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    stA.template store<NPASS>(sA[0], sA[NPL - 1], tid);
-    stB.template store<NPASS>(sB[0], sB[NPL - 1], tid);
-    __syncthreads();
-    {  // unconditional prefetch of the next step (clamped + masked beyond the K range)
-      const int k1 = kbeg + (kt + 1) * GBK;
-      if constexpr (AMODE == VPTR_A_CONV) stA.load(p, m0, k1, kend, tid);
-      else stA.load(p.A, p.lda, m0, p.M, k1, kend, tid);
-      stB.load(p.B, p.ldb, n0, p.N, k1, kend, tid);
-    }
-    bf16x8 ah[2], al[2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int off = (wm * 32 + mi * 16 + lr) * GLP + lq * 8;
-      ah[mi] = *reinterpret_cast<const bf16x8*>(&sA[0][off]);
-      if constexpr (NPASS == 3) al[mi] = *reinterpret_cast<const bf16x8*>(&sA[NPL - 1][off]);
-    }
-#pragma unroll
-    for (int ni = 0; ni < NFW; ++ni) {
-      const int off = ((wn * NFW + ni) * 16 + lr) * GLP + lq * 8;
-      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&sB[0][off]);
-      bf16x8 bl;
-      if constexpr (NPASS == 3) bl = *reinterpret_cast<const bf16x8*>(&sB[NPL - 1][off]);
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        if constexpr (NPASS == 3) {
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
-        }
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-  }
-
+// ---- epilogue (shared by both main-loop variants)
+template <int NFN>
+__device__ __forceinline__ void gemm_epilogue(const vptr_gemm_desc& p, f32x4 (&acc)[2][(NFN + 1) / 2], const int m0, const int n0,
+                                              const int wm, const int wn, const int lr, const int lq, const bool first_split,
+                                              const bool use_atomic) {
+  constexpr int NFW = (NFN + 1) / 2;
   // ---- epilogue: C/D fragment layout of v_mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg.
   // Every acc index is a compile-time constant (fully unrolled, no `continue`).
-  const bool first_split = (blockIdx.z == 0);
-  const bool use_atomic = p.atomic || gridDim.z > 1;
   const bool plain = !p.colscale && !p.Dpre && p.act == VPTR_ACT_NONE && !p.rowscale && p.dropout_p == 0.f && !p.act_after &&
                      p.alpha == 1.f;
   const int row_base = m0 + wm * 32 + lq * 4;
@@ -330,29 +296,305 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc 
   }
 }
 
+template <int NFN, int NPASS, int AMODE, int BMODE>
+__global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc p, const int k_chunk) {
+  constexpr int BN = 16 * NFN;
+  constexpr int NFW = (NFN + 1) / 2;     // column fragments per wave
+  constexpr int BROWS = 2 * NFW * 16;    // LDS rows of the B image (>= BN; the surplus rows feed never-stored fragments)
+  constexpr int NPL = (NPASS == 3) ? 2 : 1;
+  using StA = typename std::conditional<AMODE == VPTR_A_KCONTIG, StageKC<GBM, GBM, true>,
+                                        typename std::conditional<AMODE == VPTR_A_KSTRIDED, StageKS<GBM, true>, StageConv>::type>::type;
+  using StB = typename std::conditional<BMODE == VPTR_B_KCONTIG, StageKC<BN, BROWS, false>, StageKS<BROWS, false>>::type;
+  __shared__ __attribute__((aligned(16))) __bf16 sA[NPL][GBM * GLP];
+  __shared__ __attribute__((aligned(16))) __bf16 sB[NPL][BROWS * GLP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 15, lq = lane >> 4;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8, and every XCD has its own L2.  XCD x is given a contiguous
+  // range of the (split, tile_m, tile_n) order, so the A row panel of a tile_m is fetched by one L2 instead of all eight.
+  const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+  const int logical = xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles = tiles_n * ((p.M + GBM - 1) / GBM);
+  const int split = logical / tiles, tile = logical - split * tiles;
+  const int tn = tile % tiles_n, tm = tile / tiles_n;
+  const int m0 = tm * GBM, n0 = tn * BN;
+  const int kbeg = split * k_chunk;
+  const int kend = min(p.K, kbeg + k_chunk);
+  const int nkt = (kend - kbeg + GBK - 1) / GBK;
+
+  f32x4 acc[2][NFW];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NFW; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  StA stA;
+  StB stB;
+  TS_DECL
+  // K-step j+1 is fetched into registers while step j is multiplied out of LDS (single LDS image, two barriers per step);
+  // the other resident waves of the SIMD cover what is left of the HBM / LDS latencies.
+  if constexpr (AMODE == VPTR_A_CONV) stA.load(p, m0, kbeg, kend, tid);
+  else stA.load(p.A, p.lda, m0, p.M, kbeg, kend, tid);
+  stB.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid);
+
+  TS(0)
+  for (int kt = 0; kt < nkt; ++kt) {
+    stA.template store<NPASS>(sA[0], sA[NPL - 1], tid);
+    stB.template store<NPASS>(sB[0], sB[NPL - 1], tid);
+    TS(1)
+    __syncthreads();
+    TS(2)
+    {  // unconditional prefetch of the next step (clamped + masked beyond the K range)
+      const int k1 = kbeg + (kt + 1) * GBK;
+      if constexpr (AMODE == VPTR_A_CONV) stA.load(p, m0, k1, kend, tid);
+      else stA.load(p.A, p.lda, m0, p.M, k1, kend, tid);
+      stB.load(p.B, p.ldb, n0, p.N, k1, kend, tid);
+    }
+    TS(3)
+    bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int off = lds_off(wm * 32 + mi * 16 + lr, lq * 2);
+      ah[mi] = *reinterpret_cast<const bf16x8*>(&sA[0][off]);
+      if constexpr (NPASS == 3) al[mi] = *reinterpret_cast<const bf16x8*>(&sA[NPL - 1][off]);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NFW; ++ni) {
+      const int off = lds_off((wn * NFW + ni) * 16 + lr, lq * 2);
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&sB[0][off]);
+      bf16x8 bl;
+      if constexpr (NPASS == 3) bl = *reinterpret_cast<const bf16x8*>(&sB[NPL - 1][off]);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        if constexpr (NPASS == 3) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+        }
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+      }
+    }
+    TS(4)
+    __syncthreads();
+    TS(2)
+  }
+
+  gemm_epilogue<NFN>(p, acc, m0, n0, wm, wn, lr, lq, split == 0, p.atomic || nblk > tiles);
+  TS(5)
+  TS_FLUSH
+}
+
+// ---- software-pipelined main loop ("P" variant) -------------------------------------------------------------------------
+// The phase probe (tools/gemm_probe.hip) showed the single-image loop above spending ~25 % of a workgroup's cycles in the
+// convert+store phase, ~25 % at the two barriers and ~20 % issuing MFMAs: all 8 waves are in the same phase, so the VALU
+// split and the matrix cores never overlap unless a second workgroup shares the CU.  Here the LDS image is double
+// buffered (80 KB), global loads run two K-steps ahead in two register sets, and the fp32 -> bf16 hi/lo conversion of step
+// j+1 is interleaved, unit by unit, between the MFMA groups of step j: one barrier per step, one workgroup per CU.
+template <int NFN, int NPASS, int AMODE, int BMODE>
+__device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, __bf16* smem, const int m0, const int n0, const int kbeg,
+                                            const int kend, const bool first_split, const bool use_atomic) {
+  constexpr int BN = 16 * NFN;
+  constexpr int NFW = (NFN + 1) / 2;
+  constexpr int BROWS = 2 * NFW * 16;
+  constexpr int NPL = (NPASS == 3) ? 2 : 1;
+  using StA = typename std::conditional<AMODE == VPTR_A_KCONTIG, StageKC<GBM, GBM, true>,
+                                        typename std::conditional<AMODE == VPTR_A_KSTRIDED, StageKS<GBM, true>, StageConv>::type>::type;
+  using StB = typename std::conditional<BMODE == VPTR_B_KCONTIG, StageKC<BN, BROWS, false>, StageKS<BROWS, false>>::type;
+  constexpr int A_EL = GBM * GLP, B_EL = BROWS * GLP, BUF_EL = NPL * (A_EL + B_EL);  // smem: [2 buffers][A hi, A lo, B hi, B lo]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int nkt = (kend - kbeg + GBK - 1) / GBK;
+
+  f32x4 acc[2][NFW];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NFW; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  StA stA0, stA1;
+  StB stB0, stB1;
+  TS_DECL
+  auto loadA = [&](StA& st, const int k0) {
+    if constexpr (AMODE == VPTR_A_CONV) st.load(p, m0, k0, kend, tid);
+    else st.load(p.A, p.lda, m0, p.M, k0, kend, tid);
+  };
+  auto loadB = [&](StB& st, const int k0) { st.load(p.B, p.ldb, n0, p.N, k0, kend, tid); };
+  // fragment read offsets (bf16 elements inside one plane)
+  int offA[2], offB[NFW];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) offA[mi] = lds_off(wm * 32 + mi * 16 + lr, lq * 2);
+#pragma unroll
+  for (int ni = 0; ni < NFW; ++ni) offB[ni] = lds_off((wn * NFW + ni) * 16 + lr, lq * 2);
+
+  // one K-step: multiply out of buffer CUR while converting register set `cv` (step kt+1) into the other buffer
+  auto step = [&](const int cur, StA& cvA, StB& cvB) {
+    __bf16* cA = smem + cur * BUF_EL;
+    __bf16* cB = cA + NPL * A_EL;
+    __bf16* nA = smem + (cur ^ 1) * BUF_EL;
+    __bf16* nB = nA + NPL * A_EL;
+    constexpr int UA = StA::NUNIT, UB = StB::NUNIT, UT = UA + UB;
+    bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      ah[mi] = *reinterpret_cast<const bf16x8*>(&cA[offA[mi]]);
+      if constexpr (NPASS == 3) al[mi] = *reinterpret_cast<const bf16x8*>(&cA[A_EL + offA[mi]]);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NFW; ++ni) {
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&cB[offB[ni]]);
+      bf16x8 bl;
+      if constexpr (NPASS == 3) bl = *reinterpret_cast<const bf16x8*>(&cB[B_EL + offB[ni]]);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        if constexpr (NPASS == 3) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+        }
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+      }
+      // this group's share of the conversion work for the next step
+#pragma unroll
+      for (int u = (ni * UT) / NFW; u < ((ni + 1) * UT) / NFW; ++u) {
+        if (u < UA) cvA.template store_unit<NPASS>(nA, nA + (NPL - 1) * A_EL, tid, u);
+        else cvB.template store_unit<NPASS>(nB, nB + (NPL - 1) * B_EL, tid, u - UA);
+      }
+    }
+  };
+
+  loadA(stA0, kbeg);
+  loadB(stB0, kbeg);
+  loadA(stA1, kbeg + GBK);
+  loadB(stB1, kbeg + GBK);
+  TS(0)
+  stA0.template store<NPASS>(smem, smem + (NPL - 1) * A_EL, tid);
+  stB0.template store<NPASS>(smem + NPL * A_EL, smem + NPL * A_EL + (NPL - 1) * B_EL, tid);
+  TS(1)
+  __syncthreads();
+  TS(2)
+  for (int kt = 0; kt < nkt; kt += 2) {
+    // even step: buffer 0 holds step kt, set 1 holds step kt+1, set 0 is free -> fetch step kt+2 into it
+    loadA(stA0, kbeg + (kt + 2) * GBK);
+    loadB(stB0, kbeg + (kt + 2) * GBK);
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads up here: hipcc otherwise sinks them to the end of the step
+    TS(3)
+    step(0, stA1, stB1);
+    TS(4)
+    __syncthreads();
+    TS(2)
+    if (kt + 1 < nkt) {  // workgroup-uniform
+      loadA(stA1, kbeg + (kt + 3) * GBK);
+      loadB(stB1, kbeg + (kt + 3) * GBK);
+      __builtin_amdgcn_sched_barrier(0);
+      TS(3)
+      step(1, stA0, stB0);
+      TS(4)
+      __syncthreads();
+      TS(2)
+    }
+  }
+  gemm_epilogue<NFN>(p, acc, m0, n0, wm, wn, lr, lq, first_split, use_atomic);
+  TS(5)
+  TS_FLUSH
+}
+
+// XCD-aware order: workgroup b runs on XCD b % 8 and every XCD has its own L2; XCD x gets a contiguous range of the
+// logical (problem, split, tile_m, tile_n) order so that operand panels shared by neighbouring tiles meet in one L2.
+__device__ __forceinline__ int xcd_logical_block() {
+  const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+  return xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
+}
+
+template <int NFN, int NPASS, int AMODE, int BMODE>
+__global__ __launch_bounds__(GNT, 2) void vptr_gemm_kernel_p(const vptr_gemm_desc p, const int k_chunk) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+  const int logical = xcd_logical_block();
+  const int tiles_n = (p.N + 16 * NFN - 1) / (16 * NFN);
+  const int tiles = tiles_n * ((p.M + GBM - 1) / GBM);
+  const int split = logical / tiles, tile = logical - split * tiles;
+  const int kbeg = split * k_chunk;
+  gemm_tile_p<NFN, NPASS, AMODE, BMODE>(p, smem, (tile / tiles_n) * GBM, (tile % tiles_n) * 16 * NFN, kbeg, min(p.K, kbeg + k_chunk),
+                                        split == 0, p.atomic || (int)gridDim.x > tiles);
+}
+
+// Grouped launch: `count` independent problems (same operand modes / precision / NFN class) in one grid, no split-K.
+// tile_start[g] = first logical tile of problem g (prefix sums, tile_start[count] = grid size).  Used for the weight
+// gradients of a whole backward pass (vptr_gemm_grouped): K = all tokens, so every tile runs a long K loop and writes its
+// output once, instead of ~30 K-splits each paying a prologue and a 90 KB atomic epilogue.
+template <int NFN, int NPASS, int AMODE, int BMODE>
+__global__ __launch_bounds__(GNT, 2) void vptr_gemm_grouped_kernel(const vptr_gemm_desc* __restrict__ descs,
+                                                                   const int* __restrict__ tile_start, const int count) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+  const int logical = xcd_logical_block();
+  int lo = 0, hi = count - 1;  // last g with tile_start[g] <= logical (workgroup-uniform scalar search)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_start[mid] <= logical) lo = mid;
+    else hi = mid - 1;
+  }
+  const vptr_gemm_desc p = descs[lo];
+  const int tile = logical - tile_start[lo];
+  const int tiles_n = (p.N + 16 * NFN - 1) / (16 * NFN);
+  gemm_tile_p<NFN, NPASS, AMODE, BMODE>(p, smem, (tile / tiles_n) * GBM, (tile % tiles_n) * 16 * NFN, 0, p.K, true, p.atomic != 0);
+}
+
+
+static int g_gemm_variant = 1;  // 1 = software-pipelined (default), 0 = single-image loop (tools/gemm_probe.hip flips this)
+
+template <int NFN, int NPASS, int AM, int BM>
+static int launch_one(const vptr_gemm_desc& d, dim3 grid, int k_chunk, hipStream_t st) {
+  if (g_gemm_variant == 1) {
+    constexpr int NFW = (NFN + 1) / 2, BROWS = 2 * NFW * 16, NPL = (NPASS == 3) ? 2 : 1;
+    constexpr int LDS_BYTES = 2 * NPL * (GBM + BROWS) * GLP * (int)sizeof(__bf16);
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_kernel_p<NFN, NPASS, AM, BM>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+        vptr_set_error("vptr_gemm: cannot reserve %d bytes of LDS", LDS_BYTES);
+        return -1;
+      }
+      attr_set = true;
+    }
+    vptr_gemm_kernel_p<NFN, NPASS, AM, BM><<<grid, GNT, LDS_BYTES, st>>>(d, k_chunk);
+  } else {
+    vptr_gemm_kernel<NFN, NPASS, AM, BM><<<grid, GNT, 0, st>>>(d, k_chunk);
+  }
+  return 0;
+}
+
 template <int NFN, int NPASS>
 static int launch_modes(const vptr_gemm_desc& d, dim3 grid, int k_chunk, hipStream_t st) {
   if (d.a_mode == VPTR_A_KCONTIG && d.b_mode == VPTR_B_KCONTIG)
-    vptr_gemm_kernel<NFN, NPASS, VPTR_A_KCONTIG, VPTR_B_KCONTIG><<<grid, GNT, 0, st>>>(d, k_chunk);
-  else if (d.a_mode == VPTR_A_KCONTIG && d.b_mode == VPTR_B_KSTRIDED)
-    vptr_gemm_kernel<NFN, NPASS, VPTR_A_KCONTIG, VPTR_B_KSTRIDED><<<grid, GNT, 0, st>>>(d, k_chunk);
-  else if (d.a_mode == VPTR_A_KSTRIDED && d.b_mode == VPTR_B_KSTRIDED)
-    vptr_gemm_kernel<NFN, NPASS, VPTR_A_KSTRIDED, VPTR_B_KSTRIDED><<<grid, GNT, 0, st>>>(d, k_chunk);
-  else if (d.a_mode == VPTR_A_KSTRIDED && d.b_mode == VPTR_B_KCONTIG)
-    vptr_gemm_kernel<NFN, NPASS, VPTR_A_KSTRIDED, VPTR_B_KCONTIG><<<grid, GNT, 0, st>>>(d, k_chunk);
-  else if (d.a_mode == VPTR_A_CONV && d.b_mode == VPTR_B_KCONTIG)
-    vptr_gemm_kernel<NFN, NPASS, VPTR_A_CONV, VPTR_B_KCONTIG><<<grid, GNT, 0, st>>>(d, k_chunk);
-  else {
-    vptr_set_error("vptr_gemm: unsupported operand modes a=%d b=%d", d.a_mode, d.b_mode);
-    return -1;
-  }
-  return 0;
+    return launch_one<NFN, NPASS, VPTR_A_KCONTIG, VPTR_B_KCONTIG>(d, grid, k_chunk, st);
+  if (d.a_mode == VPTR_A_KCONTIG && d.b_mode == VPTR_B_KSTRIDED)
+    return launch_one<NFN, NPASS, VPTR_A_KCONTIG, VPTR_B_KSTRIDED>(d, grid, k_chunk, st);
+  if (d.a_mode == VPTR_A_KSTRIDED && d.b_mode == VPTR_B_KSTRIDED)
+    return launch_one<NFN, NPASS, VPTR_A_KSTRIDED, VPTR_B_KSTRIDED>(d, grid, k_chunk, st);
+  if (d.a_mode == VPTR_A_KSTRIDED && d.b_mode == VPTR_B_KCONTIG)
+    return launch_one<NFN, NPASS, VPTR_A_KSTRIDED, VPTR_B_KCONTIG>(d, grid, k_chunk, st);
+  if (d.a_mode == VPTR_A_CONV && d.b_mode == VPTR_B_KCONTIG)
+    return launch_one<NFN, NPASS, VPTR_A_CONV, VPTR_B_KCONTIG>(d, grid, k_chunk, st);
+  vptr_set_error("vptr_gemm: unsupported operand modes a=%d b=%d", d.a_mode, d.b_mode);
+  return -1;
 }
 
 template <int NFN>
 static int launch_prec(const vptr_gemm_desc& d, dim3 grid, int k_chunk, hipStream_t st) {
   if (d.precision == 3) return launch_modes<NFN, 3>(d, grid, k_chunk, st);
   return launch_modes<NFN, 1>(d, grid, k_chunk, st);
+}
+
+// column-fragment count: exact 176-wide tiles when N is a multiple of 176, otherwise least padding
+static int nfn_for(const int N) {
+  if (N % 176 == 0) return 11;
+  if (N <= 64) return 4;
+  if (N <= 128) return 8;
+  const int w11 = (N + 175) / 176 * 176, w8 = (N + 127) / 128 * 128, w4 = (N + 63) / 64 * 64;
+  int nfn = 11, best = w11;
+  if (w8 < best) { best = w8; nfn = 8; }
+  if (w4 < best) { best = w4; nfn = 4; }
+  return nfn;
 }
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -386,26 +628,55 @@ extern "C" int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream) {
   int k_chunk = ((d.K + d.split_k - 1) / d.split_k + GBK - 1) / GBK * GBK;
   const int splits = (d.K + k_chunk - 1) / k_chunk;
 
-  // column-fragment count: exact 176-wide tiles when N is a multiple of 176, otherwise least padding
-  int nfn;
-  if (d.N % 176 == 0) nfn = 11;
-  else if (d.N <= 64) nfn = 4;
-  else if (d.N <= 128) nfn = 8;
-  else {
-    const int w11 = (d.N + 175) / 176 * 176, w8 = (d.N + 127) / 128 * 128, w4 = (d.N + 63) / 64 * 64;
-    nfn = 11;
-    int best = w11;
-    if (w8 < best) { best = w8; nfn = 8; }
-    if (w4 < best) { best = w4; nfn = 4; }
-  }
+  const int nfn = nfn_for(d.N);
   const int bn = 16 * nfn;
   const int tiles_m = (d.M + GBM - 1) / GBM, tiles_n = (d.N + bn - 1) / bn;
-  dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)splits);
+  dim3 grid((unsigned)(tiles_m * tiles_n * splits), 1, 1);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int rc;
   if (nfn == 11) rc = launch_prec<11>(d, grid, k_chunk, st);
   else if (nfn == 8) rc = launch_prec<8>(d, grid, k_chunk, st);
   else rc = launch_prec<4>(d, grid, k_chunk, st);
+  if (rc) return rc;
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vptr_gemm_tile_cols(int N) { return 16 * nfn_for(N); }
+
+template <int NFN, int NPASS>
+static int launch_grouped(const vptr_gemm_desc* descs, const int* tile_start, int count, int total_tiles, hipStream_t st) {
+  constexpr int NFW = (NFN + 1) / 2, BROWS = 2 * NFW * 16, NPL = (NPASS == 3) ? 2 : 1;
+  constexpr int LDS_BYTES = 2 * NPL * (GBM + BROWS) * GLP * (int)sizeof(__bf16);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_grouped_kernel<NFN, NPASS, VPTR_A_KSTRIDED, VPTR_B_KSTRIDED>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+      vptr_set_error("vptr_gemm_grouped: cannot reserve %d bytes of LDS", LDS_BYTES);
+      return -1;
+    }
+    attr_set = true;
+  }
+  vptr_gemm_grouped_kernel<NFN, NPASS, VPTR_A_KSTRIDED, VPTR_B_KSTRIDED><<<dim3((unsigned)total_tiles), GNT, LDS_BYTES, st>>>(descs, tile_start, count);
+  return 0;
+}
+
+extern "C" int vptr_gemm_grouped(const vptr_gemm_desc* proto, const vptr_gemm_desc* descs_dev, const int* tile_start_dev, int count,
+                                 int total_tiles, vptr_stream_t stream) {
+  VPTR_CHECK(proto && descs_dev && tile_start_dev, "vptr_gemm_grouped: null argument");
+  VPTR_CHECK(count > 0 && total_tiles > 0, "vptr_gemm_grouped: empty group");
+  VPTR_CHECK(proto->a_mode == VPTR_A_KSTRIDED && proto->b_mode == VPTR_B_KSTRIDED,
+             "vptr_gemm_grouped: only k-strided x k-strided problems (weight gradients) are grouped");
+  VPTR_CHECK(proto->precision == 1 || proto->precision == 3, "vptr_gemm_grouped: precision must be 1 or 3");
+  const int nfn = nfn_for(proto->N);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int rc;
+  if (proto->precision == 3) rc = nfn == 11 ? launch_grouped<11, 3>(descs_dev, tile_start_dev, count, total_tiles, st)
+                                 : nfn == 8 ? launch_grouped<8, 3>(descs_dev, tile_start_dev, count, total_tiles, st)
+                                            : launch_grouped<4, 3>(descs_dev, tile_start_dev, count, total_tiles, st);
+  else rc = nfn == 11 ? launch_grouped<11, 1>(descs_dev, tile_start_dev, count, total_tiles, st)
+          : nfn == 8 ? launch_grouped<8, 1>(descs_dev, tile_start_dev, count, total_tiles, st)
+                     : launch_grouped<4, 1>(descs_dev, tile_start_dev, count, total_tiles, st);
   if (rc) return rc;
   VPTR_LAUNCH_CHECK();
   return 0;

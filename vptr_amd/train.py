@@ -120,6 +120,7 @@ class NARTrainer:
         pred_frames = self.dec(pred_feats)
         loss, l_gdl, l_mse, l_pc = self.losses(pred_frames, future, pred_feats, future_feats)
         loss.backward()
+        ops.flush_wgrads()  # no-op: the grouped weight-gradient launch already ran at the end of backward
         self._allreduce_grads()
         self.opt.step()
         return {"T_total": loss.detach(), "T_GDL": l_gdl.detach(), "T_MSE": l_mse.detach(), "T_bpc": l_pc.detach(),
