@@ -174,6 +174,51 @@ struct StageKS {
   }
 };
 
+// k-strided A operand of exactly GBM = 128 rows: 2(k) x 4(out) micro-tiles -> 512 slots, one per thread, no surplus
+// (the 4 x 4 tiling above has only 256 slots for 128 rows, so every thread would load and convert a duplicate: +21 % on
+// the weight-gradient loop).  kb2 = k pair (0..15), ob = out block (0..31); a wave covers 8 k pairs x 8 out blocks =
+// 128-byte row segments; 4 ds_write_b32 per plane, conflict-free with the swizzle above.
+template <bool KMASK>
+struct StageKS2 {
+  static constexpr int LDS_ROWS = GBM;
+  float4 r[2];
+  int nvalid;
+  static __device__ __forceinline__ int kb2_of(const int tid) { return (tid & 7) | (((tid >> 6) & 1) << 3); }
+  static __device__ __forceinline__ int ob_of(const int tid) { return ((tid >> 3) & 7) | ((tid >> 7) << 3); }
+  __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0, int kend, int tid) {
+    const int kb2 = kb2_of(tid), ob = ob_of(tid);
+    nvalid = kend - (k0 + kb2 * 2);
+    const int mm = min(row0 + ob * 4, nrows - 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) r[j] = *reinterpret_cast<const float4*>(P + (int64_t)min(k0 + kb2 * 2 + j, kend - 1) * ld + mm);
+  }
+  static constexpr int NUNIT = 4;
+  static __device__ __forceinline__ float comp(const float4 v, const int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+  template <int NPASS>
+  __device__ __forceinline__ void store_unit(__bf16* s_hi, __bf16* s_lo, int tid, const int j) {
+    const int kb2 = kb2_of(tid), ob = ob_of(tid);
+    float a = comp(r[0], j), b = comp(r[1], j);
+    if constexpr (KMASK) {
+      a = __uint_as_float(__float_as_uint(a) & (nvalid > 0 ? ~0u : 0u));
+      b = __uint_as_float(__float_as_uint(b) & (nvalid > 1 ? ~0u : 0u));
+    }
+    const int o = lds_off(ob * 4 + j, kb2 >> 1) + ((kb2 & 1) << 1);
+    if constexpr (NPASS == 3) {
+      uint32_t hi, lo;
+      split2(a, b, hi, lo);
+      *reinterpret_cast<uint32_t*>(&s_hi[o]) = hi;
+      *reinterpret_cast<uint32_t*>(&s_lo[o]) = lo;
+    } else {
+      *reinterpret_cast<uint32_t*>(&s_hi[o]) = pk_bf16(a, b);
+    }
+  }
+  template <int NPASS>
+  __device__ __forceinline__ void store(__bf16* s_hi, __bf16* s_lo, int tid) {
+#pragma unroll
+    for (int u = 0; u < NUNIT; ++u) store_unit<NPASS>(s_hi, s_lo, tid, u);
+  }
+};
+
 // implicit-GEMM gather of an NHWC image (Conv2d / gather-form ConvTranspose2d); slot map of StageKC<128>
 struct StageConv {
   static constexpr int LDS_ROWS = GBM;
@@ -303,7 +348,7 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc 
   constexpr int BROWS = 2 * NFW * 16;    // LDS rows of the B image (>= BN; the surplus rows feed never-stored fragments)
   constexpr int NPL = (NPASS == 3) ? 2 : 1;
   using StA = typename std::conditional<AMODE == VPTR_A_KCONTIG, StageKC<GBM, GBM, true>,
-                                        typename std::conditional<AMODE == VPTR_A_KSTRIDED, StageKS<GBM, true>, StageConv>::type>::type;
+                                        typename std::conditional<AMODE == VPTR_A_KSTRIDED, StageKS2<true>, StageConv>::type>::type;
   using StB = typename std::conditional<BMODE == VPTR_B_KCONTIG, StageKC<BN, BROWS, false>, StageKS<BROWS, false>>::type;
   __shared__ __attribute__((aligned(16))) __bf16 sA[NPL][GBM * GLP];
   __shared__ __attribute__((aligned(16))) __bf16 sB[NPL][BROWS * GLP];
@@ -399,7 +444,7 @@ __device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, __bf16* sme
   constexpr int BROWS = 2 * NFW * 16;
   constexpr int NPL = (NPASS == 3) ? 2 : 1;
   using StA = typename std::conditional<AMODE == VPTR_A_KCONTIG, StageKC<GBM, GBM, true>,
-                                        typename std::conditional<AMODE == VPTR_A_KSTRIDED, StageKS<GBM, true>, StageConv>::type>::type;
+                                        typename std::conditional<AMODE == VPTR_A_KSTRIDED, StageKS2<true>, StageConv>::type>::type;
   using StB = typename std::conditional<BMODE == VPTR_B_KCONTIG, StageKC<BN, BROWS, false>, StageKS<BROWS, false>>::type;
   constexpr int A_EL = GBM * GLP, B_EL = BROWS * GLP, BUF_EL = NPL * (A_EL + B_EL);  // smem: [2 buffers][A hi, A lo, B hi, B lo]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -416,11 +461,20 @@ __device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, __bf16* sme
   StA stA0, stA1;
   StB stB0, stB1;
   TS_DECL
+  // VPTR_EXP_NOLOAD / VPTR_EXP_NOCVT: elimination experiments of tools/gemm_probe.hip (results in DESIGN.md section 4)
   auto loadA = [&](StA& st, const int k0) {
+#ifdef VPTR_EXP_NOLOAD
+    if (k0 > kbeg + 2 * GBK) return;
+#endif
     if constexpr (AMODE == VPTR_A_CONV) st.load(p, m0, k0, kend, tid);
     else st.load(p.A, p.lda, m0, p.M, k0, kend, tid);
   };
-  auto loadB = [&](StB& st, const int k0) { st.load(p.B, p.ldb, n0, p.N, k0, kend, tid); };
+  auto loadB = [&](StB& st, const int k0) {
+#ifdef VPTR_EXP_NOLOAD
+    if (k0 > kbeg + 2 * GBK) return;
+#endif
+    st.load(p.B, p.ldb, n0, p.N, k0, kend, tid);
+  };
   // fragment read offsets (bf16 elements inside one plane)
   int offA[2], offB[NFW];
 #pragma unroll
@@ -455,11 +509,13 @@ __device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, __bf16* sme
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
       }
       // this group's share of the conversion work for the next step
+#ifndef VPTR_EXP_NOCVT
 #pragma unroll
       for (int u = (ni * UT) / NFW; u < ((ni + 1) * UT) / NFW; ++u) {
         if (u < UA) cvA.template store_unit<NPASS>(nA, nA + (NPL - 1) * A_EL, tid, u);
         else cvB.template store_unit<NPASS>(nB, nB + (NPL - 1) * B_EL, tid, u - UA);
       }
+#endif
     }
   };
 
