@@ -61,7 +61,19 @@ def _bn_eval(bn):
     if bn.training:
         raise NotImplementedError("HIP auto-encoder path supports eval-mode BatchNorm only (stage-2 / inference); "
                                   "stage-1 AE training is a 'next' row (SURVEY.md section 8f)")
-    return ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    # the fold (4 tiny launches) is cached per module and recomputed only when one of its tensors was modified in place
+    # or re-pointed: stage 2 runs ~100 eval-BN folds per step on parameters that never change
+    if not ops.config.weights_frozen:
+        return ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = tuple(t._version for t in ts) + tuple(t.data_ptr() for t in ts)
+    hit = getattr(bn, "_vptr_fold", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.no_grad():
+        val = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    bn._vptr_fold = (key, val)
+    return val
 
 
 class ResnetEncoder(nn.Module):
@@ -88,6 +100,10 @@ class ResnetEncoder(nn.Module):
 
     def forward(self, x):
         """x (B, Cimg, H, W) NCHW -> (B, out_dim, H/2^n, W/2^n)."""
+        with ops.frozen_weights(getattr(self, "_vptr_frozen", False)):
+            return self._forward(x)
+
+    def _forward(self, x):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             # stage 2 runs the encoder under no_grad (train_NAR.py:54-56)
             if x.requires_grad:
@@ -136,6 +152,16 @@ class _DecoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feat, dec, *params):
+        with ops.frozen_weights(getattr(dec, "_vptr_frozen", False)):
+            return _DecoderFn._forward(ctx, feat, dec, *params)
+
+    @staticmethod
+    def backward(ctx, dout):
+        with ops.frozen_weights(getattr(ctx.dec, "_vptr_frozen", False)):
+            return _DecoderFn._backward(ctx, dout)
+
+    @staticmethod
+    def _forward(ctx, feat, dec, *params):
         B, C, h, w = feat.shape
         m = dec.model
         n_up = dec.n_upsampling
@@ -166,7 +192,7 @@ class _DecoderFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def _backward(ctx, dout):
         (out,) = ctx.saved_tensors
         dec, acts, scales, geoms, B = ctx.dec, ctx.acts, ctx.scales, ctx.geoms, ctx.B
         m = dec.model
@@ -212,7 +238,7 @@ class _DecoderFn(torch.autograd.Function):
             # dgrad of ConvTranspose2d(3x3, s2, p1, op1) = Conv2d(3x3, s2, p1) of the output gradient with
             # B[ci][(ky,kx,co)] = W[ci][co][ky][kx]
             wt = m[3 * i].weight
-            Bm = wt.permute(0, 2, 3, 1).reshape(wt.shape[0], -1).contiguous()
+            Bm = ops.conv_weight_as_gemm_b(wt, False)  # = wt.permute(0, 2, 3, 1).reshape(Cin, -1), cached
             g = ops.conv_nhwc(gm, Bm, B, oh, ow, oc, ih, iw, 3, 3, 2, 1, "zero", False, ic)
         h0, w0, c0 = geoms[0][0], geoms[0][1], geoms[0][2]
         dfeat = torch.empty((B, c0, h0, w0), device=dout.device, dtype=torch.float32)

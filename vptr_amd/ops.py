@@ -26,6 +26,7 @@ class _Config:
     """
     gemm_precision = 3
     group_wgrads = True
+    weights_frozen = False  # set by the frozen_weights scope only
 
 
 config = _Config()
@@ -618,9 +619,43 @@ def conv_weight_as_gemm_b(weight, transposed):
 
     Conv2d weight [Cout, Cin, KH, KW]; ConvTranspose2d weight [Cin, Cout, KH, KW].
     """
-    if transposed:
-        return weight.permute(1, 2, 3, 0).reshape(weight.shape[1], -1).contiguous()
-    return weight.permute(0, 2, 3, 1).reshape(weight.shape[0], -1).contiguous()
+    def pack():
+        if transposed:
+            return weight.permute(1, 2, 3, 0).reshape(weight.shape[1], -1).contiguous()
+        return weight.permute(0, 2, 3, 1).reshape(weight.shape[0], -1).contiguous()
+
+    if not config.weights_frozen:
+        return pack()
+    # frozen_weights scope (stage 2: the auto-encoder is never stepped): the packed copy is kept on the parameter object,
+    # keyed by version counter and address; otherwise ~30 conv weights (up to 10 MB each) are re-packed 3x per step
+    attr = "_vptr_packed_t" if transposed else "_vptr_packed"
+    key = (weight._version, weight.data_ptr())
+    hit = getattr(weight, attr, None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.no_grad():
+        B = pack()
+    setattr(weight, attr, (key, B))
+    return B
+
+
+class frozen_weights:
+    """Scope in which derived copies of module weights (packed conv weights, eval-BN folds) may be cached on the module /
+    parameter objects.  Entered by the auto-encoder modules that `NARTrainer` marks `_vptr_frozen` (stage 2 never steps
+    them); a cache entry is keyed by the tensors' version counters and addresses, so `load_state_dict` / optimizer steps
+    invalidate it -- but writes through `.data` or raw kernels would not, hence the explicit opt-in."""
+
+    def __init__(self, flag):
+        self.flag = bool(flag)
+
+    def __enter__(self):
+        self.prev = config.weights_frozen
+        config.weights_frozen = self.flag
+        return self
+
+    def __exit__(self, *exc):
+        config.weights_frozen = self.prev
+        return False
 
 
 def conv_nhwc(x, Bmat, frames, IH, IW, Cin, OH, OW, KH, KW, stride, pad, pad_mode, transposed, Cout, colscale=None,

@@ -83,6 +83,8 @@ class NARTrainer:
         for p in dec.parameters():
             p.requires_grad_(bool(dec_weight_grads))
         self.dec_weight_grads = bool(dec_weight_grads)
+        for mod in list(self.enc.modules()) + list(self.dec.modules()):
+            mod._vptr_frozen = True  # never stepped here: packed conv weights / eval-BN folds are cached (ops.frozen_weights)
         self.opt = FlatAdamW(self.T.parameters(), lr=lr, max_grad_norm=max_grad_norm)
         dev = self.opt.flat.device
         self.mse, self.gdl = MSELoss(), GDL(alpha=1)
