@@ -161,7 +161,8 @@ int vptr_norm_act_fwd(const float* x, const float* mean, const float* rstd, cons
                       int rows, int F, int HW, int per_col, int act, float dropout_p, const uint64_t* seed_dev,
                       uint32_t site, const float* rowscale, int rs_div, int rs_mod, const float* residual,
                       vptr_stream_t stream);
-/* backward: dx written; dw/db ACCUMULATED (same layout as w/b). scratch >= 2*max(F, rows/HW) floats, zeroed inside.
+/* backward: dx written; dw/db ACCUMULATED (same layout as w/b).  scratch (initialised inside): per_col: >= 2*F floats;
+ * per-frame: >= 2*frames*(1 + 4*ceil(HW*F/1024)) floats, frames = rows/HW (frame sums + per-wave partials).
  * const_stats != 0: mean/rstd are constants (BatchNorm in eval mode) -> no statistics terms in dx. */
 int vptr_norm_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w, const float* b,
                       float* dx, float* dw, float* db, float* scratch, int rows, int F, int HW, int per_col, int act,

@@ -115,11 +115,93 @@ __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const float* __restri
   unsafeAtomicAdd(dbeta + c, ab);
 }
 
+// dx + dgamma/dbeta in ONE pass: one wave per row, the row held in registers as NC4 float4 per lane between the two
+// reductions; the parameter gradients are accumulated per lane over the wave's rows, summed over the block's 4 waves in LDS,
+// and leave the block as one atomic per column.  C % 4 == 0 and C <= 256 * NC4.
+template <int NC4>
+__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restrict__ dy_, const float* __restrict__ dy2_,
+                                                           const float* __restrict__ x_, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           float* __restrict__ dx_, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int rows, int C, int rpb) {
+  __shared__ float4 red[4][2][NC4 * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int C4 = C >> 2;
+  const int r0 = blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 gam[NC4], ag[NC4], ab[NC4];
+#pragma unroll
+  for (int k = 0; k < NC4; ++k) {
+    const int i = lane + 64 * k;
+    gam[k] = i < C4 ? reinterpret_cast<const float4*>(gamma)[i] : z;
+    ag[k] = z;
+    ab[k] = z;
+  }
+  const float inv_c = 1.f / (float)C;
+  for (int row = r0 + wv; row < r1; row += 4) {
+    const float4* dy = reinterpret_cast<const float4*>(dy_) + (int64_t)row * C4;
+    const float4* x = reinterpret_cast<const float4*>(x_) + (int64_t)row * C4;
+    float4* dx = reinterpret_cast<float4*>(dx_) + (int64_t)row * C4;
+    const float mu = mean[row], rs = rstd[row];
+    float4 g[NC4], xh[NC4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC4; ++k) {
+      const int i = lane + 64 * k;
+      const float m = i < C4 ? 1.f : 0.f;
+      const int ic = min(i, C4 - 1);
+      float4 gv = dy[ic];
+      if (dy2_) {
+        const float4 g2 = reinterpret_cast<const float4*>(dy2_)[(int64_t)row * C4 + ic];
+        gv.x += g2.x; gv.y += g2.y; gv.z += g2.z; gv.w += g2.w;
+      }
+      const float4 xv = x[ic];
+      g[k] = make_float4(gv.x * m, gv.y * m, gv.z * m, gv.w * m);
+      xh[k] = make_float4((xv.x - mu) * rs * m, (xv.y - mu) * rs * m, (xv.z - mu) * rs * m, (xv.w - mu) * rs * m);
+      const float4 gg = make_float4(g[k].x * gam[k].x, g[k].y * gam[k].y, g[k].z * gam[k].z, g[k].w * gam[k].w);
+      s1 += (gg.x + gg.y) + (gg.z + gg.w);
+      s2 += (gg.x * xh[k].x + gg.y * xh[k].y) + (gg.z * xh[k].z + gg.w * xh[k].w);
+    }
+    s1 = wave_sum(s1) * inv_c;
+    s2 = wave_sum(s2) * inv_c;
+#pragma unroll
+    for (int k = 0; k < NC4; ++k) {
+      const int i = lane + 64 * k;
+      if (i < C4)
+        dx[i] = make_float4(rs * (g[k].x * gam[k].x - s1 - xh[k].x * s2), rs * (g[k].y * gam[k].y - s1 - xh[k].y * s2),
+                            rs * (g[k].z * gam[k].z - s1 - xh[k].z * s2), rs * (g[k].w * gam[k].w - s1 - xh[k].w * s2));
+      ag[k].x += g[k].x * xh[k].x; ag[k].y += g[k].y * xh[k].y; ag[k].z += g[k].z * xh[k].z; ag[k].w += g[k].w * xh[k].w;
+      ab[k].x += g[k].x; ab[k].y += g[k].y; ab[k].z += g[k].z; ab[k].w += g[k].w;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NC4; ++k) {
+    red[wv][0][k * 64 + lane] = ag[k];
+    red[wv][1][k * 64 + lane] = ab[k];
+  }
+  __syncthreads();
+  const float* rf = reinterpret_cast<const float*>(&red[0][0][0]);
+  constexpr int WS = 2 * NC4 * 64 * 4, PS = NC4 * 64 * 4;  // floats per wave / per plane
+  for (int i = threadIdx.x; i < C; i += 256) {
+    unsafeAtomicAdd(dgamma + i, rf[i] + rf[WS + i] + rf[2 * WS + i] + rf[3 * WS + i]);
+    unsafeAtomicAdd(dbeta + i, rf[PS + i] + rf[WS + PS + i] + rf[2 * WS + PS + i] + rf[3 * WS + PS + i]);
+  }
+}
+
 extern "C" int vptr_layernorm_bwd(const float* dy, const float* dy2, const float* x, const float* gamma, const float* mean,
                                   const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int C,
                                   vptr_stream_t stream) {
   VPTR_CHECK(rows > 0 && C > 0, "layernorm_bwd: empty input");
   hipStream_t st = (hipStream_t)stream;
+  if (dx && dgamma && dbeta && C % 4 == 0 && C <= 1024) {
+    const int rpb = rows >= 4096 ? 16 : 4;
+    const int nb = cdiv(rows, rpb);
+    if (C <= 256) ln_bwd_fused_kernel<1><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb);
+    else if (C <= 768) ln_bwd_fused_kernel<3><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb);
+    else ln_bwd_fused_kernel<4><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb);
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
   if (dx) ln_bwd_dx_kernel<<<cdiv(rows, 4), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, rows, C);
   if (dgamma && dbeta) {
     const int rpb = 64;
@@ -406,59 +488,22 @@ __global__ __launch_bounds__(256) void norm_act_bwd_col_reduce(const float* __re
   unsafeAtomicAdd(acc + c, aw);
   unsafeAtomicAdd(acc + F + c, ab);
 }
-// phase 1a, per-frame (LN over (F,H,W)): a frame is one contiguous run of E = HW*F floats and the channel-last affine has
-// the same indexing, so the frame sums s1 = sum g*w, s2 = sum g*w*xhat are flat float4 reductions.  grid (frames, splits).
-__global__ __launch_bounds__(256) void norm_act_bwd_frame_sums(const float* __restrict__ dy, const float* __restrict__ x,
-                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                               const float* __restrict__ w, const float* __restrict__ b,
-                                                               float* __restrict__ fsum /* [2,frames] */, int E4, int F, int HW,
-                                                               int act, float p, const uint64_t* seed_dev, uint32_t site,
-                                                               int frames, const float* __restrict__ rowscale, int rs_div,
-                                                               int rs_mod) {
-  __shared__ float red[16];
-  const int f = blockIdx.x;
-  uint64_t seed = 0;
-  if (p > 0.f) seed = *seed_dev;
-  const float mu = mean[f], rs = rstd[f];
-  const int per = (E4 + gridDim.y - 1) / gridDim.y;
-  const int e0 = blockIdx.y * per, e1 = min(E4, e0 + per);
-  const float4* dyf = reinterpret_cast<const float4*>(dy) + (int64_t)f * E4;
-  const float4* xf = reinterpret_cast<const float4*>(x) + (int64_t)f * E4;
-  float t1 = 0.f, t2 = 0.f;
-  for (int e = e0 + threadIdx.x; e < e1; e += 256) {
-    const float4 d = dyf[e], xv = xf[e];
-    const float4 wv = reinterpret_cast<const float4*>(w)[e], bv = reinterpret_cast<const float4*>(b)[e];
-    const int64_t i = ((int64_t)f * E4 + e) * 4;
-    float rsc = 1.f;
-    if (rowscale) rsc = rowscale[((f * HW + (e * 4) / F) / rs_div) % rs_mod];
-    const float dv[4] = {d.x, d.y, d.z, d.w}, xs[4] = {xv.x, xv.y, xv.z, xv.w};
-    const float ws[4] = {wv.x, wv.y, wv.z, wv.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float xh = (xs[q] - mu) * rs;
-      const float ds = (p > 0.f ? vptr_drop_scale(seed, site, (uint64_t)(i + q), p) : 1.f) * rsc;
-      const float g = norm_act_g(dv[q], xh, ws[q], bs[q], act, ds) * ws[q];
-      t1 += g;
-      t2 += g * xh;
-    }
-  }
-  t1 = block_sum(t1, red);
-  t2 = block_sum(t2, red);
-  if (threadIdx.x == 0) {
-    unsafeAtomicAdd(fsum + f, t1);
-    unsafeAtomicAdd(fsum + frames + f, t2);
-  }
-}
-// phase 1b: affine gradients dw[e] += sum_f g*xhat, db[e] += sum_f g; thread per float4 of the frame, loop over a frame chunk.
+// phase 1 (fused 1a + 1b, one pass over dy and x instead of two): affine gradients dw[e] += sum_f g*xhat, db[e] += sum_f g
+// (thread per float4 of the frame, loop over a frame chunk) AND the frame sums s1[f] += sum_e g*w, s2[f] += sum_e g*w*xhat
+// (wave reduction per frame, one atomic pair per wave).  The threads past E4 keep running with zero weight so that every
+// wave takes part in the shuffles.
 __global__ __launch_bounds__(256) void norm_act_bwd_frame_affine(const float* __restrict__ dy, const float* __restrict__ x,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ w, const float* __restrict__ b,
-                                                                 float* __restrict__ dw, float* __restrict__ db, int E4, int F,
+                                                                 float* __restrict__ dw, float* __restrict__ db,
+                                                                 float* __restrict__ fsum /* [gridDim.x*4, frames, 2] partials */, int E4, int F,
                                                                  int HW, int act, float p, const uint64_t* seed_dev,
                                                                  uint32_t site, int frames, int fpb,
                                                                  const float* __restrict__ rowscale, int rs_div, int rs_mod) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= E4) return;
+  const int e_raw = blockIdx.x * 256 + threadIdx.x;
+  const bool live = e_raw < E4;
+  const int e = live ? e_raw : E4 - 1;
+  const float lv = live ? 1.f : 0.f;
   uint64_t seed = 0;
   if (p > 0.f) seed = *seed_dev;
   const int f0 = blockIdx.y * fpb, f1 = min(frames, f0 + fpb);
@@ -467,6 +512,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_frame_affine(const float* __
   float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
   const int hw = (e * 4) / F;
   for (int f = f0; f < f1; ++f) {
+    float t1 = 0.f, t2 = 0.f;
     const float4 d = reinterpret_cast<const float4*>(dy)[(int64_t)f * E4 + e];
     const float4 xv = reinterpret_cast<const float4*>(x)[(int64_t)f * E4 + e];
     const float mu = mean[f], rs = rstd[f];
@@ -478,11 +524,23 @@ __global__ __launch_bounds__(256) void norm_act_bwd_frame_affine(const float* __
     for (int q = 0; q < 4; ++q) {
       const float xh = (xs[q] - mu) * rs;
       const float ds = (p > 0.f ? vptr_drop_scale(seed, site, (uint64_t)(i + q), p) : 1.f) * rsc;
-      const float g = norm_act_g(dv[q], xh, ws[q], bs[q], act, ds);
+      const float g = norm_act_g(dv[q], xh, ws[q], bs[q], act, ds) * lv;
       aw[q] += g * xh;
       ab[q] += g;
+      t1 += g * ws[q];
+      t2 += g * ws[q] * xh;
+    }
+    if (fsum) {  // per-wave partials, no atomics: 500+ waves adding into the same 2*frames words serialise badly
+      t1 = wave_sum(t1);
+      t2 = wave_sum(t2);
+      if ((threadIdx.x & 63) == 0) {
+        float* dst = fsum + ((int64_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * frames + f) * 2;
+        dst[0] = t1;
+        dst[1] = t2;
+      }
     }
   }
+  if (!live) return;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     unsafeAtomicAdd(dw + (int64_t)e * 4 + q, aw[q]);
@@ -523,6 +581,19 @@ __global__ __launch_bounds__(256) void norm_act_bwd_dx_kernel(const float* __res
     dx[i] = rs * (g * ww - s1 * inv_n - xh * s2 * inv_n);
   }
 }
+// phase 1c: s1[f], s2[f] = sum of the per-wave partials of phase 1
+__global__ __launch_bounds__(64) void norm_act_bwd_frame_final(const float* __restrict__ part, float* __restrict__ fsum, int nparts,
+                                                              int frames) {
+  const int f = blockIdx.x;
+  float t1 = 0.f, t2 = 0.f;
+  for (int q = threadIdx.x; q < nparts; q += 64) {
+    t1 += part[((int64_t)q * frames + f) * 2];
+    t2 += part[((int64_t)q * frames + f) * 2 + 1];
+  }
+  t1 = wave_sum(t1);
+  t2 = wave_sum(t2);
+  if (threadIdx.x == 0) { fsum[f] = t1; fsum[frames + f] = t2; }
+}
 __global__ void accum2_kernel(const float* __restrict__ acc, float* __restrict__ dw, float* __restrict__ db, int F) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c < F) { dw[c] += acc[c]; db[c] += acc[F + c]; }
@@ -555,16 +626,15 @@ extern "C" int vptr_norm_act_bwd(const float* dy, const float* x, const float* m
   } else {
     VPTR_CHECK(rows % HW == 0, "norm_act_bwd: rows must be a multiple of HW");
     const int frames = rows / HW;
-    zero_fill_kernel<<<cdiv(2 * frames, 256), 256, 0, st>>>(scratch, 2 * frames);
     VPTR_CHECK(F % 4 == 0, "norm_act_bwd: F must be a multiple of 4");
     const int E4 = HW * F / 4;
-    const int splits = frames >= 512 ? 1 : (frames >= 128 ? 4 : 8);
-    norm_act_bwd_frame_sums<<<dim3(frames, splits), 256, 0, st>>>(dy, x, mean, rstd, w, b, scratch, E4, F, HW, act, dropout_p, seed_dev,
-                                                                 site, frames, rowscale, rs_div, rs_mod);
     const int fpb = frames >= 64 ? (frames + 3) / 4 : frames;
-    norm_act_bwd_frame_affine<<<dim3(cdiv(E4, 256), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, mean, rstd, w, b, dw, db, E4, F, HW, act,
+    const int nparts = cdiv(E4, 256) * 4;  // scratch: [2*frames] sums followed by [nparts, frames, 2] per-wave partials
+    float* part = scratch + 2 * frames;
+    norm_act_bwd_frame_affine<<<dim3(cdiv(E4, 256), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, mean, rstd, w, b, dw, db, part, E4, F, HW, act,
                                                                                      dropout_p, seed_dev, site, frames, fpb, rowscale,
                                                                                      rs_div, rs_mod);
+    norm_act_bwd_frame_final<<<frames, 64, 0, st>>>(part, scratch, nparts, frames);
     norm_act_bwd_dx_kernel<false><<<blocks, 256, 0, st>>>(dy, x, mean, rstd, w, b, scratch, dx, rows, F, HW, act, dropout_p,
                                                           seed_dev, site, frames, const_stats, rowscale, rs_div, rs_mod);
   }
@@ -575,73 +645,108 @@ extern "C" int vptr_norm_act_bwd(const float* dy, const float* x, const float* m
 // ---------------------------------------------------------------------------------------------------------------
 // depthwise 3x3, padding 1, channel-last [frames, H, W, F]; weights tap-major [9, F].
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w9,
-                                                         const float* __restrict__ b, float* __restrict__ y, int frames, int H,
+// Forward (and, with flipped taps, the data gradient): thread = (frame, x column, 4 channels); it walks down the column
+// with a rolling 3-row window in registers, so every output costs 3 new float4 loads instead of 9 inputs + 9 weights
+// (the first version was bound by the CU's vector-memory issue rate, not by HBM).
+struct DwRow { float4 l, m, r; };
+// branch-free: addresses clamped into the image, out-of-range taps multiplied by zero
+__device__ __forceinline__ float4 scale4(const float4 v, const float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
+__device__ __forceinline__ DwRow dw_load_row(const float4* __restrict__ x, int64_t frame_row0, int row, int H, int xw, int W, int F4,
+                                             int c4) {
+  const float rok = (row >= 0 && row < H) ? 1.f : 0.f;
+  const int64_t base = (frame_row0 + min(max(row, 0), H - 1)) * W;
+  DwRow o;
+  o.l = scale4(x[(base + max(xw - 1, 0)) * F4 + c4], xw > 0 ? rok : 0.f);
+  o.m = scale4(x[(base + xw) * F4 + c4], rok);
+  o.r = scale4(x[(base + min(xw + 1, W - 1)) * F4 + c4], xw + 1 < W ? rok : 0.f);
+  return o;
+}
+__device__ __forceinline__ void fma4(float4& a, const float4 w, const float4 v) {
+  a.x += w.x * v.x; a.y += w.y * v.y; a.z += w.z * v.z; a.w += w.w * v.w;
+}
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ x_, const float* __restrict__ w9,
+                                                         const float* __restrict__ b, float* __restrict__ y_, int frames, int H,
                                                          int W, int F4, int flip) {
-  const int64_t total = (int64_t)frames * H * W * F4;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c4 = (int)(i % F4);
-    const int64_t pix = i / F4;
-    const int xw = (int)(pix % W);
-    const int yh = (int)((pix / W) % H);
-    const int64_t f = pix / ((int64_t)W * H);
-    float4 a = b ? reinterpret_cast<const float4*>(b)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)frames * W * F4) return;
+  const int c4 = (int)(idx % F4);
+  const int xw = (int)((idx / F4) % W);
+  const int64_t f = idx / ((int64_t)F4 * W);
+  const float4* __restrict__ x = reinterpret_cast<const float4*>(x_);
+  float4* __restrict__ y = reinterpret_cast<float4*>(y_);
+  float4 w[9];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = yh + ky - 1;
-      if (iy < 0 || iy >= H) continue;
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = xw + kx - 1;
-        if (ix < 0 || ix >= W) continue;
-        const int tap = flip ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx;
-        const float4 wv = reinterpret_cast<const float4*>(w9)[(int64_t)tap * F4 + c4];
-        const float4 xv = reinterpret_cast<const float4*>(x)[((f * H + iy) * W + ix) * F4 + c4];
-        a.x += wv.x * xv.x; a.y += wv.y * xv.y; a.z += wv.z * xv.z; a.w += wv.w * xv.w;
-      }
-    }
-    reinterpret_cast<float4*>(y)[i] = a;
+  for (int t = 0; t < 9; ++t) w[t] = reinterpret_cast<const float4*>(w9)[(int64_t)(flip ? 8 - t : t) * F4 + c4];
+  const float4 bias = b ? reinterpret_cast<const float4*>(b)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  DwRow r0 = dw_load_row(x, f * H, -1, H, xw, W, F4, c4), r1 = dw_load_row(x, f * H, 0, H, xw, W, F4, c4);
+  for (int yh = 0; yh < H; ++yh) {
+    const DwRow r2 = dw_load_row(x, f * H, yh + 1, H, xw, W, F4, c4);
+    float4 a = bias;
+    fma4(a, w[0], r0.l); fma4(a, w[1], r0.m); fma4(a, w[2], r0.r);
+    fma4(a, w[3], r1.l); fma4(a, w[4], r1.m); fma4(a, w[5], r1.r);
+    fma4(a, w[6], r2.l); fma4(a, w[7], r2.m); fma4(a, w[8], r2.r);
+    y[((f * H + yh) * W + xw) * F4 + c4] = a;
+    r0 = r1;
+    r1 = r2;
   }
 }
-// dw9[tap, c] += sum_{f,y,x} dy[f,y,x,c] * x[f,y+ky-1,x+kx-1,c];  db[c] += sum dy.  Thread per channel.
-__global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// dw9[tap, c] += sum_{f,y,x} dy[f,y,x,c] * x[f,y+ky-1,x+kx-1,c];  db[c] += sum dy.
+// Block = 32 channel quads x 8 x-lanes over a chunk of frames; every thread walks its columns with the same rolling window
+// (1 + 3 float4 loads per pixel), the 8 x-lanes are summed through LDS and each block issues 40 atomics per channel quad.
+#define DWB_C4 32
+#define DWB_XL 8
+__global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restrict__ dy_, const float* __restrict__ x_,
                                                            float* __restrict__ dw9, float* __restrict__ db, int frames, int H,
-                                                           int W, int F, int fpb) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= F) return;
+                                                           int W, int F4, int fpb) {
+  __shared__ float red[DWB_XL * DWB_C4 * 41];
+  const int cl = threadIdx.x % DWB_C4, xl = threadIdx.x / DWB_C4;
+  const int c4 = blockIdx.x * DWB_C4 + cl;
+  const bool cok = c4 < F4;
+  const int c4c = cok ? c4 : F4 - 1;
+  const float4* __restrict__ x = reinterpret_cast<const float4*>(x_);
+  const float4* __restrict__ dy = reinterpret_cast<const float4*>(dy_);
   const int f0 = blockIdx.y * fpb, f1 = min(frames, f0 + fpb);
-  float a[9];
+  float4 acc[9], ab = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int t = 0; t < 9; ++t) a[t] = 0.f;
-  float ab = 0.f;
-  for (int f = f0; f < f1; ++f)
-    for (int yh = 0; yh < H; ++yh)
-      for (int xw = 0; xw < W; ++xw) {
-        const float g = dy[(((int64_t)f * H + yh) * W + xw) * F + c];
-        ab += g;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int iy = yh + ky - 1;
-          if (iy < 0 || iy >= H) continue;
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int ix = xw + kx - 1;
-            if (ix < 0 || ix >= W) continue;
-            a[ky * 3 + kx] += g * x[(((int64_t)f * H + iy) * W + ix) * F + c];
-          }
-        }
+  for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t f = f0; f < f1; ++f)
+    for (int xw = xl; xw < W; xw += DWB_XL) {
+      DwRow r0 = dw_load_row(x, f * H, -1, H, xw, W, F4, c4c), r1 = dw_load_row(x, f * H, 0, H, xw, W, F4, c4c);
+      for (int yh = 0; yh < H; ++yh) {
+        const DwRow r2 = dw_load_row(x, f * H, yh + 1, H, xw, W, F4, c4c);
+        const float4 g = dy[((f * H + yh) * W + xw) * F4 + c4c];
+        ab.x += g.x; ab.y += g.y; ab.z += g.z; ab.w += g.w;
+        fma4(acc[0], g, r0.l); fma4(acc[1], g, r0.m); fma4(acc[2], g, r0.r);
+        fma4(acc[3], g, r1.l); fma4(acc[4], g, r1.m); fma4(acc[5], g, r1.r);
+        fma4(acc[6], g, r2.l); fma4(acc[7], g, r2.m); fma4(acc[8], g, r2.r);
+        r0 = r1;
+        r1 = r2;
       }
+    }
+  float* mine = red + (xl * DWB_C4 + cl) * 41;  // 41-float pitch: conflict-free column sums below
 #pragma unroll
-  for (int t = 0; t < 9; ++t) unsafeAtomicAdd(dw9 + (int64_t)t * F + c, a[t]);
-  unsafeAtomicAdd(db + c, ab);
+  for (int t = 0; t < 9; ++t) { mine[t * 4 + 0] = acc[t].x; mine[t * 4 + 1] = acc[t].y; mine[t * 4 + 2] = acc[t].z; mine[t * 4 + 3] = acc[t].w; }
+  mine[36] = ab.x; mine[37] = ab.y; mine[38] = ab.z; mine[39] = ab.w;
+  __syncthreads();
+  const int F = F4 * 4;
+  for (int o = threadIdx.x; o < DWB_C4 * 40; o += 256) {
+    const int ocl = o / 40, k = o - ocl * 40;
+    const int oc4 = blockIdx.x * DWB_C4 + ocl;
+    if (oc4 >= F4) continue;
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < DWB_XL; ++q) sum += red[(q * DWB_C4 + ocl) * 41 + k];
+    const int comp = k & 3, tap = k >> 2;
+    if (tap < 9) unsafeAtomicAdd(dw9 + (int64_t)tap * F + oc4 * 4 + comp, sum);
+    else unsafeAtomicAdd(db + oc4 * 4 + comp, sum);
+  }
 }
 
 extern "C" int vptr_dwconv3x3_fwd(const float* x, const float* w9, const float* b, float* y, int frames, int H, int W, int F,
                                   vptr_stream_t stream) {
   VPTR_CHECK(frames > 0 && H > 0 && W > 0 && F > 0 && F % 4 == 0, "dwconv3x3_fwd: bad arguments");
-  const int64_t total = (int64_t)frames * H * W * (F / 4);
-  const int blocks = (int)hmin64((total + 255) / 256, 8192);
-  dwconv_fwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(x, w9, b, y, frames, H, W, F / 4, 0);
+  const int64_t total = (int64_t)frames * W * (F / 4);
+  dwconv_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, w9, b, y, frames, H, W, F / 4, 0);
   VPTR_LAUNCH_CHECK();
   return 0;
 }
@@ -650,12 +755,11 @@ extern "C" int vptr_dwconv3x3_bwd(const float* dy, const float* x, const float* 
                                   int frames, int H, int W, int F, vptr_stream_t stream) {
   VPTR_CHECK(frames > 0 && H > 0 && W > 0 && F > 0 && F % 4 == 0, "dwconv3x3_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  const int64_t total = (int64_t)frames * H * W * (F / 4);
-  const int blocks = (int)hmin64((total + 255) / 256, 8192);
-  if (dx) dwconv_fwd_kernel<<<blocks, 256, 0, st>>>(dy, w9, nullptr, dx, frames, H, W, F / 4, 1);
+  const int64_t total = (int64_t)frames * W * (F / 4);
+  if (dx) dwconv_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(dy, w9, nullptr, dx, frames, H, W, F / 4, 1);
   if (dw9 && db) {
-    const int fpb = 1;
-    dwconv_bwd_w_kernel<<<dim3(cdiv(F, 256), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F, fpb);
+    const int fpb = frames >= 64 ? 8 : 1;
+    dwconv_bwd_w_kernel<<<dim3(cdiv(F / 4, DWB_C4), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
   }
   VPTR_LAUNCH_CHECK();
   return 0;

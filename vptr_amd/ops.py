@@ -508,7 +508,8 @@ class _NormActFn(torch.autograd.Function):
         rows, F = x.shape
         dx = torch.empty_like(x)
         dw, db = torch.zeros_like(w), torch.zeros_like(b)
-        scratch = torch.empty((2 * max(F, rows // HW),), device=x.device, dtype=torch.float32)
+        frames = rows // HW
+        scratch = torch.empty((max(2 * F, 2 * frames * (1 + 4 * ((HW * F // 4 + 255) // 256))),), device=x.device, dtype=torch.float32)
         check(lib.vptr_norm_act_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(b), ptr(dx), ptr(dw), ptr(db),
                                     ptr(scratch), rows, F, HW, int(per_col), act, int(const_stats), p,
                                     ptr(ctx.seed), site, ptr(rowscale), rs_div, rs_mod,
