@@ -65,6 +65,32 @@ def test_gemm_dgrad_wgrad_modes(ops, dev, prec, tol):
         assert rel(out, g.double().t() @ Bk.double().t()) < tol
 
 
+def test_gemm_grouped_wgrad_with_bias_rowsum(ops, dev):
+    """vptr_gemm_grouped (deferred weight gradients of a backward pass, no split-K) + the a_rowsum bias-gradient fusion, and
+    the same a_rowsum through the split-K single launch; accumulation into pre-filled destinations."""
+    probs = [(1000, 528, 528), (640, 176, 2112), (512, 1056, 528), (260, 48, 48)]  # tokens, out features, in features
+    keep, refs = [], []
+    for i, (M, N, K) in enumerate(probs):
+        g, x = rn((M, N), 10 + i), rn((M, K), 20 + i)
+        dW0, db0 = rn((N, K), 30 + i), rn((N,), 40 + i)
+        gd, xd, dW, db = g.to(dev), x.to(dev), dW0.to(dev), db0.to(dev)
+        keep.append((gd, xd, dW, db))
+        refs.append((dW0.double() + g.double().t() @ x.double(), db0.double() + g.double().sum(0)))
+        ops.defer_wgrad(gd, xd, dW, N, K, M, db=db)
+    ops.flush_wgrads()
+    for (gd, xd, dW, db), (rW, rb) in zip(keep, refs):
+        assert rel(dW, rW) < TOL3
+        assert rel(db, rb) < TOL3
+    # single launch, split-K + atomics, with the row sums
+    M, N, K = 2048, 528, 352
+    g, x = rn((M, N), 50), rn((M, K), 51)
+    dW, db = torch.zeros((N, K), device=dev), torch.zeros((N,), device=dev)
+    gd, xd = g.to(dev), x.to(dev)
+    d = ops.gemm_raw(gd, xd, dW, N, K, M, 1, 1, atomic=True, split_k=4, a_rowsum=db)
+    assert rel(dW, g.double().t() @ x.double()) < TOL3
+    assert rel(db, g.double().sum(0)) < TOL3
+
+
 def test_gemm_epilogue_variants(ops, dev):
     M, N, K = 200, 176, 64
     x, W = rn((M, K), 9), rn((N, K), 10, K ** -0.5)

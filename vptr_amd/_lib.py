@@ -32,6 +32,7 @@ class GemmDesc(ctypes.Structure):
         ("conv_IH", c_int), ("conv_IW", c_int), ("conv_Cin", c_int), ("conv_OH", c_int), ("conv_OW", c_int),
         ("conv_KH", c_int), ("conv_KW", c_int), ("conv_stride", c_int), ("conv_pad", c_int), ("conv_pad_mode", c_int),
         ("conv_transposed", c_int),
+        ("a_rowsum", c_void_p),
     ]
 
 

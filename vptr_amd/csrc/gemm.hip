@@ -183,6 +183,7 @@ struct StageKS2 {
   static constexpr int LDS_ROWS = GBM;
   float4 r[2];
   int nvalid;
+  float rsum[4] = {0.f, 0.f, 0.f, 0.f};  // running sum over k of this thread's 4 output rows (vptr_gemm_desc::a_rowsum)
   static __device__ __forceinline__ int kb2_of(const int tid) { return (tid & 7) | (((tid >> 6) & 1) << 3); }
   static __device__ __forceinline__ int ob_of(const int tid) { return ((tid >> 3) & 7) | ((tid >> 7) << 3); }
   __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0, int kend, int tid) {
@@ -202,6 +203,7 @@ struct StageKS2 {
       a = __uint_as_float(__float_as_uint(a) & (nvalid > 0 ? ~0u : 0u));
       b = __uint_as_float(__float_as_uint(b) & (nvalid > 1 ? ~0u : 0u));
     }
+    rsum[j] += a + b;
     const int o = lds_off(ob * 4 + j, kb2 >> 1) + ((kb2 & 1) << 1);
     if constexpr (NPASS == 3) {
       uint32_t hi, lo;
@@ -551,6 +553,28 @@ __device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, __bf16* sme
     }
   }
   gemm_epilogue<NFN>(p, acc, m0, n0, wm, wn, lr, lq, first_split, use_atomic);
+  if constexpr (AMODE == VPTR_A_KSTRIDED) {
+    if (p.a_rowsum && n0 == 0) {  // workgroup-uniform: column tile 0 owns the row sums of its A panel
+      // thread (kb2, ob) summed k = kb2*2 + {0,1} (mod 32) of rows ob*4 + j: fold the 8 kb2 lanes, then the wave pair
+      float* sred = reinterpret_cast<float*>(smem);  // the K loop's last barrier has passed: LDS is free
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = stA0.rsum[j] + stA1.rsum[j];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        if ((lane & 7) == 0) sred[(wave * 8 + (lane >> 3)) * 4 + j] = v;
+      }
+      __syncthreads();
+      if (tid < GBM) {
+        const int ob = tid >> 2, j = tid & 3;                  // ob = (wave pair q) * 8 + (lane >> 3)
+        const int q = ob >> 3, lo8 = ob & 7;
+        const float v = sred[((2 * q) * 8 + lo8) * 4 + j] + sred[((2 * q + 1) * 8 + lo8) * 4 + j];
+        // rows of a clamped out block (beyond M - 4) hold duplicates of other rows: only in-range rows are written
+        if (m0 + tid < p.M && m0 + ob * 4 <= p.M - 4) unsafeAtomicAdd(p.a_rowsum + m0 + tid, v);
+      }
+    }
+  }
   TS(5)
   TS_FLUSH
 }
@@ -679,6 +703,7 @@ extern "C" int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream) {
   if (d.dropout_p > 0.f) VPTR_CHECK(d.seed_dev != nullptr && d.dropout_p < 1.f, "vptr_gemm: dropout needs seed_dev and p < 1");
   if (d.rowscale) VPTR_CHECK(d.rs_div >= 1 && d.rs_mod >= 1, "vptr_gemm: rowscale needs rs_div, rs_mod >= 1");
   if (d.alpha == 0.f) d.alpha = 1.f;
+  if (d.a_rowsum) VPTR_CHECK(d.a_mode == VPTR_A_KSTRIDED && g_gemm_variant == 1, "vptr_gemm: a_rowsum needs a k-strided A operand");
 
   // k range per split, multiple of the K tile
   int k_chunk = ((d.K + d.split_k - 1) / d.split_k + GBK - 1) / GBK * GBK;

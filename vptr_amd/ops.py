@@ -83,8 +83,9 @@ def _c(t):
 # ------------------------------------------------------------------------------------------------------------------
 def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None, colscale=None, alpha=1.0, act=ACT_NONE,
              Dpre=None, rowscale=None, rs_div=1, rs_mod=1, dropout_p=0.0, site=0, residual=None, act_after=False,
-             atomic=False, split_k=1, conv=None, precision=None, seed=None):
+             atomic=False, split_k=1, conv=None, precision=None, seed=None, a_rowsum=None):
     d = GemmDesc()
+    d.a_rowsum = ptr(a_rowsum)
     d.A, d.B, d.D, d.Dpre = ptr(A), ptr(B), ptr(D), ptr(Dpre)
     d.lda = lda if lda is not None else (A.stride(0) if a_mode != 2 else 0)
     d.ldb = ldb if ldb is not None else B.stride(0)
@@ -147,12 +148,16 @@ _wgrad_q = []
 _wgrad_cb = [False]
 
 
-def defer_wgrad(g, x, dW, N, K, M):
-    """record dW[N,K] += g[M,N]^T . x[M,K] (dW must be a view of a flat gradient slab)"""
-    _wgrad_q.append((g, x, dW, N, K, M, config.gemm_precision))
+def defer_wgrad(g, x, dW, N, K, M, db=None):
+    """record dW[N,K] += g[M,N]^T . x[M,K] (dW, and db if given, must be views of a flat gradient slab); with db the bias
+    gradient db[N] += column sums of g rides on the same launch (vptr_gemm_desc::a_rowsum)"""
+    _wgrad_q.append((g, x, dW, N, K, M, config.gemm_precision, db))
     if not _wgrad_cb[0]:
-        _wgrad_cb[0] = True
-        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+            _wgrad_cb[0] = True
+        except RuntimeError:  # not inside a backward pass: the caller flushes explicitly
+            pass
 
 
 def flush_wgrads():
@@ -171,9 +176,10 @@ def flush_wgrads():
         starts = []
         total = 0
         flops = 0.0
-        for i, (g, x, dW, N, K, M, _) in enumerate(its):
+        for i, (g, x, dW, N, K, M, _, db) in enumerate(its):
             d = descs[i]
             d.A, d.B, d.D = ptr(g), ptr(x), ptr(dW)
+            d.a_rowsum = ptr(db)
             d.lda, d.ldb, d.ldd = g.stride(0), x.stride(0), dW.stride(0)
             d.M, d.N, d.K = N, K, M
             d.a_mode, d.b_mode, d.precision, d.split_k, d.atomic, d.alpha = 1, 1, prec, 1, 1, 1.0
@@ -276,17 +282,20 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), device=dy.device, dtype=torch.float32)
             gemm_raw(g, W, dx, M, K, N, 0, 1)                      # dx[M,K] = g[M,N] . W[N,K]
+        bias_done = False
         if ctx.needs_input_grad[1]:
             slab = flat_grad_for(W)          # accumulate straight into the flat gradient slab when there is one
             if slab is not None and config.group_wgrads:
-                defer_wgrad(g, x, slab, N, K, M)                   # dW[N,K] += g^T . x, grouped at the end of backward
+                bslab = flat_grad_for(ctx.bias_ref) if (has_b and ctx.needs_input_grad[2]) else None
+                defer_wgrad(g, x, slab, N, K, M, db=bslab)         # dW[N,K] += g^T . x (+ db), grouped at the end of backward
+                bias_done = bslab is not None
             else:
                 dW = slab if slab is not None else torch.zeros((N, K), device=dy.device, dtype=torch.float32)
                 tiles = ((N + 127) // 128) * ((K + 175) // 176)
                 gemm_raw(g, x, dW, N, K, M, 1, 1, atomic=True, split_k=_split_k_for(tiles, M))
                 if slab is not None:
                     dW = None
-        if has_b and ctx.needs_input_grad[2]:
+        if has_b and ctx.needs_input_grad[2] and not bias_done:
             b_t = ctx.bias_ref
             slab = flat_grad_for(b_t)
             db = slab if slab is not None else torch.zeros((N,), device=dy.device, dtype=torch.float32)
