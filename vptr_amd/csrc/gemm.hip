@@ -620,11 +620,24 @@ __global__ __launch_bounds__(GNT, 2) void vptr_gemm_grouped_kernel(const vptr_ge
 }
 
 
-static int g_gemm_variant = 1;  // 1 = software-pipelined (default), 0 = single-image loop (tools/gemm_probe.hip flips this)
+// Main-loop choice.  The pipelined loop keeps one workgroup per CU busy (80 KB LDS, 150-190 VGPRs); the single-image loop
+// fits two workgroups per CU, whose phases interleave on their own.  Measured (tools/gemm_bench.py, M = 10240): with >= 2
+// workgroups per CU in the grid the single-image loop wins (N = 2112: 228 vs 179 TFLOP/s); with ~1 per CU the pipelined
+// one does (N = 528, K = 2112: 237 vs 186).  2 = choose by grid size (default); 0 / 1 force one (tools/gemm_probe.hip).
+static int g_gemm_variant = 2;
+static int v4_min_tiles() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VPTR_GEMM_V4_MIN_TILES");
+    v = e ? atoi(e) : 384;
+  }
+  return v;
+}
 
 template <int NFN, int NPASS, int AM, int BM>
 static int launch_one(const vptr_gemm_desc& d, dim3 grid, int k_chunk, hipStream_t st) {
-  if (g_gemm_variant == 1) {
+  const bool pipelined = g_gemm_variant == 1 || (g_gemm_variant == 2 && ((int)grid.x < v4_min_tiles() || d.a_rowsum != nullptr));
+  if (pipelined) {
     constexpr int NFW = (NFN + 1) / 2, BROWS = 2 * NFW * 16, NPL = (NPASS == 3) ? 2 : 1;
     constexpr int LDS_BYTES = 2 * NPL * (GBM + BROWS) * GLP * (int)sizeof(__bf16);
     static bool attr_set = false;
@@ -703,7 +716,7 @@ extern "C" int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream) {
   if (d.dropout_p > 0.f) VPTR_CHECK(d.seed_dev != nullptr && d.dropout_p < 1.f, "vptr_gemm: dropout needs seed_dev and p < 1");
   if (d.rowscale) VPTR_CHECK(d.rs_div >= 1 && d.rs_mod >= 1, "vptr_gemm: rowscale needs rs_div, rs_mod >= 1");
   if (d.alpha == 0.f) d.alpha = 1.f;
-  if (d.a_rowsum) VPTR_CHECK(d.a_mode == VPTR_A_KSTRIDED && g_gemm_variant == 1, "vptr_gemm: a_rowsum needs a k-strided A operand");
+  if (d.a_rowsum) VPTR_CHECK(d.a_mode == VPTR_A_KSTRIDED && g_gemm_variant != 0, "vptr_gemm: a_rowsum needs a k-strided A operand");
 
   // k range per split, multiple of the K tile
   int k_chunk = ((d.K + d.split_k - 1) / d.split_k + GBK - 1) / GBK * GBK;
