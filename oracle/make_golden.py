@@ -274,6 +274,48 @@ def step_case(ref, name, cfg, feat, HW, N, seed, steps=2):
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
 
 
+def far_step_case(ref, name, cfg, feat, HW, N, seed, steps=2):
+    """single_iter recipe of train_FAR.py:48-101 with the real reference modules (VPTR_Disc = None), dropout 0."""
+    enc = ref.VPTREnc(1, feat_dim=feat, n_downsampling=3, padding_type="reflect").eval()
+    dec = ref.VPTRDec(1, feat_dim=feat, n_downsampling=3, out_layer="Sigmoid", padding_type="reflect").eval()
+    T = build_nar(ref, cfg, seed + 20, far=True)
+    fill.apply_fill(enc, seed)
+    fill.apply_fill(dec, seed + 10)
+    opt = torch.optim.AdamW(T.parameters(), lr=1e-4)
+    mse, gdl = ref.MSELoss(), ref.GDL(alpha=1)
+    st = O.FARStep(dict(enc.state_dict()), dict(dec.state_dict()), dict(T.state_dict()), cfg, out_layer="Sigmoid")
+    recs = []
+    for s in range(steps):
+        past = fill.rand_input((N, cfg["Tp"], 1, HW, HW), seed + 100 + s)
+        fut = fill.rand_input((N, cfg["Tf"], 1, HW, HW), seed + 200 + s)
+        with torch.no_grad():
+            gt_feats = enc(torch.cat([past, fut[:, 0:-1, ...]], dim=1))
+        T.train()
+        T.zero_grad(set_to_none=True)
+        dec.zero_grad(set_to_none=True)
+        pred = dec(T(gt_feats))
+        real = torch.cat([past[:, 1:, ...], fut], dim=1)
+        l_mse, l_gdl = mse(pred, real), gdl(real, pred)
+        loss = l_gdl + l_mse
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(T.parameters(), max_norm=1.0, norm_type=2)
+        opt.step()
+        r = st.step(past, fut)
+        rec = {"T_total": loss.item(), "T_GDL": l_gdl.item(), "T_MSE": l_mse.item(), "grad_norm": float(gn)}
+        for k in rec:
+            assert abs(rec[k] - r[k]) <= 2e-4 * abs(rec[k]) + 1e-7, (k, rec[k], r[k])
+        recs.append(rec)
+    e = max(rel(st.P_T[k], v) for k, v in T.state_dict().items() if v.is_floating_point())
+    print(f"[{name}] {steps} FAR train steps: losses {recs}; post-step params oracle-vs-ref {e:.2e}")
+    assert e < 1e-4
+    save = {"cfg": json.dumps(cfg), "meta": json.dumps(dict(feat=feat, HW=HW, N=N, seed=seed, steps=steps, out_layer="Sigmoid")),
+            "records": json.dumps(recs), "T_template": json.dumps(template_of(T.state_dict()))}
+    for k, v in T.state_dict().items():
+        if v.is_floating_point() and k not in ("temporal_pos", "lw_pos", "Tlw_pos"):
+            save["post:" + k] = v.numpy()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
+
+
 def pos_case(ref, name):
     from utils.position_encoding import PositionEmbeddding1D, PositionEmbeddding2D, PositionEmbeddding3D
     from utils.misc import NestedTensor
@@ -300,25 +342,34 @@ def pos_case(ref, name):
 
 
 def main():
+    """python oracle/make_golden.py [fixture names ...]   (no names: regenerate every fixture)"""
     os.makedirs(GOLD, exist_ok=True)
     ref = import_reference()
     torch.set_num_threads(8)
-    pos_case(ref, "pos_tables")
     tiny = dict(Tp=3, Tf=3, H=8, W=8, C=48, nhead=8, window_size=4, num_encoder_layers=1, num_decoder_layers=1, rpe=True)
-    transformer_case(ref, "nar_tiny", tiny, False, 2, 11)
-    transformer_case(ref, "nar_tiny_norpe", dict(tiny, rpe=False), False, 2, 12)
-    transformer_case(ref, "far_tiny", dict(tiny, Tin=5, num_encoder_layers=2), True, 2, 13)
-    transformer_case(ref, "nar_tiny_pad", dict(tiny, H=6, W=6, Tp=2, Tf=2), False, 1, 14)
-    transformer_case(ref, "nar_tiny_T", dict(tiny, Tp=2, Tf=4, num_decoder_layers=2), False, 1, 15)
-    ae_case(ref, "ae_tiny_reflect", 1, 48, 32, 1, 2, "reflect", "Tanh", 21)
-    ae_case(ref, "ae_tiny_zero", 3, 48, 32, 1, 2, "zero", "Sigmoid", 22)
-    losses_case(ref, "losses_tiny", 31)
-    step_case(ref, "step_tiny", dict(tiny, Tp=2, Tf=2), 48, 64, 2, 41)
     k64 = dict(Tp=10, Tf=10, H=8, W=8, C=528, nhead=8, window_size=4, num_encoder_layers=4, num_decoder_layers=8, rpe=True)
-    transformer_case(ref, "nar_k64_digest", k64, False, 1, 51, full=False, check64=False)
     far = dict(Tp=2, Tf=10, Tin=11, H=8, W=8, C=528, nhead=8, window_size=4, num_encoder_layers=12, rpe=True)
-    transformer_case(ref, "far_bair_digest", far, True, 1, 52, full=False, check64=False)
-    print("all golden fixtures written to", GOLD)
+    far_tiny = dict(Tp=3, Tf=2, H=8, W=8, C=48, nhead=8, window_size=4, num_encoder_layers=2, rpe=False)
+    cases = [
+        ("pos_tables", lambda n: pos_case(ref, n)),
+        ("nar_tiny", lambda n: transformer_case(ref, n, tiny, False, 2, 11)),
+        ("nar_tiny_norpe", lambda n: transformer_case(ref, n, dict(tiny, rpe=False), False, 2, 12)),
+        ("far_tiny", lambda n: transformer_case(ref, n, dict(tiny, Tin=5, num_encoder_layers=2), True, 2, 13)),
+        ("nar_tiny_pad", lambda n: transformer_case(ref, n, dict(tiny, H=6, W=6, Tp=2, Tf=2), False, 1, 14)),
+        ("nar_tiny_T", lambda n: transformer_case(ref, n, dict(tiny, Tp=2, Tf=4, num_decoder_layers=2), False, 1, 15)),
+        ("ae_tiny_reflect", lambda n: ae_case(ref, n, 1, 48, 32, 1, 2, "reflect", "Tanh", 21)),
+        ("ae_tiny_zero", lambda n: ae_case(ref, n, 3, 48, 32, 1, 2, "zero", "Sigmoid", 22)),
+        ("losses_tiny", lambda n: losses_case(ref, n, 31)),
+        ("step_tiny", lambda n: step_case(ref, n, dict(tiny, Tp=2, Tf=2), 48, 64, 2, 41)),
+        ("step_far_tiny", lambda n: far_step_case(ref, n, far_tiny, 48, 64, 2, 61)),
+        ("nar_k64_digest", lambda n: transformer_case(ref, n, k64, False, 1, 51, full=False, check64=False)),
+        ("far_bair_digest", lambda n: transformer_case(ref, n, far, True, 1, 52, full=False, check64=False)),
+    ]
+    only = sys.argv[1:]
+    for name, fn in cases:
+        if not only or name in only:
+            fn(name)
+    print("golden fixtures written to", GOLD, "(" + (", ".join(only) if only else "all") + ")")
 
 
 if __name__ == "__main__":

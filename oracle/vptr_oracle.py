@@ -446,3 +446,46 @@ class NARStep:
         self.opt.step()
         return {"T_total": loss.item(), "T_GDL": l_gdl.item(), "T_MSE": l_mse.item(), "T_bpc": l_pc.item(),
                 "grad_norm": float(gn)}
+
+
+class FARStep:
+    """Functional FAR train step without the GAN branch (train_FAR.py:48-101 with VPTR_Disc = None, its default :186-192):
+    Enc(cat(past, future[:, :-1])) under no_grad, FAR (causal), Dec, MSE + GDL against cat(past[:, 1:], future), backward,
+    clip_grad_norm_(1.0) on the transformer params, AdamW(1e-4)."""
+
+    def __init__(self, P_enc, P_dec, P_T, cfg, padding_type="reflect", out_layer="Tanh", lr=1e-4, max_grad_norm=1.0):
+        self.cfg, self.padding_type, self.out_layer = cfg, padding_type, out_layer
+        self.P_enc = {k: v.detach().clone() for k, v in P_enc.items()}
+        self.P_dec = {k: v.detach().clone() for k, v in P_dec.items()}
+        self.P_T = {k: v.detach().clone() for k, v in P_T.items()}
+        isbuf = NARStep._is_buffer
+        for d in (self.P_T, self.P_dec):  # the reference leaves Dec params trainable here too (train_FAR.py:181-182)
+            for k, v in d.items():
+                if v.is_floating_point() and not isbuf(self, k):
+                    v.requires_grad_(True)
+        self.params_T = [v for v in self.P_T.values() if v.requires_grad]
+        self.opt = torch.optim.AdamW(self.params_T, lr=lr)
+        self.max_grad_norm = max_grad_norm
+
+    def forward_losses(self, past, future):
+        x = torch.cat([past, future[:, :-1]], dim=1)                     # train_FAR.py:54
+        with torch.no_grad():
+            gt_feats = enc_forward(self.P_enc, x, padding_type=self.padding_type)
+        pred_feats = far_forward(self.P_T, gt_feats, self.cfg, training=True)
+        pred_frames = dec_forward(self.P_dec, pred_feats, out_layer=self.out_layer)
+        target = torch.cat([past[:, 1:], future], dim=1)                 # :80
+        l_mse = mse_loss(pred_frames, target)                            # cal_lossT :32-46
+        l_gdl = gdl_loss(target, pred_frames)
+        return l_gdl + l_mse, l_gdl, l_mse, pred_frames
+
+    def step(self, past, future):
+        for p in self.params_T:
+            p.grad = None
+        for v in self.P_dec.values():
+            if v.requires_grad:
+                v.grad = None
+        loss, l_gdl, l_mse, _ = self.forward_losses(past, future)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(self.params_T, self.max_grad_norm)
+        self.opt.step()
+        return {"T_total": loss.item(), "T_GDL": l_gdl.item(), "T_MSE": l_mse.item(), "grad_norm": float(gn)}

@@ -37,3 +37,24 @@ def grad_floor(norms):
     """Gradients that are analytically zero (biases in front of a train-mode BatchNorm, the k-bias of a softmax) are pure
     round-off; errors are measured against ||ref|| + 1e-2 * median gradient norm (same rule as oracle/make_golden.py)."""
     return 1e-2 * float(np.median(list(norms)))
+
+
+def post_step_params_close(state_dict, z, rel_tol=1e-4, lr=1e-4, max_flip_frac=0.02):
+    """Post-step parameters vs the `post:` arrays of a golden step record.  The first AdamW updates are ~lr * sign(g), so
+    elements whose gradient is analytically zero move by +-lr on rounding noise alone (and atomics make that noise
+    run-dependent): compare the concatenated parameters globally and bound the share of updates that differ by > lr/2."""
+    num = den = 0.0
+    bad = tot = 0
+    for k in z.files:
+        if not k.startswith("post:"):
+            continue
+        r = torch.from_numpy(z[k]).double()
+        d = state_dict[k[5:]].detach().cpu().double() - r
+        num += float((d * d).sum())
+        den += float((r * r).sum())
+        bad += int((d.abs() > 0.5 * lr).sum())
+        tot += d.numel()
+    relerr = (num / den) ** 0.5
+    assert relerr < rel_tol, relerr
+    assert bad <= max_flip_frac * tot, (bad, tot)
+    return relerr

@@ -214,3 +214,120 @@ def test_losses_cpu_match_oracle():
     assert abs(l.item() - float(z["loss"])) < 1e-6 * abs(float(z["loss"]))
     w = pkg.temporal_weight_func(10)
     assert abs(float(w[-1]) - 10.0) < 1e-4 and float(w[0]) == 1.0
+
+
+# ------------------------------------------------------------------------------------------- checkpoints (section 8f rank 1)
+def _tiny_modules():
+    import vptr_amd.model as M
+    T = M.VPTRFormerNAR(2, 2, 8, 8, 48, 8, 1, 1, 0.0, 4, 4, False, True)
+    enc = M.VPTREnc(1, 48, 3, "reflect")
+    return enc, T
+
+
+def test_checkpoint_roundtrip_and_ddp_prefix(tmp_path):
+    from vptr_amd import checkpoint as C
+    enc, T = _tiny_modules()
+    fill.apply_fill(enc, 1)
+    fill.apply_fill(T, 2)
+    opt = torch.optim.AdamW(T.parameters(), lr=1e-4)
+    for p in T.parameters():
+        p.grad = torch.full_like(p, 1e-3)
+    opt.step()
+    loss_dict = C.init_loss_dict(["T_MSE", "T_total"])
+    loss_dict["T_MSE"].train.append(0.5)
+    loss_dict["epochs"] = 1
+    f = C.save_ckpt({"VPTR_Enc": enc, "VPTR_Transformer": T}, {"optimizer_T": opt}, 7, loss_dict, tmp_path)
+    assert f.name == "epoch_7.tar"
+    raw = open(f, "rb").read() if not __import__("zipfile").is_zipfile(f) else b"".join(
+        __import__("zipfile").ZipFile(f).read(n) for n in __import__("zipfile").ZipFile(f).namelist() if n.endswith("data.pkl"))
+    assert b"utils.train_summary" in raw and b"Loss_tuple" in raw and b"vptr_amd" not in raw  # loadable by the reference
+    msd, osd, epoch, ld, code = C.load_ckpt(f)
+    assert epoch == 7 and ld["T_MSE"].train == [0.5] and isinstance(ld["T_total"], C.LossTuple) and code == {}
+    enc2, T2 = _tiny_modules()
+    opt2 = torch.optim.AdamW(T2.parameters(), lr=3e-4)
+    ld2, start = C.resume_training({"VPTR_Enc": enc2, "VPTR_Transformer": T2}, {"optimizer_T": opt2}, f, ["T_MSE", "T_total", "T_new"])
+    assert start == 7 and ld2["T_new"].train == [0]
+    for (k, a), (_, b) in zip(T.state_dict().items(), T2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert opt2.state_dict()["param_groups"][0]["lr"] == 1e-4
+    # a checkpoint written under DistributedDataParallel: every key prefixed with `module.` (train_summary.py:16-21)
+    ddp_sd = {"module." + k: v for k, v in T.state_dict().items()}
+    torch.save({"epoch": 3, "loss_dict": {"epochs": 0}, "Module_state_dict": {"VPTR_Transformer": ddp_sd},
+                "optimizer_state_dict": {}, "code": {}}, tmp_path / "ddp.tar")
+    _, T3 = _tiny_modules()
+    start, hist = C.resume_training({"VPTR_Transformer": T3}, {}, tmp_path / "ddp.tar", None, map_location="cpu")
+    assert start == 3 and torch.equal(T3.state_dict()["frame_queries"], T.state_dict()["frame_queries"])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference checkout (build container only)")
+def test_checkpoint_interop_with_reference(tmp_path):
+    """a checkpoint written by the REFERENCE's save_ckpt loads here, and one written here loads through its load_ckpt"""
+    from oracle.ref_import import import_reference
+    from vptr_amd import checkpoint as C
+    ref = import_reference()
+    import utils.train_summary as RS  # the reference's own module
+    Tr = ref.VPTRFormerNAR(2, 2, 8, 8, 48, 8, 1, 1, 0.0, 4, 4, False, True)
+    fill.apply_fill(Tr, 5)
+    optr = torch.optim.AdamW(Tr.parameters(), lr=1e-4)
+    ld = RS.init_loss_dict(["T_MSE"])
+    ld["T_MSE"].val.append(0.25)
+    RS.save_ckpt({"VPTR_Transformer": Tr}, {"optimizer_T": optr}, 2, ld, tmp_path / "ref")
+    _, T = _tiny_modules()
+    loss_dict, start = C.resume_training({"VPTR_Transformer": T}, {}, tmp_path / "ref" / "epoch_2.tar", ["T_MSE"])
+    assert start == 2 and loss_dict["T_MSE"].val == [0.25]
+    for (k, a), (k2, b) in zip(Tr.state_dict().items(), T.state_dict().items()):
+        assert k == k2 and torch.equal(a, b), k
+    f = C.save_ckpt({"VPTR_Transformer": T}, {}, 4, loss_dict, tmp_path / "ours")
+    # what the reference's load_ckpt does (train_summary.py:150-160); torch >= 2.6 needs weights_only=False for its pickled class
+    ck = torch.load(f, map_location=None, weights_only=False)
+    assert ck["epoch"] == 4 and isinstance(ck["loss_dict"]["T_MSE"], RS.Loss_tuple) and ck["loss_dict"]["T_MSE"].val == [0.25]
+    Tr.load_state_dict(ck["Module_state_dict"]["VPTR_Transformer"])
+
+
+def test_flat_adamw_state_dict_is_torch_adamw_compatible():
+    from vptr_amd.train import FlatAdamW
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(8, 5), torch.nn.Linear(5, 3))
+    ref_opt = torch.optim.AdamW(lin.parameters(), lr=2e-4, weight_decay=0.02)
+    for _ in range(3):
+        for p in lin.parameters():
+            p.grad = torch.randn_like(p)
+        ref_opt.step()
+    sd = ref_opt.state_dict()
+    lin2 = torch.nn.Sequential(torch.nn.Linear(8, 5), torch.nn.Linear(5, 3))
+    fo = FlatAdamW(lin2.parameters(), lr=1e-4)
+    fo.load_state_dict(sd)
+    assert fo.lr == 2e-4 and fo.weight_decay == 0.02 and float(fo.step_dev) == 3.0
+    off = 0
+    for i, p in enumerate(lin.parameters()):
+        n = p.numel()
+        assert torch.equal(fo.m[off:off + n].view(p.shape), sd["state"][i]["exp_avg"])
+        assert torch.equal(fo.v[off:off + n].view(p.shape), sd["state"][i]["exp_avg_sq"])
+        off += n
+    back = torch.optim.AdamW(lin2.parameters(), lr=1.0)
+    back.load_state_dict(fo.state_dict())
+    b = back.state_dict()
+    assert b["param_groups"][0]["lr"] == 2e-4
+    for i in sd["state"]:
+        assert torch.equal(b["state"][i]["exp_avg_sq"], sd["state"][i]["exp_avg_sq"]) and float(b["state"][i]["step"]) == 3.0
+
+
+def test_oracle_far_train_step_golden():
+    z = load("step_far_tiny")
+    cfg, meta = jload(z, "cfg"), jload(z, "meta")
+    import vptr_amd.model as M
+    enc = M.VPTREnc(1, meta["feat"], 3, "reflect")
+    dec = M.VPTRDec(1, meta["feat"], 3, meta["out_layer"], "reflect")
+    T = build_transformer(M, cfg, True)
+    fill.apply_fill(enc, meta["seed"])
+    fill.apply_fill(dec, meta["seed"] + 10)
+    fill.apply_fill(T, meta["seed"] + 20)
+    st = O.FARStep(dict(enc.state_dict()), dict(dec.state_dict()), dict(T.state_dict()), cfg, out_layer=meta["out_layer"])
+    for s, ref in enumerate(jload(z, "records")):
+        past = fill.rand_input((meta["N"], cfg["Tp"], 1, meta["HW"], meta["HW"]), meta["seed"] + 100 + s)
+        fut = fill.rand_input((meta["N"], cfg["Tf"], 1, meta["HW"], meta["HW"]), meta["seed"] + 200 + s)
+        r = st.step(past, fut)
+        for k in ref:
+            assert abs(r[k] - ref[k]) <= 2e-4 * abs(ref[k]) + 1e-7, (k, r[k], ref[k])
+    worst = max(rel(st.P_T[k[5:]], z[k]) for k in z.files if k.startswith("post:"))
+    assert worst < 1e-4

@@ -515,7 +515,9 @@ __device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, __bf16* sme
 #pragma unroll
       for (int u = (ni * UT) / NFW; u < ((ni + 1) * UT) / NFW; ++u) {
         if (u < UA) cvA.template store_unit<NPASS>(nA, nA + (NPL - 1) * A_EL, tid, u);
+#ifndef VPTR_EXP_NOCVT_B
         else cvB.template store_unit<NPASS>(nB, nB + (NPL - 1) * B_EL, tid, u - UA);
+#endif
       }
 #endif
     }

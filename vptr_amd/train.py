@@ -46,6 +46,45 @@ class FlatAdamW:
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
         ops.register_flat_slab(self.flat, self.grad)  # backward kernels accumulate weight gradients in place
 
+    # -- torch.optim.AdamW-compatible state (checkpoints of the reference carry `optimizer_T.state_dict()`) ------------------
+    def state_dict(self):
+        state, off = {}, 0
+        step = self.step_dev.detach().clone().reshape(())
+        for i, p in enumerate(self.params):
+            n = p.numel()
+            state[i] = {"step": step.clone(), "exp_avg": self.m[off:off + n].view(p.shape).clone(),
+                        "exp_avg_sq": self.v[off:off + n].view(p.shape).clone()}
+            off += n
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        ids = [i for g in groups for i in g["params"]]
+        if len(ids) != len(self.params):
+            raise ValueError("FlatAdamW.load_state_dict: %d parameters in the checkpoint, %d here" % (len(ids), len(self.params)))
+        g0 = groups[0]
+        self.lr, self.betas, self.eps, self.weight_decay = g0["lr"], tuple(g0["betas"]), g0["eps"], g0["weight_decay"]
+        off, step = 0, None
+        with torch.no_grad():
+            for pid, p in zip(ids, self.params):
+                n = p.numel()
+                st = sd["state"].get(pid)
+                if st is None:  # parameter never stepped
+                    self.m[off:off + n].zero_()
+                    self.v[off:off + n].zero_()
+                else:
+                    self.m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                    self.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    s_i = float(st["step"])
+                    if step is not None and s_i != step:
+                        raise ValueError("FlatAdamW.load_state_dict: per-parameter step counts differ (%g vs %g)" % (s_i, step))
+                    step = s_i
+                off += n
+            self.step_dev.fill_(0.0 if step is None else step)
+
     def zero_grad(self):
         p0 = self.params[0]
         if p0.grad is None or p0.grad.data_ptr() != self.grad.data_ptr():
@@ -164,3 +203,50 @@ class NARTrainer:
         """Inference: Enc -> NAR -> Dec (Test_VPTR.ipynb cell 5, one NAR round)."""
         self.T.eval()
         return self.dec(self.T(self.enc(past)))
+
+
+class FARTrainer(NARTrainer):
+    """One FAR training step without the GAN branch (`single_iter` of train_FAR.py:48-101 with VPTR_Disc = None, the
+    script's default :186-192): Enc(cat(past, future[:, :-1])) under no_grad, VPTRFormerFAR (causal temporal attention as a
+    kernel flag), Dec, MSE + GDL against cat(past[:, 1:], future), backward, clip_grad_norm_(max_norm), AdamW.  Shares the
+    flat-slab optimizer, grouped weight gradients and data-parallel exchange with `NARTrainer`."""
+
+    def __init__(self, enc, dec, transformer, lr=1e-4, max_grad_norm=1.0, process_group=None, bucket_mb=64, dec_weight_grads=True):
+        self.enc, self.dec, self.T = enc.eval(), dec.eval(), transformer
+        for p in enc.parameters():
+            p.requires_grad_(False)
+        for p in dec.parameters():
+            p.requires_grad_(bool(dec_weight_grads))  # train_FAR.py:181-182 leaves the decoder trainable (never stepped)
+        self.dec_weight_grads = bool(dec_weight_grads)
+        for mod in list(self.enc.modules()) + list(self.dec.modules()):
+            mod._vptr_frozen = True
+        self.opt = FlatAdamW(self.T.parameters(), lr=lr, max_grad_norm=max_grad_norm)
+        self.mse, self.gdl = MSELoss(), GDL(alpha=1)
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.bucket_elems = bucket_mb * (1 << 20) // 4
+        self._graph = None
+
+    def _step_impl(self, past, future):
+        with torch.no_grad():
+            gt_feats = self.enc(torch.cat([past, future[:, :-1]], dim=1))    # train_FAR.py:53-55
+        self.T.train()
+        self.opt.zero_grad()
+        if self.dec_weight_grads:
+            self.dec.zero_grad(set_to_none=True)
+        pred_frames = self.dec(self.T(gt_feats))
+        real = torch.cat([past[:, 1:], future], dim=1)                       # :80
+        l_mse = self.mse(pred_frames, real)                                  # cal_lossT :32-46
+        l_gdl = self.gdl(real, pred_frames)
+        loss = l_gdl + l_mse
+        loss.backward()
+        ops.flush_wgrads()
+        self._allreduce_grads()
+        self.opt.step()
+        return {"T_total": loss.detach(), "T_GDL": l_gdl.detach(), "T_MSE": l_mse.detach(), "grad_norm": self.opt.grad_norm()}
+
+    @torch.no_grad()
+    def predict(self, past, num_pred):
+        """Autoregressive test-phase rollout (train_FAR.py:103-125): see vptr_amd.inference.far_rollout."""
+        from .inference import far_rollout
+        return far_rollout(self.enc, self.dec, self.T, past, num_pred)
