@@ -197,6 +197,12 @@ int vptr_dropout(const float* x, float* y, int64_t n, float dropout_p, const uin
 /* dx[m,n] = dy[m,n] * rowscale[(m / div) % mod] */
 int vptr_rowscale(const float* dy, const float* rowscale, float* dx, int rows, int C, int div, int mod, vptr_stream_t stream);
 
+/* Token grids [frames, H, W, C]: dst[f, hd, wd, :] = src[f, hd - off_h, wd - off_w, :] inside the source grid, 0 outside.
+ * off > 0: centre padding of PadBlock.pad_if_needed (VidHRFormer_modules.py:546-557) before the window partition when
+ * H or W is not a multiple of the window; off < 0: the crop of depad_if_needed (:559-569).  C % 4 == 0. */
+int vptr_window_copy(const float* src, float* dst, int frames, int Hs, int Ws, int Hd, int Wd, int off_h, int off_w, int C,
+                     vptr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Direct convolutions of the auto-encoder ends (ResNetAutoEncoder.py:26-29 and :89-96).
  * ---------------------------------------------------------------------------------------------- */

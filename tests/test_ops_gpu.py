@@ -375,3 +375,18 @@ def test_adamw_clip(ops, dev):
         check(lib.vptr_adamw(ptr(pd), ptr(gd), ptr(m), ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 1e-2, ptr(step), ptr(ss), 1.0, 1.0,
                              stream()), "adamw")
     assert rel(pd, pr) < 1e-6
+
+
+def test_window_copy_pad_and_crop(ops, dev):
+    frames, H, W, C, ws = 3, 6, 5, 8, 4
+    x = rn((frames * H * W, C), 90).to(dev).requires_grad_(True)
+    y, Hp, Wp = ops.pad_tokens(x, frames, H, W, ws)
+    assert (Hp, Wp) == (8, 8)
+    ref = F.pad(x.detach().cpu().view(frames, H, W, C), (0, 0, (Wp - W) // 2, Wp - W - (Wp - W) // 2, (Hp - H) // 2, Hp - H - (Hp - H) // 2))
+    assert torch.equal(y.detach().cpu().view(frames, Hp, Wp, C), ref)
+    z = ops.crop_tokens(y, frames, Hp, Wp, H, W)
+    assert torch.equal(z.detach().cpu(), x.detach().cpu())
+    g = rn((frames * Hp * Wp, C), 91).to(dev)
+    y.backward(g)
+    gref = g.cpu().view(frames, Hp, Wp, C)[:, (Hp - H) // 2:(Hp - H) // 2 + H, (Wp - W) // 2:(Wp - W) // 2 + W].reshape(-1, C)
+    assert torch.equal(x.grad.cpu(), gref)

@@ -46,6 +46,7 @@ SIGNATURES = {
     "vptr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, I, P],
     "vptr_rowmod_sum": [P, P, I, I, I, I, P],
     "vptr_colsum": [P, P, I, I, P],
+    "vptr_window_copy": [P, P, I, I, I, I, I, I, I, I, P],
     "vptr_add_rowtab": [P, P, P, I, I, I, I, P],
     "vptr_winattn_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, P],
     "vptr_winattn_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, P],

@@ -109,6 +109,34 @@ extern "C" int vptr_dropout(const float* x, float* y, int64_t n, float dropout_p
   return 0;
 }
 
+// dst[f, hd, wd, :] = src[f, hd - off_h, wd - off_w, :] when that lies inside the source grid, else 0: with positive
+// offsets the centre padding of PadBlock.pad_if_needed (VidHRFormer_modules.py:546-557), with negative ones its crop
+// (depad_if_needed :559-569); each is the other's gradient.
+__global__ __launch_bounds__(256) void window_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int frames,
+                                                          int Hs, int Ws, int Hd, int Wd, int off_h, int off_w, int C4) {
+  const int64_t total = (int64_t)frames * Hd * Wd * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    const int64_t pix = i / C4;
+    const int wd = (int)(pix % Wd), hd = (int)((pix / Wd) % Hd);
+    const int64_t f = pix / ((int64_t)Wd * Hd);
+    const int hs = hd - off_h, ws = wd - off_w;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hs >= 0 && hs < Hs && ws >= 0 && ws < Ws) v = src[((f * Hs + hs) * Ws + ws) * C4 + c];
+    dst[i] = v;
+  }
+}
+extern "C" int vptr_window_copy(const float* src, float* dst, int frames, int Hs, int Ws, int Hd, int Wd, int off_h, int off_w, int C,
+                                vptr_stream_t stream) {
+  VPTR_CHECK(src && dst && frames > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && C > 0 && C % 4 == 0, "window_copy: bad arguments");
+  const int64_t total = (int64_t)frames * Hd * Wd * (C / 4);
+  const int blocks = (int)hmin64((total + 255) / 256, 8192);
+  window_copy_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst),
+                                                              frames, Hs, Ws, Hd, Wd, off_h, off_w, C / 4);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ dy, const float* __restrict__ rs,
                                                        float* __restrict__ dx, int rows, int C, int div, int mod) {
   const int64_t total = (int64_t)rows * C;

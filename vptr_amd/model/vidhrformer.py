@@ -86,26 +86,31 @@ class SpatialLocalMultiheadAttention(nn.Module):
 
     def forward_tokens(self, xqk, xv, residual, g, lw_pos, site, rowscale=None, rs_div=1, rs_mod=1):
         C, nh, ws = self.dim, self.num_heads, self.window_size
-        if g.H % ws or g.W % ws:
-            raise NotImplementedError("window attention on the HIP path needs H and W to be multiples of window_size "
-                                      "(got %dx%d, ws %d); the centre-pad variant is not on the measured path" % (g.H, g.W, ws))
         p = self.dropout if self.training else 0.0
         scale = float(C // nh) ** -0.5
         a = self.attn
+        frames, H, W = g.N * g.T, g.H, g.W
+        padded = bool(H % ws or W % ws)
+        if padded:  # PadBlock: zero centre padding BEFORE the positional add and the projections (VidHRFormer_modules.py:332-346)
+            same = xv is xqk
+            xqk, H, W = ops.pad_tokens(xqk, frames, g.H, g.W, ws)
+            xv = xqk if same else ops.pad_tokens(xv, frames, g.H, g.W, ws)[0]
         if self.rpe:
             Wq, Wk, Wv = a.q_proj.weight, a.k_proj.weight, a.v_proj.weight
             bq, bk, bv = a.q_proj.bias, a.k_proj.bias, a.v_proj.bias
             xin = xqk
             table, index = a.relative_position_bias_table, a.relative_position_index
         else:
-            xin = ops.add_rowtab(xqk, self._window_pos_table(lw_pos, g.H, g.W), 1, g.H * g.W)
+            xin = ops.add_rowtab(xqk, self._window_pos_table(lw_pos, H, W), 1, H * W)
             Wq, Wk, Wv = a.in_proj_weight[:C], a.in_proj_weight[C:2 * C], a.in_proj_weight[2 * C:]
             bq, bk, bv = a.in_proj_bias[:C], a.in_proj_bias[C:2 * C], a.in_proj_bias[2 * C:]
             table, index = None, None
         q = ops.linear(xin, Wq, bq, alpha=scale)
         k = ops.linear(xin, Wk, bk)
         v = ops.linear(xv, Wv, bv)
-        o = ops.window_attention(q, k, v, table, index, g.N * g.T, g.H, g.W, nh, ws, p, site)
+        o = ops.window_attention(q, k, v, table, index, frames, H, W, nh, ws, p, site)
+        if padded:  # the out-projection is per token, so cropping first is equivalent to depad_if_needed after it (:347-351)
+            o = ops.crop_tokens(o, frames, H, W, g.H, g.W)
         return ops.linear(o, a.out_proj.weight, a.out_proj.bias, residual=residual, rowscale=rowscale, rs_div=rs_div,
                           rs_mod=rs_mod)
 

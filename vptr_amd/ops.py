@@ -567,6 +567,40 @@ def dwconv3x3(x, weight, bias, frames, H, W):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# centre padding / cropping of token grids (PadBlock, VidHRFormer_modules.py:538-569)
+# ------------------------------------------------------------------------------------------------------------------
+class _WindowCopyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, frames, Hs, Ws, Hd, Wd, off_h, off_w):
+        x = _c(x)
+        C = x.shape[1]
+        y = torch.empty((frames * Hd * Wd, C), device=x.device, dtype=torch.float32)
+        check(lib.vptr_window_copy(ptr(x), ptr(y), frames, Hs, Ws, Hd, Wd, off_h, off_w, C, stream()), "vptr_window_copy")
+        ctx.cfg = (frames, Hs, Ws, Hd, Wd, off_h, off_w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        frames, Hs, Ws, Hd, Wd, off_h, off_w = ctx.cfg
+        dy = _c(dy)
+        C = dy.shape[1]
+        dx = torch.empty((frames * Hs * Ws, C), device=dy.device, dtype=torch.float32)
+        check(lib.vptr_window_copy(ptr(dy), ptr(dx), frames, Hd, Wd, Hs, Ws, -off_h, -off_w, C, stream()), "vptr_window_copy")
+        return dx, None, None, None, None, None, None, None
+
+
+def pad_tokens(x, frames, H, W, ws):
+    """[frames*H*W, C] -> ([frames*Hp*Wp, C], Hp, Wp): zero centre padding up to multiples of the window size"""
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    return _WindowCopyFn.apply(x, frames, H, W, Hp, Wp, (Hp - H) // 2, (Wp - W) // 2), Hp, Wp
+
+
+def crop_tokens(x, frames, Hp, Wp, H, W):
+    """inverse selection of pad_tokens"""
+    return _WindowCopyFn.apply(x, frames, Hp, Wp, H, W, -((Hp - H) // 2), -((Wp - W) // 2))
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # layout
 # ------------------------------------------------------------------------------------------------------------------
 class _ToTokensFn(torch.autograd.Function):
