@@ -151,8 +151,13 @@ class NARTrainer:
 
     def _step_impl(self, past, future):
         with torch.no_grad():
-            past_feats = self.enc(past)
-            future_feats = self.enc(future)
+            # train_NAR.py:54-56 encodes past and future in two calls; the encoder is per-frame (eval-mode BN), so one call on
+            # the concatenated clip gives the same features with twice the rows per conv GEMM (480 instead of 240 tiles)
+            if past.shape[0] == future.shape[0] and past.shape[2:] == future.shape[2:]:
+                feats = self.enc(torch.cat([past, future], dim=1))
+                past_feats, future_feats = feats[:, :past.shape[1]], feats[:, past.shape[1]:]
+            else:
+                past_feats, future_feats = self.enc(past), self.enc(future)
         self.T.train()
         self.opt.zero_grad()
         if self.dec_weight_grads:
