@@ -47,7 +47,7 @@ const char* vptr_last_error(void);
  * ---------------------------------------------------------------------------------------------- */
 enum { VPTR_A_KCONTIG = 0, VPTR_A_KSTRIDED = 1, VPTR_A_CONV = 2 };
 enum { VPTR_B_KCONTIG = 0, VPTR_B_KSTRIDED = 1 };
-enum { VPTR_ACT_NONE = 0, VPTR_ACT_GELU = 1, VPTR_ACT_RELU = 2 };
+enum { VPTR_ACT_NONE = 0, VPTR_ACT_GELU = 1, VPTR_ACT_RELU = 2, VPTR_ACT_LRELU = 3 /* LeakyReLU(0.2), VPTR_modules.py:70 */ };
 enum { VPTR_PAD_ZERO = 0, VPTR_PAD_REFLECT = 1, VPTR_PAD_REPLICATE = 2 };
 
 typedef struct vptr_gemm_desc {
@@ -207,7 +207,8 @@ int vptr_window_copy(const float* src, float* dst, int frames, int Hs, int Ws, i
  * Direct convolutions of the auto-encoder ends (ResNetAutoEncoder.py:26-29 and :89-96).
  * ---------------------------------------------------------------------------------------------- */
 /* first layer: ReflectionPad2d(3) + Conv7x7(Cimg -> Cout) + folded BN + ReLU; x NCHW [B,Cimg,H,W] -> y NHWC [B,H,W,Cout];
- * w is the PyTorch weight [Cout, Cimg, 7, 7]. */
+ * w is the PyTorch weight [Cout, Cimg, 7, 7].  scale == NULL: the raw convolution output (train-mode BatchNorm follows
+ * as its own statistics + normalise passes, stage-1 training train_AutoEncoder.py:44-86). */
 int vptr_conv7_in_fwd(const float* x, const float* w, const float* scale, const float* shift, float* y, int B, int Cimg,
                       int H, int W, int Cout, vptr_stream_t stream);
 /* last layer: ReflectionPad2d(3) + Conv7x7(Cin -> Cimg) + bias + Tanh(1)/Sigmoid(2); x NHWC -> y NCHW; w [Cimg,Cin,7,7] */
@@ -225,10 +226,19 @@ int vptr_bnrelu_bwd(const float* dy, const float* y, const float* scale, float* 
  * db[c] += sum_{y>0} dy;  dw[c] += sum_{y>0} dy * (y - b[c]) / w[c]   (ResNetAutoEncoder.py:79-80 in stage 2) */
 int vptr_bnrelu_bwd_params(const float* dy, const float* y, const float* w, const float* b, float* dw, float* db, int64_t rows,
                            int C, vptr_stream_t stream);
-/* zero-padded im2col on NHWC: out[(b,oy,ox)][(ky,kx,c)] = x[b, oy*stride-pad+ky, ox*stride-pad+kx, c]; the patch matrix
- * is the k-strided operand of the ConvTranspose2d weight-gradient GEMM (ResNetAutoEncoder.py:74-88 autograd). */
+/* im2col on NHWC: out[(b,oy,ox)][(ky,kx,c)] = x[b, oy*stride-pad+ky, ox*stride-pad+kx, c] (pad_mode: VPTR_PAD_ZERO or
+ * VPTR_PAD_REFLECT for out-of-range taps); the patch matrix is the k-strided operand of the convolution weight-gradient
+ * GEMMs (autograd of ResNetAutoEncoder.py:33-48,74-88,138,151 and of the PatchGAN convs VPTR_modules.py:70-91). */
 int vptr_im2col_nhwc(const float* x, float* out, int B, int IH, int IW, int C, int OH, int OW, int KH, int KW, int stride,
-                     int pad, vptr_stream_t stream);
+                     int pad, int pad_mode, vptr_stream_t stream);
+/* adjoint of reflection padding: dxpad [B, H+2p, W+2p, C] (gradient w.r.t. the padded image, e.g. from the gather-form
+ * transposed convolution with pad 0) -> dx [B, H, W, C], each border contribution folded back onto the pixel it mirrors
+ * (nn.ReflectionPad2d of ResnetBlock, ResNetAutoEncoder.py:127-151). */
+int vptr_reflect_fold(const float* dxpad, float* dx, int B, int H, int W, int C, int pad, vptr_stream_t stream);
+/* weight gradient of the first layer: dw[Cout=64, Cimg, 7, 7] += sum_pix dy[pix, co] * xpad[pix + tap, ci];
+ * dy NHWC [B,H,W,64] (gradient of the RAW convolution output), x NCHW [B,Cimg,H,W] (ResNetAutoEncoder.py:26-27 autograd) */
+int vptr_conv7_in_bwd_weight(const float* dy, const float* x, float* dw, int B, int Cimg, int H, int W, int Cout,
+                             vptr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer: global-norm clip + AdamW on flat fp32 buffers (train_NAR.py:85-86,205).

@@ -316,6 +316,61 @@ def far_step_case(ref, name, cfg, feat, HW, N, seed, steps=2):
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
 
 
+def ae_step_case(ref, name, cimg, feat, HW, N, T, seed, steps=2, lam_gan=0.01):
+    """single_iter recipe of train_AutoEncoder.py:44-78 with the real reference modules (train-mode BN, PatchGAN, Adam)."""
+    enc = ref.VPTREnc(cimg, feat_dim=feat, n_downsampling=3, padding_type="reflect")
+    dec = ref.VPTRDec(cimg, feat_dim=feat, n_downsampling=3, out_layer="Tanh", padding_type="reflect")
+    disc = ref.VPTRDisc(cimg, ndf=64, n_layers=3, norm_layer=torch.nn.BatchNorm2d)
+    fill.apply_fill(enc, seed)
+    fill.apply_fill(dec, seed + 10)
+    fill.apply_fill(disc, seed + 20)
+    st = O.AEStep(dict(enc.state_dict()), dict(dec.state_dict()), dict(disc.state_dict()), lam_gan=lam_gan)
+    opt_G = torch.optim.Adam(list(enc.parameters()) + list(dec.parameters()), lr=2e-4, betas=(0.5, 0.999))
+    opt_D = torch.optim.Adam(disc.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    gan, mse, gdl = ref.GANLoss("vanilla", target_real_label=1.0, target_fake_label=0.0), ref.MSELoss(), ref.GDL(alpha=1)
+    recs = []
+    for s in range(steps):
+        past = (fill.rand_input((N, T, cimg, HW, HW), seed + 100 + s) - 0.6013795) / 2.7570653
+        fut = (fill.rand_input((N, T, cimg, HW, HW), seed + 200 + s) - 0.6013795) / 2.7570653
+        x = torch.cat([past, fut], dim=1)
+        enc.train(); enc.zero_grad(); dec.train(); dec.zero_grad()
+        rec = dec(enc(x))
+        disc.train()
+        for p in disc.parameters():
+            p.requires_grad_(True)
+        disc.zero_grad(set_to_none=True)
+        l_fake = gan(disc(rec.detach().flatten(0, 1)), False)
+        l_real = gan(disc(x.flatten(0, 1)), True)
+        loss_D = (l_fake + l_real) * 0.5 * lam_gan
+        loss_D.backward()
+        opt_D.step()
+        for p in disc.parameters():
+            p.requires_grad_(False)
+        l_gan = gan(disc(rec.flatten(0, 1)), True)
+        l_mse, l_gdl = mse(rec, x), gdl(x, rec)
+        loss_G = lam_gan * l_gan + l_mse + l_gdl
+        loss_G.backward()
+        opt_G.step()
+        rec_ = {"AEgan": l_gan.item(), "AE_MSE": l_mse.item(), "AE_GDL": l_gdl.item(), "AE_total": loss_G.item(),
+                "Dtotal": loss_D.item(), "Dfake": l_fake.item(), "Dreal": l_real.item()}
+        r = st.step(past, fut)
+        for k in rec_:
+            assert abs(rec_[k] - r[k]) <= 2e-4 * abs(rec_[k]) + 1e-7, (k, rec_[k], r[k])
+        recs.append(rec_)
+    errs = [max(rel(P[k], v) for k, v in mod.state_dict().items() if v.is_floating_point())
+            for P, mod in ((st.P_enc, enc), (st.P_dec, dec), (st.P_disc, disc))]
+    print(f"[{name}] {steps} AE train steps: losses {recs}; post-step params oracle-vs-ref enc/dec/disc {errs}")
+    assert max(errs) < 1e-4
+    save = {"meta": json.dumps(dict(cimg=cimg, feat=feat, HW=HW, N=N, T=T, seed=seed, steps=steps, lam_gan=lam_gan)),
+            "records": json.dumps(recs)}
+    for tag, mod in (("enc", enc), ("dec", dec), ("disc", disc)):
+        for k, v in mod.state_dict().items():
+            if v.is_floating_point():  # strided sample of <= ~4096 elements per tensor keeps the fixture small (the disc has 2.8 M)
+                flat = v.flatten()
+                save[f"post:{tag}:{k}"] = flat[::max(1, flat.numel() // 4096)].numpy()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
+
+
 def pos_case(ref, name):
     from utils.position_encoding import PositionEmbeddding1D, PositionEmbeddding2D, PositionEmbeddding3D
     from utils.misc import NestedTensor
@@ -362,6 +417,7 @@ def main():
         ("losses_tiny", lambda n: losses_case(ref, n, 31)),
         ("step_tiny", lambda n: step_case(ref, n, dict(tiny, Tp=2, Tf=2), 48, 64, 2, 41)),
         ("step_far_tiny", lambda n: far_step_case(ref, n, far_tiny, 48, 64, 2, 61)),
+        ("step_ae_tiny", lambda n: ae_step_case(ref, n, 1, 48, 32, 2, 2, 81)),
         ("nar_k64_digest", lambda n: transformer_case(ref, n, k64, False, 1, 51, full=False, check64=False)),
         ("far_bair_digest", lambda n: transformer_case(ref, n, far, True, 1, 52, full=False, check64=False)),
     ]

@@ -489,3 +489,70 @@ class FARStep:
         gn = torch.nn.utils.clip_grad_norm_(self.params_T, self.max_grad_norm)
         self.opt.step()
         return {"T_total": loss.item(), "T_GDL": l_gdl.item(), "T_MSE": l_mse.item(), "grad_norm": float(gn)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# stage-1 auto-encoder training with the PatchGAN discriminator (train_AutoEncoder.py:20-86)
+# ---------------------------------------------------------------------------------------------------------------------
+def disc_forward(P, x, training=False, n_layers=3):
+    """VPTRDisc.forward (VPTR_modules.py:49-95): x (N,Cimg,H,W) -> patch logits (N,1,h,w); keys `model.{i}.*`."""
+    y = F.leaky_relu(F.conv2d(x, P["model.0.weight"], P["model.0.bias"], stride=2, padding=1), 0.2)
+    i = 2
+    for n in range(1, n_layers + 1):
+        stride = 2 if n < n_layers else 1
+        y = F.conv2d(y, P[f"model.{i}.weight"], None, stride=stride, padding=1)
+        y = F.leaky_relu(_bn(P, f"model.{i + 1}.", y, training), 0.2)
+        i += 3
+    return F.conv2d(y, P[f"model.{i}.weight"], P[f"model.{i}.bias"], stride=1, padding=1)
+
+
+def gan_loss_vanilla(pred, target_is_real):
+    """GANLoss('vanilla') (criterion.py:15-74): BCEWithLogits against a constant label map."""
+    return F.binary_cross_entropy_with_logits(pred, torch.full_like(pred, 1.0 if target_is_real else 0.0))
+
+
+class AEStep:
+    """Functional stage-1 step (train_AutoEncoder.py:44-78): rec = Dec(Enc(x)) with train-mode BatchNorm; discriminator
+    update on (rec.detach(), x) with Adam(2e-4, betas (0.5, 0.999)); generator update with
+    lam_gan * GAN(D(rec), real) + MSE + GDL and the same Adam on Enc + Dec parameters."""
+
+    def __init__(self, P_enc, P_dec, P_disc, padding_type="reflect", out_layer="Tanh", lr=2e-4, lam_gan=0.01):
+        self.padding_type, self.out_layer, self.lam_gan = padding_type, out_layer, lam_gan
+        self.P_enc = {k: v.detach().clone() for k, v in P_enc.items()}
+        self.P_dec = {k: v.detach().clone() for k, v in P_dec.items()}
+        self.P_disc = {k: v.detach().clone() for k, v in P_disc.items()}
+
+        def isbuf(k):
+            return k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked")
+        for d in (self.P_enc, self.P_dec, self.P_disc):
+            for k, v in d.items():
+                if v.is_floating_point() and not isbuf(k):
+                    v.requires_grad_(True)
+        self.params_G = [v for d in (self.P_enc, self.P_dec) for v in d.values() if v.requires_grad]
+        self.params_D = [v for v in self.P_disc.values() if v.requires_grad]
+        self.opt_G = torch.optim.Adam(self.params_G, lr=lr, betas=(0.5, 0.999))
+        self.opt_D = torch.optim.Adam(self.params_D, lr=lr, betas=(0.5, 0.999))
+
+    def step(self, past, future):
+        x = torch.cat([past, future], dim=1)
+        for p in self.params_G + self.params_D:
+            p.grad = None
+        feat = enc_forward(self.P_enc, x, padding_type=self.padding_type, training=True)
+        rec = dec_forward(self.P_dec, feat, out_layer=self.out_layer, training=True)
+        for p in self.params_D:
+            p.requires_grad_(True)
+        pred_fake = disc_forward(self.P_disc, rec.detach().flatten(0, 1), training=True)
+        pred_real = disc_forward(self.P_disc, x.flatten(0, 1), training=True)
+        l_fake, l_real = gan_loss_vanilla(pred_fake, False), gan_loss_vanilla(pred_real, True)
+        loss_D = (l_fake + l_real) * 0.5 * self.lam_gan
+        loss_D.backward()
+        self.opt_D.step()
+        for p in self.params_D:
+            p.requires_grad_(False)
+        l_gan = gan_loss_vanilla(disc_forward(self.P_disc, rec.flatten(0, 1), training=True), True)
+        l_mse, l_gdl = mse_loss(rec, x), gdl_loss(x, rec)
+        loss_G = self.lam_gan * l_gan + l_mse + l_gdl
+        loss_G.backward()
+        self.opt_G.step()
+        return {"AEgan": l_gan.item(), "AE_MSE": l_mse.item(), "AE_GDL": l_gdl.item(), "AE_total": loss_G.item(),
+                "Dtotal": loss_D.item(), "Dfake": l_fake.item(), "Dreal": l_real.item()}

@@ -331,3 +331,29 @@ def test_oracle_far_train_step_golden():
             assert abs(r[k] - ref[k]) <= 2e-4 * abs(ref[k]) + 1e-7, (k, r[k], ref[k])
     worst = max(rel(st.P_T[k[5:]], z[k]) for k in z.files if k.startswith("post:"))
     assert worst < 1e-4
+
+
+def test_oracle_ae_gan_step_golden():
+    z = load("step_ae_tiny")
+    meta = jload(z, "meta")
+    import vptr_amd.model as M
+    enc = M.VPTREnc(meta["cimg"], meta["feat"], 3, "reflect")
+    dec = M.VPTRDec(meta["cimg"], meta["feat"], 3, "Tanh", "reflect")
+    disc = M.VPTRDisc(meta["cimg"], ndf=64, n_layers=3)
+    fill.apply_fill(enc, meta["seed"])
+    fill.apply_fill(dec, meta["seed"] + 10)
+    fill.apply_fill(disc, meta["seed"] + 20)
+    st = O.AEStep(dict(enc.state_dict()), dict(dec.state_dict()), dict(disc.state_dict()), lam_gan=meta["lam_gan"])
+    shape = (meta["N"], meta["T"], meta["cimg"], meta["HW"], meta["HW"])
+    for s, ref in enumerate(jload(z, "records")):
+        past = (fill.rand_input(shape, meta["seed"] + 100 + s) - 0.6013795) / 2.7570653
+        fut = (fill.rand_input(shape, meta["seed"] + 200 + s) - 0.6013795) / 2.7570653
+        r = st.step(past, fut)
+        for k in ref:
+            assert abs(r[k] - ref[k]) <= 2e-4 * abs(ref[k]) + 1e-7, (k, r[k], ref[k])
+    P = {"enc": st.P_enc, "dec": st.P_dec, "disc": st.P_disc}
+    for k in z.files:
+        if k.startswith("post:"):
+            _, tag, name = k.split(":", 2)
+            flat = P[tag][name].detach().flatten()
+            assert rel(flat[::max(1, flat.numel() // 4096)], z[k]) < 1e-4, k

@@ -70,7 +70,9 @@ SIGNATURES = {
     "vptr_conv7_out_bwd_weight": [P, P, P, P, P, I, I, I, I, I, I, P],
     "vptr_bnrelu_bwd": [P, P, P, P, L, I, P],
     "vptr_bnrelu_bwd_params": [P, P, P, P, P, P, L, I, P],
-    "vptr_im2col_nhwc": [P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "vptr_im2col_nhwc": [P, P, I, I, I, I, I, I, I, I, I, I, I, P],
+    "vptr_reflect_fold": [P, P, I, I, I, I, I, P],
+    "vptr_conv7_in_bwd_weight": [P, P, P, I, I, I, I, I, P],
     "vptr_sumsq": [P, L, P, P],
     "vptr_adamw": [P, P, P, P, L, F, F, F, F, F, P, P, F, F, P],
 }

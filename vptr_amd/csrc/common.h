@@ -59,6 +59,7 @@ __device__ __forceinline__ float vptr_gelu_grad(float x) {
 __device__ __forceinline__ float vptr_act(float v, int act) {
   if (act == VPTR_ACT_GELU) return vptr_gelu(v);
   if (act == VPTR_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == VPTR_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
   return v;
 }
 

@@ -51,10 +51,14 @@ __global__ __launch_bounds__(256) void conv7_in_fwd_kernel(const float* __restri
   for (int j = 0; j < 4; ++j) {
     const int c = cg * 16 + j * 4;
     float4 o;
-    o.x = fmaxf(acc[j * 4 + 0] * scale[c + 0] + shift[c + 0], 0.f);
-    o.y = fmaxf(acc[j * 4 + 1] * scale[c + 1] + shift[c + 1], 0.f);
-    o.z = fmaxf(acc[j * 4 + 2] * scale[c + 2] + shift[c + 2], 0.f);
-    o.w = fmaxf(acc[j * 4 + 3] * scale[c + 3] + shift[c + 3], 0.f);
+    if (scale) {
+      o.x = fmaxf(acc[j * 4 + 0] * scale[c + 0] + shift[c + 0], 0.f);
+      o.y = fmaxf(acc[j * 4 + 1] * scale[c + 1] + shift[c + 1], 0.f);
+      o.z = fmaxf(acc[j * 4 + 2] * scale[c + 2] + shift[c + 2], 0.f);
+      o.w = fmaxf(acc[j * 4 + 3] * scale[c + 3] + shift[c + 3], 0.f);
+    } else {  // raw convolution output (train-mode BatchNorm is applied by its own passes)
+      o = make_float4(acc[j * 4 + 0], acc[j * 4 + 1], acc[j * 4 + 2], acc[j * 4 + 3]);
+    }
     yp[j] = o;
   }
 }
@@ -297,7 +301,8 @@ extern "C" int vptr_conv7_out_bwd_weight(const float* dy, const float* y, const 
 // im2col on NHWC with zero padding: out[(b,oy,ox)][(ky,kx,c)] = x[b, oy*s-p+ky, ox*s-p+kx, c].  The patch matrix is the
 // k-strided B operand of the ConvTranspose2d weight-gradient GEMM  dW[ci][(ky,kx,co)] = sum_pix x[pix][ci] * P[pix][...].
 __global__ __launch_bounds__(256) void im2col_nhwc_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int IH,
-                                                          int IW, int C4, int OH, int OW, int KH, int KW, int stride, int pad) {
+                                                          int IW, int C4, int OH, int OW, int KH, int KW, int stride, int pad,
+                                                          int pad_mode) {
   const int64_t total = (int64_t)B * OH * OW * KH * KW * C4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c4 = (int)(i % C4);
@@ -307,19 +312,22 @@ __global__ __launch_bounds__(256) void im2col_nhwc_kernel(const float* __restric
     const int ox = (int)(t % OW); t /= OW;
     const int oy = (int)(t % OH);
     const int b = (int)(t / OH);
-    const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+    int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+    if (pad_mode == VPTR_PAD_REFLECT) { iy = reflect_idx(iy, IH); ix = reflect_idx(ix, IW); }
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) v = reinterpret_cast<const float4*>(x)[(((int64_t)b * IH + iy) * IW + ix) * C4 + c4];
     reinterpret_cast<float4*>(out)[i] = v;
   }
 }
 extern "C" int vptr_im2col_nhwc(const float* x, float* out, int B, int IH, int IW, int C, int OH, int OW, int KH, int KW,
-                                int stride, int pad, vptr_stream_t stream) {
+                                int stride, int pad, int pad_mode, vptr_stream_t stream) {
   VPTR_CHECK(B > 0 && IH > 0 && IW > 0 && C > 0 && C % 4 == 0 && OH > 0 && OW > 0 && KH > 0 && KW > 0 && stride >= 1,
              "im2col_nhwc: bad arguments");
+  VPTR_CHECK(pad_mode == VPTR_PAD_ZERO || pad_mode == VPTR_PAD_REFLECT, "im2col_nhwc: pad_mode must be zero or reflect");
+  if (pad_mode == VPTR_PAD_REFLECT) VPTR_CHECK(pad < IH && pad < IW, "im2col_nhwc: reflect padding needs pad < H, W");
   const int64_t total = (int64_t)B * OH * OW * KH * KW * (C / 4);
   const int blocks = (int)hmin64((total + 255) / 256, 16384);
-  im2col_nhwc_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(x, out, B, IH, IW, C / 4, OH, OW, KH, KW, stride, pad);
+  im2col_nhwc_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(x, out, B, IH, IW, C / 4, OH, OW, KH, KW, stride, pad, pad_mode);
   VPTR_LAUNCH_CHECK();
   return 0;
 }
@@ -367,6 +375,88 @@ extern "C" int vptr_bnrelu_bwd_params(const float* dy, const float* y, const flo
                                       int64_t rows, int C, vptr_stream_t stream) {
   VPTR_CHECK(rows > 0 && C > 0 && C % 4 == 0, "bnrelu_bwd_params: bad arguments");
   bnrelu_bwd_params_kernel<<<dim3(cdiv(C / 4, 32), cdiv(rows, 512)), 256, 0, (hipStream_t)stream>>>(dy, y, w, b, dw, db, rows, C / 4);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// adjoint of ReflectionPad2d(p): padded index q mirrors source reflect_idx(q - p, n); the pre-images of source j are
+// q = j + p, q = p - j (1 <= j <= p) and q = 2n - 2 - j + p (1 <= n - 1 - j <= p).
+__device__ __forceinline__ int fold_preimages(int j, int n, int p, int (&q)[3]) {
+  int c = 0;
+  q[c++] = j + p;
+  if (j >= 1 && j <= p) q[c++] = p - j;
+  if (n - 1 - j >= 1 && n - 1 - j <= p) q[c++] = 2 * n - 2 - j + p;
+  return c;
+}
+__global__ __launch_bounds__(256) void reflect_fold_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int B, int H,
+                                                           int W, int C4, int p) {
+  const int Hp = H + 2 * p, Wp = W + 2 * p;
+  const int64_t total = (int64_t)B * H * W * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    const int64_t pix = i / C4;
+    const int xw = (int)(pix % W), yh = (int)((pix / W) % H);
+    const int64_t b = pix / ((int64_t)W * H);
+    int qy[3], qx[3];
+    const int ny = fold_preimages(yh, H, p, qy), nx = fold_preimages(xw, W, p, qx);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < ny; ++u)
+      for (int v = 0; v < nx; ++v) {
+        const float4 s = src[((b * Hp + qy[u]) * Wp + qx[v]) * C4 + c];
+        a.x += s.x; a.y += s.y; a.z += s.z; a.w += s.w;
+      }
+    dst[i] = a;
+  }
+}
+extern "C" int vptr_reflect_fold(const float* dxpad, float* dx, int B, int H, int W, int C, int pad, vptr_stream_t stream) {
+  VPTR_CHECK(dxpad && dx && B > 0 && H > pad && W > pad && pad >= 1 && C > 0 && C % 4 == 0, "reflect_fold: bad arguments");
+  const int64_t total = (int64_t)B * H * W * (C / 4);
+  const int blocks = (int)hmin64((total + 255) / 256, 16384);
+  reflect_fold_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const float4*>(dxpad), reinterpret_cast<float4*>(dx),
+                                                               B, H, W, C / 4, pad);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight gradient of the 7x7 input convolution (Cout = 64): thread = (output channel, tap group of 4); a workgroup sweeps a
+// chunk of pixels, every thread accumulating its taps in registers, and leaves Cimg*49 atomics per channel.
+#define C7W_CHUNK 2048
+__global__ __launch_bounds__(256) void conv7_in_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                  float* __restrict__ dw, int B, int Cimg, int H, int W) {
+  const int co = threadIdx.x & 63, tg = threadIdx.x >> 6;  // taps tg, tg + 4, ... < 49 (13 or 12 per thread)
+  const int64_t npix = (int64_t)B * H * W;
+  const int64_t p0 = (int64_t)blockIdx.x * C7W_CHUNK, p1 = p0 + C7W_CHUNK < npix ? p0 + C7W_CHUNK : npix;
+  for (int ci = 0; ci < Cimg; ++ci) {
+    float acc[13];
+#pragma unroll
+    for (int t = 0; t < 13; ++t) acc[t] = 0.f;
+    for (int64_t pix = p0; pix < p1; ++pix) {
+      const int ox = (int)(pix % W), oy = (int)((pix / W) % H);
+      const int64_t b = pix / ((int64_t)W * H);
+      const float g = dy[pix * 64 + co];
+      const float* xp = x + (b * Cimg + ci) * H * W;
+#pragma unroll
+      for (int t = 0; t < 13; ++t) {
+        const int tap = min(tg + 4 * t, 48);
+        const int ky = tap / 7, kx = tap - ky * 7;
+        acc[t] += g * xp[reflect_idx(oy + ky - 3, H) * W + reflect_idx(ox + kx - 3, W)];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 13; ++t) {
+      const int tap = tg + 4 * t;
+      if (tap < 49) unsafeAtomicAdd(dw + ((int64_t)co * Cimg + ci) * 49 + tap, acc[t]);
+    }
+  }
+}
+extern "C" int vptr_conv7_in_bwd_weight(const float* dy, const float* x, float* dw, int B, int Cimg, int H, int W, int Cout,
+                                        vptr_stream_t stream) {
+  VPTR_CHECK(dy && x && dw && B > 0 && Cimg > 0 && H > 3 && W > 3, "conv7_in_bwd_weight: bad arguments");
+  VPTR_CHECK(Cout == 64, "conv7_in_bwd_weight: Cout must be 64 (ngf of the reference encoder), got %d", Cout);
+  const int64_t npix = (int64_t)B * H * W;
+  conv7_in_bwd_weight_kernel<<<(unsigned)cdiv(npix, C7W_CHUNK), 256, 0, (hipStream_t)stream>>>(dy, x, dw, B, Cimg, H, W);
   VPTR_LAUNCH_CHECK();
   return 0;
 }

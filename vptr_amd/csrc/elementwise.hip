@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     if (rowscale) g *= rowscale[((int)(i / C) / rs_div) % rs_mod];
     if (act == VPTR_ACT_GELU) g *= vptr_gelu_grad(h[i]);
     else if (act == VPTR_ACT_RELU) g = h[i] > 0.f ? g : 0.f;
+    else if (act == VPTR_ACT_LRELU) g = h[i] > 0.f ? g : 0.2f * g;  // h: pre-activation or output (same sign)
     dx[i] = g;
   }
 }

@@ -459,6 +459,7 @@ __device__ __forceinline__ float norm_act_g(float dy, float xh, float w, float b
   float g = dy * dscale;
   if (act == VPTR_ACT_GELU) g *= vptr_gelu_grad(z);
   else if (act == VPTR_ACT_RELU) g = z > 0.f ? g : 0.f;
+  else if (act == VPTR_ACT_LRELU) g = z > 0.f ? g : 0.2f * g;
   return g;
 }
 

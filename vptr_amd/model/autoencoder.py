@@ -76,6 +76,16 @@ def _bn_eval(bn):
     return val
 
 
+def _bn_act(y, bn, HW, act, residual=None):
+    """BatchNorm2d (+ ReLU / LeakyReLU, + residual) on NHWC tokens [pixels, C]: batch statistics + running-stat update in
+    train mode, running statistics in eval mode -- both with autograd (vptr_colstats + vptr_norm_act_fwd/bwd)."""
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        with torch.no_grad():
+            bn.num_batches_tracked.add_(1)
+    return ops.norm_act(y, bn.weight, bn.bias, "bn", HW, bn.training, running_mean=bn.running_mean, running_var=bn.running_var,
+                        act=act, eps=bn.eps, momentum=bn.momentum if bn.momentum is not None else 0.1, residual=residual)
+
+
 class ResnetEncoder(nn.Module):
     def __init__(self, input_nc, ngf=64, out_dim=528, n_downsampling=2, norm_layer=nn.BatchNorm2d, use_dropout=False,
                  padding_type="reflect"):
@@ -104,12 +114,38 @@ class ResnetEncoder(nn.Module):
             return self._forward(x)
 
     def _forward(self, x):
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            # stage 2 runs the encoder under no_grad (train_NAR.py:54-56)
-            if x.requires_grad:
-                raise NotImplementedError("backward through VPTREnc is not on the HIP path yet (stage-1 AE training)")
-        with torch.no_grad():
+        if self.training:
+            # stage-1 training (train_AutoEncoder.py:52-56): train-mode BatchNorm, gradients for every parameter
+            return self._forward_train(x)
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError("gradients w.r.t. the input frames of an eval-mode VPTREnc are not on the HIP path")
+        with torch.no_grad():  # stage 2 / inference: the encoder runs under no_grad (train_NAR.py:54-56)
             return self._forward_impl(x)
+
+    def _forward_train(self, x):
+        """Differentiable forward with whatever mode each BatchNorm2d is in: conv (MFMA implicit GEMM, raw output) ->
+        batch statistics -> normalise + ReLU, ResnetBlocks with the skip add fused into the second normalise pass."""
+        B, Cimg, H, W = x.shape
+        m = self.model
+        y = ops.conv7_in(x.contiguous().float(), m[1].weight)
+        if m[1].bias is not None:
+            y = y + m[1].bias
+        y = _bn_act(y, m[2], H * W, ops.ACT_RELU)
+        h, w, cin = H, W, m[1].weight.shape[0]
+        idx = 4
+        for _ in range(self.n_downsampling):
+            conv, bn = m[idx], m[idx + 1]
+            y, h, w = ops.conv2d_nhwc(y, conv.weight, conv.bias, B, h, w, 2, 1, "zero")
+            y = _bn_act(y, bn, h * w, ops.ACT_RELU)
+            cin = conv.weight.shape[0]
+            idx += 3
+        for bi in range(9):
+            convs, bns = m[idx + bi]._layers()
+            t, _, _ = ops.conv2d_nhwc(y, convs[0].weight, convs[0].bias, B, h, w, 1, 1, self.padding_type)
+            t = _bn_act(t, bns[0], h * w, ops.ACT_RELU)
+            t, _, _ = ops.conv2d_nhwc(t, convs[1].weight, convs[1].bias, B, h, w, 1, 1, self.padding_type)
+            y = _bn_act(t, bns[1], h * w, ops.ACT_NONE, residual=y)                  # out = x + conv_block(x)
+        return ops.tokens_to_nchw(y, B, cin, h, w, relu=True)                        # the trailing nn.ReLU()
 
     def _forward_impl(self, x):
         B, Cimg, H, W = x.shape
@@ -230,7 +266,7 @@ class _DecoderFn(torch.autograd.Function):
                 # split-K GEMM  D[ci][(ky,kx,co)] = x^T . P  with both operands k-strided
                 xin = ctx.x0 if i == 0 else acts[i - 1]
                 P = torch.empty((B * ih * iw, 9 * oc), device=dout.device, dtype=torch.float32)
-                check(lib.vptr_im2col_nhwc(ptr(gm), ptr(P), B, oh, ow, oc, ih, iw, 3, 3, 2, 1, stream()), "vptr_im2col_nhwc")
+                check(lib.vptr_im2col_nhwc(ptr(gm), ptr(P), B, oh, ow, oc, ih, iw, 3, 3, 2, 1, 0, stream()), "vptr_im2col_nhwc")
                 D = torch.zeros((ic, 9 * oc), device=dout.device, dtype=torch.float32)
                 tiles = ((ic + 127) // 128) * ((9 * oc + 175) // 176)
                 ops.gemm_raw(xin, P, D, ic, 9 * oc, B * ih * iw, 1, 1, atomic=True, split_k=ops._split_k_for(tiles, B * ih * iw))
@@ -276,7 +312,22 @@ class ResnetDecoder(nn.Module):
     def forward(self, x):
         """x (B, feat_dim, h, w) -> (B, output_nc, h*2^n, w*2^n); differentiable w.r.t. x (decoder weights are frozen
         in stage 2: the reference never steps them, train_NAR.py:205)."""
+        if self.training:
+            return self._forward_train(x)
         return _DecoderFn.apply(x, self, *[p for p in self.parameters()])
+
+    def _forward_train(self, x):
+        """stage-1 training (train_AutoEncoder.py:52-56): ConvTranspose2d (gather-form MFMA GEMM) -> train-mode BatchNorm +
+        ReLU, then the direct 7x7 output convolution + Tanh / Sigmoid, all with parameter gradients."""
+        B, C, h, w = x.shape
+        m = self.model
+        y = ops.nchw_to_tokens(x.contiguous().float())
+        for i in range(self.n_upsampling):
+            convt, bn = m[3 * i], m[3 * i + 1]
+            y, h, w = ops.conv2d_nhwc(y, convt.weight, convt.bias, B, h, w, 2, 1, "zero", transposed=True, output_padding=1)
+            y = _bn_act(y, bn, h * w, ops.ACT_RELU)
+        conv = m[3 * self.n_upsampling + 1]
+        return ops.conv7_out(y, conv.weight, conv.bias, B, h, w, self.out_act)
 
 
 def init_weights(net, init_type="normal", init_gain=0.02):

@@ -6,6 +6,7 @@ working and released checkpoints load.  Underneath every forward/backward is HIP
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import ops
 from .autoencoder import ResnetDecoder, ResnetEncoder
@@ -43,8 +44,10 @@ class VPTRDec(nn.Module):
 
 
 class VPTRDisc(nn.Module):
-    """PatchGAN discriminator (VPTR_modules.py:49-95).  Stage-1 GAN training is a 'next' row (SURVEY.md 8f, rank 3);
-    the module is constructible so that state_dicts load, its forward is not on the HIP path yet."""
+    """PatchGAN discriminator (VPTR_modules.py:49-95): Conv4x4(s2)+LeakyReLU, n_layers-1 x [Conv4x4(s2)+BN+LeakyReLU],
+    Conv4x4(s1)+BN+LeakyReLU, Conv4x4(s1) -> 1-channel patch logits.  On the HIP path every conv is an MFMA implicit GEMM
+    with dgrad / wgrad (ops.conv2d_nhwc); the 1- or 3-channel input and the 1-channel output are zero-padded to 4 channels
+    (the GEMM stages 4 channels per load)."""
 
     def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d):
         super().__init__()
@@ -62,7 +65,28 @@ class VPTRDisc(nn.Module):
         self.model = nn.Sequential(*seq)
 
     def forward(self, input):
-        raise NotImplementedError("VPTRDisc forward is not on the MI355X hot path yet (stage-1 GAN training is a 'next' row)")
+        """input (N, Cimg, H, W) -> patch logits (N, 1, h, w)"""
+        from ..ops import ACT_LRELU, ACT_NONE, conv2d_nhwc, nchw_to_tokens, tokens_to_nchw
+        from .autoencoder import _bn_act
+        N, Cimg, H, W = input.shape
+        mods = list(self.model)
+        cpad = (-Cimg) % 4
+        x = nchw_to_tokens(F.pad(input.float(), (0, 0, 0, 0, 0, cpad)).contiguous())           # [N*H*W, Cimg+pad]
+        conv = mods[0]
+        y, h, w = conv2d_nhwc(x, F.pad(conv.weight, (0, 0, 0, 0, 0, cpad)), conv.bias, N, H, W, conv.stride[0], conv.padding[0],
+                              "zero", act=ACT_LRELU)
+        i = 2
+        while i < len(mods) - 1:                                                               # [conv, norm, LeakyReLU] groups
+            conv, bn = mods[i], mods[i + 1]
+            if not isinstance(bn, nn.BatchNorm2d):
+                raise NotImplementedError("VPTRDisc on the HIP path supports norm_layer=nn.BatchNorm2d only")
+            y, h, w = conv2d_nhwc(y, conv.weight, conv.bias, N, h, w, conv.stride[0], conv.padding[0], "zero")
+            y = _bn_act(y, bn, h * w, ACT_LRELU)
+            i += 3
+        conv = mods[-1]
+        y, h, w = conv2d_nhwc(y, F.pad(conv.weight, (0, 0, 0, 0, 0, 0, 0, 3)), F.pad(conv.bias, (0, 3)), N, h, w, conv.stride[0],
+                              conv.padding[0], "zero", act=ACT_NONE)
+        return tokens_to_nchw(y[:, :1].contiguous(), N, 1, h, w)
 
 
 class _NCEProjector(nn.Sequential):

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import GemmDesc, check, lib, ptr, stream
 
-ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU = 0, 1, 2, 3
 PAD_MODES = {"zero": 0, "reflect": 1, "replicate": 2}
 
 
@@ -710,6 +710,162 @@ def conv_nhwc(x, Bmat, frames, IH, IW, Cin, OH, OW, KH, KW, stride, pad, pad_mod
     gemm_raw(x, Bmat, y, M, Cout, KH * KW * Cin, 2, 0, lda=0, colscale=colscale, bias=bias, act=act, residual=residual,
              act_after=act_after, conv=(IH, IW, Cin, OH, OW, KH, KW, stride, pad, PAD_MODES[pad_mode], int(transposed)))
     return y
+
+
+# ---- trainable convolutions (stage-1 auto-encoder / PatchGAN training, train_AutoEncoder.py:44-86) -------------------------
+class _Conv2dNHWCFn(torch.autograd.Function):
+    """nn.Conv2d / nn.ConvTranspose2d on NHWC token grids with full autograd, every piece an MFMA GEMM:
+    forward  = implicit-GEMM gather (vptr_gemm, a_mode = conv);
+    dgrad    = the gather-form transposed convolution of dy (Conv2d) / the strided convolution of dy (ConvTranspose2d);
+               reflection padding: gradient on the padded grid, then vptr_reflect_fold;
+    wgrad    = vptr_im2col_nhwc + one k-strided x k-strided split-K GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, frames, IH, IW, stride, pad, pad_mode, transposed, out_pad, act):
+        x = _c(x)
+        if transposed:
+            Cin, Cout, KH, KW = weight.shape
+            OH, OW = (IH - 1) * stride - 2 * pad + KH + out_pad, (IW - 1) * stride - 2 * pad + KW + out_pad
+        else:
+            Cout, Cin, KH, KW = weight.shape
+            OH, OW = (IH + 2 * pad - KH) // stride + 1, (IW + 2 * pad - KW) // stride + 1
+        if x.shape != (frames * IH * IW, Cin):
+            raise RuntimeError("conv2d_nhwc: input %s does not match frames*IH*IW x Cin = %d x %d" % (tuple(x.shape), frames * IH * IW, Cin))
+        if transposed and pad_mode != "zero":
+            raise RuntimeError("conv2d_nhwc: ConvTranspose2d supports zero padding only")
+        y = conv_nhwc(x, conv_weight_as_gemm_b(weight, transposed), frames, IH, IW, Cin, OH, OW, KH, KW, stride, pad, pad_mode,
+                      transposed, Cout, bias=bias, act=act)
+        ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        ctx.cfg = (frames, IH, IW, OH, OW, Cin, Cout, KH, KW, stride, pad, pad_mode, transposed, act, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        frames, IH, IW, OH, OW, Cin, Cout, KH, KW, stride, pad, pad_mode, transposed, act, has_b = ctx.cfg
+        dy = _c(dy)
+        pix_o, pix_i = frames * OH * OW, frames * IH * IW
+        if act != ACT_NONE:  # ReLU / LeakyReLU epilogue: sign of the output decides
+            if act == ACT_GELU:
+                raise RuntimeError("conv2d_nhwc: GELU epilogue is not differentiable from its output")
+            g = torch.empty_like(dy)
+            check(lib.vptr_act_bwd(ptr(dy), ptr(y), ptr(g), pix_o, Cout, act, 1.0, None, 1, 1, 0.0, None, 0, stream()), "vptr_act_bwd")
+        else:
+            g = dy
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            if transposed:   # dx = Conv2d(g, W) with the same stride / padding
+                dx = conv_nhwc(g, weight.permute(0, 2, 3, 1).reshape(Cin, -1).contiguous(), frames, OH, OW, Cout, IH, IW, KH, KW,
+                               stride, pad, "zero", False, Cin)
+            else:
+                Bt = weight.permute(1, 2, 3, 0).reshape(Cin, -1).contiguous()      # [ci][(ky, kx, co)]
+                if pad_mode == "zero" or pad == 0:
+                    dx = conv_nhwc(g, Bt, frames, OH, OW, Cout, IH, IW, KH, KW, stride, pad, "zero", True, Cin)
+                elif pad_mode == "reflect" and stride == 1:
+                    dxp = conv_nhwc(g, Bt, frames, OH, OW, Cout, IH + 2 * pad, IW + 2 * pad, KH, KW, 1, 0, "zero", True, Cin)
+                    dx = torch.empty((pix_i, Cin), device=dy.device, dtype=torch.float32)
+                    check(lib.vptr_reflect_fold(ptr(dxp), ptr(dx), frames, IH, IW, Cin, pad, stream()), "vptr_reflect_fold")
+                else:
+                    raise NotImplementedError("conv2d_nhwc backward: padding mode %r with stride %d" % (pad_mode, stride))
+        if ctx.needs_input_grad[1]:
+            if transposed:   # dW[ci][co][ky][kx] = sum_pix x[pix][ci] * patches(g)[pix][(ky, kx, co)]
+                P = torch.empty((pix_i, KH * KW * Cout), device=dy.device, dtype=torch.float32)
+                check(lib.vptr_im2col_nhwc(ptr(g), ptr(P), frames, OH, OW, Cout, IH, IW, KH, KW, stride, pad, 0, stream()), "vptr_im2col_nhwc")
+                D = torch.zeros((Cin, KH * KW * Cout), device=dy.device, dtype=torch.float32)
+                tiles = ((Cin + 127) // 128) * ((KH * KW * Cout + 175) // 176)
+                gemm_raw(x, P, D, Cin, KH * KW * Cout, pix_i, 1, 1, atomic=True, split_k=_split_k_for(tiles, pix_i))
+                dW = D.view(Cin, KH, KW, Cout).permute(0, 3, 1, 2).contiguous()
+            else:            # dW[co][ci][ky][kx] = sum_pix g[pix][co] * patches(x)[pix][(ky, kx, ci)]
+                P = torch.empty((pix_o, KH * KW * Cin), device=dy.device, dtype=torch.float32)
+                check(lib.vptr_im2col_nhwc(ptr(x), ptr(P), frames, IH, IW, Cin, OH, OW, KH, KW, stride, pad, PAD_MODES[pad_mode] if pad else 0,
+                                           stream()), "vptr_im2col_nhwc")
+                D = torch.zeros((Cout, KH * KW * Cin), device=dy.device, dtype=torch.float32)
+                tiles = ((Cout + 127) // 128) * ((KH * KW * Cin + 175) // 176)
+                gemm_raw(g, P, D, Cout, KH * KW * Cin, pix_o, 1, 1, atomic=True, split_k=_split_k_for(tiles, pix_o))
+                dW = D.view(Cout, KH, KW, Cin).permute(0, 3, 1, 2).contiguous()
+        if has_b and ctx.needs_input_grad[2]:
+            db = torch.zeros((Cout,), device=dy.device, dtype=torch.float32)
+            check(lib.vptr_colsum(ptr(g), ptr(db), pix_o, Cout, stream()), "vptr_colsum")
+        return dx, dW, db, None, None, None, None, None, None, None, None, None
+
+
+def conv2d_nhwc(x, weight, bias, frames, IH, IW, stride=1, pad=0, pad_mode="zero", transposed=False, output_padding=0, act=ACT_NONE):
+    """Trainable convolution on an NHWC token grid [frames*IH*IW, Cin] -> ([frames*OH*OW, Cout], OH, OW).  Channel counts must be
+    multiples of 4 (callers zero-pad 1- and 3-channel ends)."""
+    y = _Conv2dNHWCFn.apply(x, weight, bias, int(frames), int(IH), int(IW), int(stride), int(pad), pad_mode, bool(transposed),
+                            int(output_padding), int(act))
+    if transposed:
+        KH, KW = weight.shape[2], weight.shape[3]
+        OH, OW = (IH - 1) * stride - 2 * pad + KH + output_padding, (IW - 1) * stride - 2 * pad + KW + output_padding
+    else:
+        KH, KW = weight.shape[2], weight.shape[3]
+        OH, OW = (IH + 2 * pad - KH) // stride + 1, (IW + 2 * pad - KW) // stride + 1
+    return y, OH, OW
+
+
+class _Conv7InFn(torch.autograd.Function):
+    """ReflectionPad2d(3) + Conv7x7(Cimg -> 64) of the encoder's first layer, raw output (ResNetAutoEncoder.py:26-27);
+    x NCHW -> y NHWC tokens.  Only the weight gradient exists (the input is the image)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x, weight = _c(x), _c(weight)
+        B, Cimg, H, W = x.shape
+        Cout = weight.shape[0]
+        y = torch.empty((B * H * W, Cout), device=x.device, dtype=torch.float32)
+        check(lib.vptr_conv7_in_fwd(ptr(x), ptr(weight), None, None, ptr(y), B, Cimg, H, W, Cout, stream()), "vptr_conv7_in_fwd")
+        ctx.save_for_backward(x)
+        ctx.wshape = tuple(weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, Cimg, H, W = x.shape
+        dW = torch.zeros(ctx.wshape, device=dy.device, dtype=torch.float32)
+        check(lib.vptr_conv7_in_bwd_weight(ptr(_c(dy)), ptr(x), ptr(dW), B, Cimg, H, W, ctx.wshape[0], stream()), "vptr_conv7_in_bwd_weight")
+        return None, dW
+
+
+def conv7_in(x, weight):
+    return _Conv7InFn.apply(x, weight)
+
+
+class _Conv7OutFn(torch.autograd.Function):
+    """ReflectionPad2d(3) + Conv7x7(64 -> Cimg) + bias + Tanh / Sigmoid of the decoder's last layer
+    (ResNetAutoEncoder.py:89-96); x NHWC tokens [B*H*W, 64] -> y NCHW."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, B, H, W, out_act):
+        x, weight, bias = _c(x), _c(weight), _c(bias)
+        Cimg, Cin = weight.shape[0], weight.shape[1]
+        y = torch.empty((B, Cimg, H, W), device=x.device, dtype=torch.float32)
+        check(lib.vptr_conv7_out_fwd(ptr(x), ptr(weight), ptr(bias), ptr(y), B, Cin, H, W, Cimg, out_act, stream()), "vptr_conv7_out_fwd")
+        ctx.save_for_backward(x, weight, y)
+        ctx.cfg = (B, H, W, out_act)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        B, H, W, out_act = ctx.cfg
+        Cimg, Cin = weight.shape[0], weight.shape[1]
+        dy = _c(dy)
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((B * H * W, Cin), device=dy.device, dtype=torch.float32)
+            check(lib.vptr_conv7_out_bwd_data(ptr(dy), ptr(y), ptr(weight), ptr(dx), B, Cin, H, W, Cimg, out_act, stream()),
+                  "vptr_conv7_out_bwd_data")
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dW = torch.zeros_like(weight)
+            db = torch.zeros((Cimg,), device=dy.device, dtype=torch.float32)
+            check(lib.vptr_conv7_out_bwd_weight(ptr(dy), ptr(y), ptr(x), ptr(dW), ptr(db), B, Cin, H, W, Cimg, out_act, stream()),
+                  "vptr_conv7_out_bwd_weight")
+        return dx, dW, db, None, None, None, None
+
+
+def conv7_out(x, weight, bias, B, H, W, out_act):
+    return _Conv7OutFn.apply(x, weight, bias, int(B), int(H), int(W), int(out_act))
 
 
 def bn_fold(bn_weight, bn_bias, running_mean, running_var, eps=1e-5):

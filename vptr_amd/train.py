@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from . import ops
 from ._lib import check, lib, ptr, stream
-from .model.criterion import GDL, BiPatchNCE, MSELoss
+from .model.criterion import GDL, BiPatchNCE, GANLoss, MSELoss
 
 
 class FlatAdamW:
@@ -255,3 +255,48 @@ class FARTrainer(NARTrainer):
         """Autoregressive test-phase rollout (train_FAR.py:103-125): see vptr_amd.inference.far_rollout."""
         from .inference import far_rollout
         return far_rollout(self.enc, self.dec, self.T, past, num_pred)
+
+
+class AETrainer:
+    """One stage-1 step (`single_iter` of train_AutoEncoder.py:44-78): rec = Dec(Enc(cat(past, future))) with train-mode
+    BatchNorm; discriminator update on (rec.detach(), x): 0.5 * lam_gan * (BCE(D(fake), 0) + BCE(D(real), 1)), Adam; generator
+    update: lam_gan * BCE(D(rec), 1) + MSE + GDL, Adam on Enc + Dec.  torch.optim.Adam(lr 2e-4, betas (0.5, 0.999)) is
+    AdamW with weight_decay 0, so both optimizers are `FlatAdamW` slabs (no clipping in this stage)."""
+
+    def __init__(self, enc, dec, disc, lr=2e-4, lam_gan=0.01, betas=(0.5, 0.999), gan_mode="vanilla"):
+        self.enc, self.dec, self.disc = enc, dec, disc
+        for m in (enc, dec, disc):
+            for p in m.parameters():
+                p.requires_grad_(True)
+        self.opt_G = FlatAdamW(list(enc.parameters()) + list(dec.parameters()), lr=lr, betas=betas, weight_decay=0.0)
+        self.opt_D = FlatAdamW(list(disc.parameters()), lr=lr, betas=betas, weight_decay=0.0)
+        self.gan = GANLoss(gan_mode, target_real_label=1.0, target_fake_label=0.0).to(self.opt_G.flat.device)
+        self.mse, self.gdl = MSELoss(), GDL(alpha=1)
+        self.lam_gan = lam_gan
+
+    def step(self, past, future):
+        x = torch.cat([past, future], dim=1)
+        self.enc.train()
+        self.dec.train()
+        self.opt_G.zero_grad()
+        rec = self.dec(self.enc(x))
+        # ---- discriminator (cal_lossD, :20-29)
+        self.disc.train()
+        for p in self.disc.parameters():
+            p.requires_grad_(True)
+        self.opt_D.zero_grad()
+        l_fake = self.gan(self.disc(rec.detach().flatten(0, 1)), False)
+        l_real = self.gan(self.disc(x.flatten(0, 1)), True)
+        loss_D = (l_fake + l_real) * 0.5 * self.lam_gan
+        loss_D.backward()
+        self.opt_D.step()
+        # ---- generator (cal_lossG, :31-42)
+        for p in self.disc.parameters():
+            p.requires_grad_(False)
+        l_gan = self.gan(self.disc(rec.flatten(0, 1)), True)
+        l_mse, l_gdl = self.mse(rec, x), self.gdl(x, rec)
+        loss_G = self.lam_gan * l_gan + l_mse + l_gdl
+        loss_G.backward()
+        self.opt_G.step()
+        return {"AEgan": l_gan.detach(), "AE_MSE": l_mse.detach(), "AE_GDL": l_gdl.detach(), "AE_total": loss_G.detach(),
+                "Dtotal": loss_D.detach(), "Dfake": l_fake.detach(), "Dreal": l_real.detach()}
