@@ -371,6 +371,21 @@ def ae_step_case(ref, name, cimg, feat, HW, N, T, seed, steps=2, lam_gan=0.01):
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
 
 
+def metrics_case(ref, name):
+    """utils/metrics.py PSNR / MSEScore / SSIM of the real reference on seeded image batches"""
+    import utils.metrics as RM
+    save, out = {}, {}
+    for tag, (n, c, h, w) in (("a", (3, 1, 32, 32)), ("b", (2, 3, 20, 28))):
+        x, y = fill.rand_input((n, c, h, w), 301), fill.rand_input((n, c, h, w), 302)
+        y = 0.8 * x + 0.2 * y
+        save["x:" + tag], save["y:" + tag] = x.numpy(), y.numpy()
+        out[tag] = {"psnr": RM.PSNR(x, y), "psnr255": RM.PSNR(x * 255, y * 255, 255), "mse": RM.MSEScore(x, y),
+                    "ssim": float(RM.SSIM()(x, y)), "ssim_each": RM.SSIM(size_average=False)(x, y).tolist()}
+    save["expected"] = json.dumps(out)
+    print(f"[{name}] {out}")
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
+
+
 def pos_case(ref, name):
     from utils.position_encoding import PositionEmbeddding1D, PositionEmbeddding2D, PositionEmbeddding3D
     from utils.misc import NestedTensor
@@ -418,6 +433,7 @@ def main():
         ("step_tiny", lambda n: step_case(ref, n, dict(tiny, Tp=2, Tf=2), 48, 64, 2, 41)),
         ("step_far_tiny", lambda n: far_step_case(ref, n, far_tiny, 48, 64, 2, 61)),
         ("step_ae_tiny", lambda n: ae_step_case(ref, n, 1, 48, 32, 2, 2, 81)),
+        ("metrics_tiny", lambda n: metrics_case(ref, n)),
         ("nar_k64_digest", lambda n: transformer_case(ref, n, k64, False, 1, 51, full=False, check64=False)),
         ("far_bair_digest", lambda n: transformer_case(ref, n, far, True, 1, 52, full=False, check64=False)),
     ]

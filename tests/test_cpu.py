@@ -357,3 +357,15 @@ def test_oracle_ae_gan_step_golden():
             _, tag, name = k.split(":", 2)
             flat = P[tag][name].detach().flatten()
             assert rel(flat[::max(1, flat.numel() // 4096)], z[k]) < 1e-4, k
+
+
+def test_metrics_match_reference_golden():
+    from vptr_amd import metrics as M
+    z = load("metrics_tiny")
+    exp = jload(z, "expected")
+    for tag, e in exp.items():
+        x, y = torch.from_numpy(z["x:" + tag]), torch.from_numpy(z["y:" + tag])
+        assert abs(M.PSNR(x, y) - e["psnr"]) < 1e-4 and abs(M.PSNR(x * 255, y * 255, 255) - e["psnr255"]) < 1e-4
+        assert abs(M.MSEScore(x, y) - e["mse"]) < 1e-5 * abs(e["mse"])
+        assert abs(float(M.SSIM()(x, y)) - e["ssim"]) < 2e-6
+        assert np.allclose(M.SSIM(size_average=False)(x, y).numpy(), np.array(e["ssim_each"]), atol=2e-6)

@@ -8,7 +8,7 @@ stale.  Only `vptr_amd.build` (the hipcc driver that produces the library) is im
 import importlib
 
 __version__ = "0.1.0"
-_LAZY = ("_lib", "ops", "model", "train", "parallel", "build", "inference", "checkpoint")
+_LAZY = ("_lib", "ops", "model", "train", "parallel", "build", "inference", "checkpoint", "metrics")
 
 
 def __getattr__(name):
