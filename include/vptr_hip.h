@@ -148,6 +148,16 @@ int vptr_tattn_bwd(const float* q, const float* k, const float* v, const float* 
                    int Nb, int Tq, int Tk, int HW, int C, int nh, int causal, float dropout_p, const uint64_t* seed_dev,
                    uint32_t site, vptr_stream_t stream);
 
+/* Temporal-spatial window attention (TemporalSpatialLocalMultiheadAttention, VidHRFormer_modules.py:219-284 with the
+ * permutes of :444-484 folded into index arithmetic): q [(n,tq,h,w), C] (pre-scaled), k, v [(n,tk,h,w), C]; for every
+ * ws x ws window and head the Tq*ws*ws queries attend to the Tk*ws*ws memory tokens of the same window.
+ * H, W multiples of ws (PadBlock padding is applied by the caller with vptr_window_copy). */
+int vptr_tsattn_fwd(const float* q, const float* k, const float* v, float* o, int Nb, int Tq, int Tk, int H, int W, int ws, int C,
+                    int nh, float dropout_p, const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream);
+int vptr_tsattn_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk, float* dv, int Nb,
+                    int Tq, int Tk, int H, int W, int ws, int C, int nh, float dropout_p, const uint64_t* seed_dev,
+                    uint32_t site, vptr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Conv-FFN pieces (MlpDWBN, VidHRFormer_modules.py:424-442) on channel-last [rows = frames*HW, F].
  * Normalisation statistics:

@@ -52,7 +52,7 @@ def build_nar(ref, cfg, seed, far=False):
     else:
         m = ref.VPTRFormerNAR(cfg["Tp"], cfg["Tf"], cfg["H"], cfg["W"], cfg["C"], cfg["nhead"],
                               cfg["num_encoder_layers"], cfg["num_decoder_layers"], 0.0, cfg["window_size"], 4,
-                              False, cfg["rpe"])
+                              bool(cfg.get("TSLMA", False)), cfg["rpe"])
     fill.apply_fill(m, seed)
     return m
 
@@ -427,6 +427,8 @@ def main():
         ("far_tiny", lambda n: transformer_case(ref, n, dict(tiny, Tin=5, num_encoder_layers=2), True, 2, 13)),
         ("nar_tiny_pad", lambda n: transformer_case(ref, n, dict(tiny, H=6, W=6, Tp=2, Tf=2), False, 1, 14)),
         ("nar_tiny_T", lambda n: transformer_case(ref, n, dict(tiny, Tp=2, Tf=4, num_decoder_layers=2), False, 1, 15)),
+        ("nar_tiny_tslma", lambda n: transformer_case(ref, n, dict(tiny, Tp=2, TSLMA=True, num_decoder_layers=2), False, 2, 16)),
+        ("nar_tiny_tslma_pad", lambda n: transformer_case(ref, n, dict(tiny, H=6, W=6, Tp=2, Tf=2, TSLMA=True), False, 1, 17)),
         ("ae_tiny_reflect", lambda n: ae_case(ref, n, 1, 48, 32, 1, 2, "reflect", "Tanh", 21)),
         ("ae_tiny_zero", lambda n: ae_case(ref, n, 3, 48, 32, 1, 2, "zero", "Sigmoid", 22)),
         ("losses_tiny", lambda n: losses_case(ref, n, 31)),

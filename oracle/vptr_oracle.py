@@ -222,6 +222,30 @@ def enc_block(P, pre, x, lw_pos, tpos, cfg, far, training):
     return x.reshape(T, N, H, W, C).permute(1, 0, 2, 3, 4)
 
 
+def _ts_permute(x, ws):
+    """TemporalLocalPermuteModule.permute (VidHRFormer_modules.py:444-470) after PadBlock centre padding:
+    (N,T,H,W,C) -> ((T*ws*ws), N*(Hp/ws)*(Wp/ws), C) plus the padded size."""
+    N, T, H, W, C = x.shape
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    ph, pw = Hp - H, Wp - W
+    x = F.pad(x, (0, 0, pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+    x = x.reshape(N, T, Hp // ws, ws, Wp // ws, ws, C).permute(1, 3, 5, 0, 2, 4, 6)   # t ph pw n qh qw c
+    return x.reshape(T * ws * ws, N * (Hp // ws) * (Wp // ws), C), (Hp, Wp)
+
+
+def tslma(P, pre, mem, query, Tlw, ws, nh):
+    """TemporalSpatialLocalMultiheadAttention.forward (VidHRFormer_modules.py:247-284): cross attention of the T2*ws*ws
+    query tokens of a window to the T1*ws*ws memory tokens of the same window, stock packed-weight MHA."""
+    N, T1, H, W, C = mem.shape
+    T2 = query.shape[1]
+    mp, (Hp, Wp) = _ts_permute(mem, ws)
+    qp, _ = _ts_permute(query, ws)
+    out = mha(P, pre + "attn.", qp + Tlw[T1:T1 + T2].flatten(0, 2)[:, None, :], mp + Tlw[:T1].flatten(0, 2)[:, None, :], mp, nh)
+    out = out.reshape(T2, ws, ws, N, Hp // ws, Wp // ws, C).permute(3, 0, 4, 1, 5, 2, 6).reshape(N, T2, Hp, Wp, C)
+    ph, pw = Hp - H, Wp - W
+    return out[:, :, ph // 2:ph // 2 + H, pw // 2:pw // 2 + W, :]
+
+
 def dec_block(P, pre, tgt, qpos, mem, lw_pos, tpos_f, tpos_p, cfg, training):
     N, T2, H, W, C = tgt.shape
     T1 = mem.shape[1]
@@ -236,11 +260,16 @@ def dec_block(P, pre, tgt, qpos, mem, lw_pos, tpos_f, tpos_p, cfg, training):
     u = _ln(P, pre + "norm4.", x)
     x = x + F.linear(F.gelu(F.linear(u, P[pre + "linear1.weight"], P[pre + "linear1.bias"])),
                      P[pre + "linear2.weight"], P[pre + "linear2.bias"])
-    u = _ln(P, pre + "norm5.", x)
-    mem_s = mem.permute(1, 0, 2, 3, 4).reshape(T1, N * H * W, C)
-    qpos_s = qpos.permute(1, 0, 2, 3, 4).reshape(T2, N * H * W, C)
-    x = x + mha(P, pre + "EncDecAttn.", u + qpos_s + tpos_f[:, None, :], mem_s + tpos_p[:, None, :], mem_s, nh)
-    x = x.reshape(T2, N, H, W, C).permute(1, 0, 2, 3, 4)
+    if cfg.get("TSLMA", False):       # VidHRFormer_modules.py:195-199
+        x = x.reshape(T2, N, H, W, C).permute(1, 0, 2, 3, 4)
+        u = _ln(P, pre + "norm5.", x)
+        x = x + tslma(P, pre + "TSLMA.", mem, u + qpos, P["Tlw_pos"], ws, nh)
+    else:
+        u = _ln(P, pre + "norm5.", x)
+        mem_s = mem.permute(1, 0, 2, 3, 4).reshape(T1, N * H * W, C)
+        qpos_s = qpos.permute(1, 0, 2, 3, 4).reshape(T2, N * H * W, C)
+        x = x + mha(P, pre + "EncDecAttn.", u + qpos_s + tpos_f[:, None, :], mem_s + tpos_p[:, None, :], mem_s, nh)
+        x = x.reshape(T2, N, H, W, C).permute(1, 0, 2, 3, 4)
     x = x + conv_ffn(P, pre + "SpatialFFN1.", _ln(P, pre + "norm6.", x), "ln", training)
     return x
 

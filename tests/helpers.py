@@ -30,7 +30,7 @@ def build_transformer(pkg, cfg, far, dropout=0.0):
         return pkg.VPTRFormerFAR(cfg["Tp"], cfg["Tf"], cfg["H"], cfg["W"], cfg["C"], cfg["nhead"], cfg["num_encoder_layers"],
                                  dropout, cfg["window_size"], 4, cfg["rpe"])
     return pkg.VPTRFormerNAR(cfg["Tp"], cfg["Tf"], cfg["H"], cfg["W"], cfg["C"], cfg["nhead"], cfg["num_encoder_layers"],
-                             cfg["num_decoder_layers"], dropout, cfg["window_size"], 4, False, cfg["rpe"])
+                             cfg["num_decoder_layers"], dropout, cfg["window_size"], 4, bool(cfg.get("TSLMA", False)), cfg["rpe"])
 
 
 def grad_floor(norms):

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 # ------------------------------------------------------------------------------------------------------- oracle pinning
-@pytest.mark.parametrize("name", ["nar_tiny", "nar_tiny_norpe", "far_tiny", "nar_tiny_pad", "nar_tiny_T"])
+@pytest.mark.parametrize("name", ["nar_tiny", "nar_tiny_norpe", "far_tiny", "nar_tiny_pad", "nar_tiny_T", "nar_tiny_tslma", "nar_tiny_tslma_pad"])
 def test_oracle_matches_reference_golden(name):
     z = load(name)
     cfg, far = jload(z, "cfg"), bool(int(z["far"]))
@@ -152,7 +152,7 @@ def test_product_path_has_no_cpu_fallback():
                 assert "import oracle" not in src and "from oracle" not in src, f
 
 
-@pytest.mark.parametrize("name", ["nar_tiny", "nar_tiny_norpe", "far_tiny", "nar_k64_digest", "far_bair_digest"])
+@pytest.mark.parametrize("name", ["nar_tiny", "nar_tiny_norpe", "far_tiny", "nar_tiny_tslma", "nar_k64_digest", "far_bair_digest"])
 def test_state_dict_keys_match_reference(name):
     import vptr_amd.model as pkg
     z = load(name)

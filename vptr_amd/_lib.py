@@ -52,6 +52,8 @@ SIGNATURES = {
     "vptr_winattn_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, P],
     "vptr_tattn_fwd": [P, P, P, P, I, I, I, I, I, I, I, F, P, U, P],
     "vptr_tattn_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, P, U, P],
+    "vptr_tsattn_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, F, P, U, P],
+    "vptr_tsattn_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P, U, P],
     "vptr_colstats": [P, P, P, P, I, I, P],
     "vptr_groupstats": [P, P, P, I, I, P],
     "vptr_norm_act_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, P, U, P, I, I, P, P],

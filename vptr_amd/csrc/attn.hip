@@ -389,3 +389,240 @@ extern "C" int vptr_tattn_bwd(const float* q, const float* k, const float* v, co
   VPTR_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// temporal-spatial window attention (TemporalSpatialLocalMultiheadAttention, VidHRFormer_modules.py:219-284,444-484):
+// for every window (n, qh, qw) and head, the Tq*ws*ws query tokens attend to the Tk*ws*ws memory tokens of the same
+// window.  Sequence element s = (t, ph, pw) lives at token row ((n*T + t)*H + qh*ws + ph)*W + qw*ws + pw, so the
+// reference's pad / permute / reverse-permute copies are index arithmetic here.  Exact fp32, K and V of the window
+// staged in LDS, queries in chunks of TS_QC.
+// ------------------------------------------------------------------------------------------------------------
+#define TS_QC 16
+__device__ __forceinline__ int64_t ts_row(int n, int T, int H, int W, int ws, int qh, int qw, int s) {
+  const int w2 = ws * ws;
+  const int t = s / w2, r = s - t * w2;
+  const int ph = r / ws, pw = r - ph * ws;
+  return ((int64_t)(n * T + t) * H + qh * ws + ph) * W + qw * ws + pw;
+}
+
+__global__ __launch_bounds__(256) void tsattn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, float* __restrict__ o, int Tq, int Tk,
+                                                         int H, int W, int ws, int C, int nh, float p,
+                                                         const uint64_t* seed_dev, uint32_t site) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int hd = C / nh, hp = hd + 1, w2 = ws * ws;
+  const int Lq = Tq * w2, Lk = Tk * w2, Lp = Lk + 1;
+  float* sk = smem;               // [Lk][hp]
+  float* sv = sk + Lk * hp;       // [Lk][hp]
+  float* sq = sv + Lk * hp;       // [TS_QC][hp]
+  float* ss = sq + TS_QC * hp;    // [TS_QC][Lp]
+  const int nwx = W / ws, nwy = H / ws;
+  const int b = blockIdx.x, h = blockIdx.y, i0 = blockIdx.z * TS_QC;
+  const int n = b / (nwy * nwx), qh = (b / nwx) % nwy, qw = b % nwx;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nq = min(TS_QC, Lq - i0);
+  for (int e = tid; e < Lk * hd; e += 256) {
+    const int j = e / hd, d = e - j * hd;
+    const int64_t g = ts_row(n, Tk, H, W, ws, qh, qw, j) * C + h * hd + d;
+    sk[j * hp + d] = k[g];
+    sv[j * hp + d] = v[g];
+  }
+  for (int e = tid; e < nq * hd; e += 256) {
+    const int i = e / hd, d = e - i * hd;
+    sq[i * hp + d] = q[ts_row(n, Tq, H, W, ws, qh, qw, i0 + i) * C + h * hd + d];
+  }
+  __syncthreads();
+  for (int e = tid; e < nq * Lk; e += 256) {
+    const int i = e / Lk, j = e - i * Lk;
+    float a = 0.f;
+    for (int d = 0; d < hd; ++d) a += sq[i * hp + d] * sk[j * hp + d];
+    ss[i * Lp + j] = a;
+  }
+  __syncthreads();
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  for (int i = wv; i < nq; i += 4) {  // one wave per query row
+    float m = -INFINITY;
+    for (int j = lane; j < Lk; j += 64) m = fmaxf(m, ss[i * Lp + j]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < Lk; j += 64) { const float e = __expf(ss[i * Lp + j] - m); ss[i * Lp + j] = e; s += e; }
+    const float inv = 1.f / wave_sum(s);
+    for (int j = lane; j < Lk; j += 64) {
+      float pr = ss[i * Lp + j] * inv;
+      if (p > 0.f) pr *= vptr_drop_scale(seed, site, (((uint64_t)b * nh + h) * Lq + (i0 + i)) * Lk + j, p);
+      ss[i * Lp + j] = pr;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < nq * hd; e += 256) {
+    const int i = e / hd, d = e - i * hd;
+    float a = 0.f;
+    for (int j = 0; j < Lk; ++j) a += ss[i * Lp + j] * sv[j * hp + d];
+    o[ts_row(n, Tq, H, W, ws, qh, qw, i0 + i) * C + h * hd + d] = a;
+  }
+}
+
+// backward: one workgroup of 512 threads per (window, head) walks the query chunks; dK / dV are accumulated in registers
+// (thread (jg, d) owns channel d of keys jg, jg + 512/hd, ...: at most TS_NACC each) and written once, dQ chunk by chunk.
+#define TS_NACC 24
+__global__ __launch_bounds__(512) void tsattn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, const float* __restrict__ dout,
+                                                         float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+                                                         int Tq, int Tk, int H, int W, int ws, int C, int nh, float p,
+                                                         const uint64_t* seed_dev, uint32_t site) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int hd = C / nh, hp = hd + 1, w2 = ws * ws;
+  const int Lq = Tq * w2, Lk = Tk * w2, Lp = Lk + 1;
+  float* sk = smem;                 // [Lk][hp]
+  float* sv = sk + Lk * hp;         // [Lk][hp]
+  float* sq = sv + Lk * hp;         // [TS_QC][hp]
+  float* sdo = sq + TS_QC * hp;     // [TS_QC][hp]
+  float* sp = sdo + TS_QC * hp;     // [TS_QC][Lp]   P * dropout scale
+  float* sds = sp + TS_QC * Lp;     // [TS_QC][Lp]   dS
+  const int nwx = W / ws, nwy = H / ws;
+  const int b = blockIdx.x, h = blockIdx.y;
+  const int n = b / (nwy * nwx), qh = (b / nwx) % nwy, qw = b % nwx;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int e = tid; e < Lk * hd; e += 512) {
+    const int j = e / hd, d = e - j * hd;
+    const int64_t g = ts_row(n, Tk, H, W, ws, qh, qw, j) * C + h * hd + d;
+    sk[j * hp + d] = k[g];
+    sv[j * hp + d] = v[g];
+  }
+  float ak[TS_NACC], av[TS_NACC];
+#pragma unroll
+  for (int u = 0; u < TS_NACC; ++u) { ak[u] = 0.f; av[u] = 0.f; }
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  // dK / dV ownership: thread = (key group jg, channel od); it owns keys jg, jg + jgroups, ... (nu <= TS_NACC of them)
+  const int jgroups = 512 / hd, jg = tid / hd, od = tid - jg * hd;
+  const bool owner = jg < jgroups;
+  const int nu = (Lk + jgroups - 1) / jgroups;
+  for (int i0 = 0; i0 < Lq; i0 += TS_QC) {
+    const int nq = min(TS_QC, Lq - i0);
+    __syncthreads();  // previous chunk's tiles are no longer read (also orders the K/V stores before the first use)
+    for (int e = tid; e < TS_QC * hd; e += 512) {
+      const int i = e / hd, d = e - i * hd;
+      float qv = 0.f, dv_ = 0.f;
+      if (i < nq) {
+        const int64_t g = ts_row(n, Tq, H, W, ws, qh, qw, i0 + i) * C + h * hd + d;
+        qv = q[g];
+        dv_ = dout[g];
+      }
+      sq[i * hp + d] = qv;      // rows beyond nq are zero: they add nothing to dK / dV
+      sdo[i * hp + d] = dv_;
+    }
+    __syncthreads();
+    for (int e = tid; e < TS_QC * Lk; e += 512) {
+      const int i = e / Lk, j = e - i * Lk;
+      float a = 0.f, c = 0.f;
+      for (int d = 0; d < hd; ++d) {
+        a += sq[i * hp + d] * sk[j * hp + d];
+        c += sdo[i * hp + d] * sv[j * hp + d];
+      }
+      sp[i * Lp + j] = a;
+      sds[i * Lp + j] = c;
+    }
+    __syncthreads();
+    for (int i = wv; i < TS_QC; i += 8) {  // one wave per query row: softmax, dropout, dS = P * (dP - sum(dP * P))
+      float m = -INFINITY;
+      for (int j = lane; j < Lk; j += 64) m = fmaxf(m, sp[i * Lp + j]);
+      m = wave_max(m);
+      float s = 0.f;
+      for (int j = lane; j < Lk; j += 64) { const float e = __expf(sp[i * Lp + j] - m); sp[i * Lp + j] = e; s += e; }
+      const float inv = 1.f / wave_sum(s);
+      float dot = 0.f;
+      for (int j = lane; j < Lk; j += 64) {
+        const float pr = sp[i * Lp + j] * inv;
+        float sc = 1.f;
+        if (p > 0.f) sc = vptr_drop_scale(seed, site, (((uint64_t)b * nh + h) * Lq + (i0 + i)) * Lk + j, p);
+        const float dpr = sds[i * Lp + j] * sc;
+        dot += dpr * pr;
+        sds[i * Lp + j] = dpr;
+        sp[i * Lp + j] = pr;
+      }
+      dot = wave_sum(dot);
+      for (int j = lane; j < Lk; j += 64) {
+        const float pr = sp[i * Lp + j];
+        float sc = 1.f;
+        if (p > 0.f) sc = vptr_drop_scale(seed, site, (((uint64_t)b * nh + h) * Lq + (i0 + i)) * Lk + j, p);
+        sds[i * Lp + j] = (i < nq) ? pr * (sds[i * Lp + j] - dot) : 0.f;
+        sp[i * Lp + j] = (i < nq) ? pr * sc : 0.f;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < nq * hd; e += 512) {
+      const int i = e / hd, d = e - i * hd;
+      float a = 0.f;
+      for (int j = 0; j < Lk; ++j) a += sds[i * Lp + j] * sk[j * hp + d];
+      dq[ts_row(n, Tq, H, W, ws, qh, qw, i0 + i) * C + h * hd + d] = a;
+    }
+    if (owner) {
+#pragma unroll 1
+      for (int i = 0; i < TS_QC; ++i) {
+        const float qv = sq[i * hp + od], dov = sdo[i * hp + od];
+#pragma unroll
+        for (int u = 0; u < TS_NACC; ++u) {
+          if (u < nu) {  // workgroup-uniform
+            const int j = min(jg + u * jgroups, Lk - 1);  // the clamped duplicates of the last group are never written
+            ak[u] += sds[i * Lp + j] * qv;
+            av[u] += sp[i * Lp + j] * dov;
+          }
+        }
+      }
+    }
+  }
+  if (owner) {
+#pragma unroll
+    for (int u = 0; u < TS_NACC; ++u) {
+      const int j = jg + u * jgroups;
+      if (u < nu && j < Lk) {
+        const int64_t g = ts_row(n, Tk, H, W, ws, qh, qw, j) * C + h * hd + od;
+        dk[g] = ak[u];
+        dv[g] = av[u];
+      }
+    }
+  }
+}
+
+static int tsattn_check(const char* who, int Nb, int Tq, int Tk, int H, int W, int ws, int C, int nh, float p,
+                        const uint64_t* seed_dev) {
+  VPTR_CHECK(Nb > 0 && Tq > 0 && Tk > 0 && H > 0 && W > 0 && ws > 0 && C > 0 && nh > 0, "%s: bad arguments", who);
+  VPTR_CHECK(C % nh == 0 && H % ws == 0 && W % ws == 0, "%s: C %% heads and H, W %% window must be 0 (pad first)", who);
+  if (p > 0.f) VPTR_CHECK(seed_dev && p < 1.f, "%s: dropout needs seed_dev", who);
+  return 0;
+}
+
+extern "C" int vptr_tsattn_fwd(const float* q, const float* k, const float* v, float* o, int Nb, int Tq, int Tk, int H, int W,
+                               int ws, int C, int nh, float dropout_p, const uint64_t* seed_dev, uint32_t site,
+                               vptr_stream_t stream) {
+  if (tsattn_check("tsattn_fwd", Nb, Tq, Tk, H, W, ws, C, nh, dropout_p, seed_dev)) return -1;
+  const int hd = C / nh, Lq = Tq * ws * ws, Lk = Tk * ws * ws;
+  const size_t lds = sizeof(float) * ((size_t)(2 * Lk + TS_QC) * (hd + 1) + (size_t)TS_QC * (Lk + 1));
+  VPTR_CHECK(lds <= 160 * 1024, "tsattn_fwd: window sequence too long for LDS (Tk*ws*ws = %d, %zu B)", Lk, lds);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)tsattn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int windows = Nb * (H / ws) * (W / ws);
+  tsattn_fwd_kernel<<<dim3(windows, nh, cdiv(Lq, TS_QC)), 256, lds, (hipStream_t)stream>>>(q, k, v, o, Tq, Tk, H, W, ws, C, nh,
+                                                                                          dropout_p, seed_dev, site);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vptr_tsattn_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,
+                               float* dv, int Nb, int Tq, int Tk, int H, int W, int ws, int C, int nh, float dropout_p,
+                               const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream) {
+  if (tsattn_check("tsattn_bwd", Nb, Tq, Tk, H, W, ws, C, nh, dropout_p, seed_dev)) return -1;
+  const int hd = C / nh, Lk = Tk * ws * ws;
+  VPTR_CHECK(hd <= 512 && Lk <= TS_NACC * (512 / hd), "tsattn_bwd: Tk*ws*ws = %d exceeds %d keys per window", Lk, TS_NACC * (512 / hd));
+  const size_t lds = sizeof(float) * ((size_t)(2 * Lk + 2 * TS_QC) * (hd + 1) + (size_t)2 * TS_QC * (Lk + 1));
+  VPTR_CHECK(lds <= 160 * 1024, "tsattn_bwd: window sequence too long for LDS (Tk*ws*ws = %d, %zu B)", Lk, lds);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)tsattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int windows = Nb * (H / ws) * (W / ws);
+  tsattn_bwd_kernel<<<dim3(windows, nh), 512, lds, (hipStream_t)stream>>>(q, k, v, dout, dq, dk, dv, Tq, Tk, H, W, ws, C, nh,
+                                                                         dropout_p, seed_dev, site);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}

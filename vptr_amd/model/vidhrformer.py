@@ -118,6 +118,51 @@ class SpatialLocalMultiheadAttention(nn.Module):
         return f"dim={self.dim}, window_size={self.window_size}, num_heads={self.num_heads}"
 
 
+class TemporalSpatialLocalMultiheadAttention(nn.Module):
+    """Encoder-decoder attention over (time x window) tokens (VidHRFormer_modules.py:219-284): for every ws x ws window the
+    T2*ws*ws query tokens attend to the T1*ws*ws memory tokens of the same window with a stock packed-weight
+    nn.MultiheadAttention; TS_local_pos_embed[:T1] is added to the keys, [T1:T1+T2] to the queries, after PadBlock's zero
+    centre padding.  On the HIP path pad / permute / reverse permute are index arithmetic of vptr_tsattn_fwd/bwd."""
+
+    def __init__(self, embed_dim, num_heads, window_size=7, dropout=0.0):
+        super().__init__()
+        self.dim, self.num_heads, self.window_size, self.dropout = embed_dim, num_heads, window_size, dropout
+        self.attn = nn.MultiheadAttention(embed_dim, num_heads, dropout=dropout)
+        self._tabs = {}
+
+    def _pos_table(self, Tlw, t0, T, H, W):
+        key = (t0, T, H, W, Tlw.device)
+        if key not in self._tabs:
+            ws = self.window_size
+            hh = torch.arange(H, device=Tlw.device) % ws
+            ww = torch.arange(W, device=Tlw.device) % ws
+            self._tabs[key] = Tlw[t0:t0 + T][:, hh[:, None], ww[None, :]].reshape(T * H * W, -1).contiguous()
+        return self._tabs[key]
+
+    def forward_tokens(self, mem, query, residual, g, T1, Tlw, site, rowscale=None, rs_div=1, rs_mod=1):
+        """mem [N*T1*HW, C], query [N*T2*HW, C] (= LN(tgt) + query_pos), residual [N*T2*HW, C] -> residual + rowscale * attn"""
+        C, nh, ws = self.dim, self.num_heads, self.window_size
+        p = self.dropout if self.training else 0.0
+        T2, H, W = g.T, g.H, g.W
+        padded = bool(H % ws or W % ws)
+        if padded:
+            mem, H, W = ops.pad_tokens(mem, g.N * T1, g.H, g.W, ws)
+            query = ops.pad_tokens(query, g.N * T2, g.H, g.W, ws)[0]
+        a = self.attn
+        Wq, Wk, Wv = a.in_proj_weight[:C], a.in_proj_weight[C:2 * C], a.in_proj_weight[2 * C:]
+        bq, bk, bv = a.in_proj_bias[:C], a.in_proj_bias[C:2 * C], a.in_proj_bias[2 * C:]
+        q_in = ops.add_rowtab(query, self._pos_table(Tlw, T1, T2, H, W), 1, T2 * H * W)
+        k_in = ops.add_rowtab(mem, self._pos_table(Tlw, 0, T1, H, W), 1, T1 * H * W)
+        q = ops.linear(q_in, Wq, bq, alpha=float(C // nh) ** -0.5)
+        k = ops.linear(k_in, Wk, bk)
+        v = ops.linear(mem, Wv, bv)
+        o = ops.temporal_spatial_window_attention(q, k, v, g.N, T2, T1, H, W, ws, nh, p, site)
+        if padded:
+            o = ops.crop_tokens(o, g.N * T2, H, W, g.H, g.W)
+        return ops.linear(o, a.out_proj.weight, a.out_proj.bias, residual=residual, rowscale=rowscale, rs_div=rs_div,
+                          rs_mod=rs_mod)
+
+
 class MlpDWBN(nn.Module):
     """Conv feed-forward 1x1 -> DW3x3 -> 1x1, each followed by norm + GELU (VidHRFormer_modules.py:376-442).
     AR_model=True (the constructor default, used by FAR and by every NAR *decoder* block) normalises with
@@ -269,9 +314,9 @@ class VidHRFormerBlockDecNAR(nn.Module):
         self.norm4 = nn.LayerNorm(embed_dim)
         self.TSLMA_flag = TSLMA_flag
         if TSLMA_flag:
-            raise NotImplementedError("TSLMA_flag=True (TemporalSpatialLocalMultiheadAttention) is a 'next' item "
-                                      "(SURVEY.md section 8f); every reference script uses TSLMA_flag=False")
-        self.EncDecAttn = nn.MultiheadAttention(embed_dim, num_heads, dropout=dropout)
+            self.TSLMA = TemporalSpatialLocalMultiheadAttention(embed_dim, num_heads, window_size, dropout)
+        else:
+            self.EncDecAttn = nn.MultiheadAttention(embed_dim, num_heads, dropout=dropout)
         self.SpatialFFN1 = MlpDWBN(encH, encW, embed_dim, hidden_features=hidden, out_features=embed_dim, drop=dropout)
         self.norm5 = nn.LayerNorm(embed_dim)
         self.norm6 = nn.LayerNorm(embed_dim)
@@ -279,9 +324,9 @@ class VidHRFormerBlockDecNAR(nn.Module):
         self.drop_path_p = drop_path
         self._site = 0
 
-    def forward_tokens(self, tgt, g, qpos_tab, qpos_tpos_tab, mem, mem_k, T1, lw_pos, tpos_f):
+    def forward_tokens(self, tgt, g, qpos_tab, qpos_tpos_tab, mem, mem_k, T1, lw_pos, tpos_f, Tlw_pos=None):
         """tgt [N*T2*HW, C]; qpos_tab = frame_queries as [T2*HW, C]; qpos_tpos_tab = frame_queries + tpos_f per (t, pixel);
-        mem, mem_k = memory and memory + past temporal pos, [N*T1*HW, C]; tpos_f (T2, C)."""
+        mem, mem_k = memory and memory + past temporal pos, [N*T1*HW, C]; tpos_f (T2, C); Tlw_pos (T1+T2, ws, ws, C)."""
         HW = g.H * g.W
         T2 = g.T
         p = self.dropout if self.training else 0.0
@@ -300,9 +345,16 @@ class VidHRFormerBlockDecNAR(nn.Module):
         x = ops.linear(h, self.linear2.weight, self.linear2.bias, residual=x, dropout_p=p, site=s + 6)
         # encoder-decoder attention; the reference applies drop_path1 to a (T2, N*HW, C) tensor, i.e. along TIME
         # (VidHRFormer_modules.py:204) -- reproduced: scale indexed by t = (row // HW) % T2
-        dpt = _droppath_scale(self.drop_path_p, self.training, T2, tgt.device)
-        _, uq = ops.layernorm(x, self.norm5.weight, self.norm5.bias, tab=qpos_tpos_tab, tab_div=1, tab_mod=per_n, eps=self.norm5.eps)
-        x = _mha_tokens(self.EncDecAttn, uq, mem_k, mem, x, g.N, T2, T1, HW, False, p, s + 7, rowscale=dpt, rs_div=HW, rs_mod=T2)
+        if self.TSLMA_flag:
+            # temporal-spatial window cross-attention (VidHRFormer_modules.py:195-199); here drop_path1 sees (N,T2,H,W,C): per sample
+            dp = _droppath_scale(self.drop_path_p, self.training, g.N, tgt.device)
+            _, uq = ops.layernorm(x, self.norm5.weight, self.norm5.bias, tab=qpos_tab, tab_div=1, tab_mod=per_n, eps=self.norm5.eps)
+            x = self.TSLMA.forward_tokens(mem, uq, x, g, T1, Tlw_pos, s + 7, rowscale=dp, rs_div=per_n, rs_mod=g.N)
+        else:
+            dpt = _droppath_scale(self.drop_path_p, self.training, T2, tgt.device)
+            _, uq = ops.layernorm(x, self.norm5.weight, self.norm5.bias, tab=qpos_tpos_tab, tab_div=1, tab_mod=per_n,
+                                  eps=self.norm5.eps)
+            x = _mha_tokens(self.EncDecAttn, uq, mem_k, mem, x, g.N, T2, T1, HW, False, p, s + 7, rowscale=dpt, rs_div=HW, rs_mod=T2)
         dp = _droppath_scale(self.drop_path_p, self.training, g.N, tgt.device)
         u = ops.layernorm(x, self.norm6.weight, self.norm6.bias, eps=self.norm6.eps)
         return self.SpatialFFN1.forward_tokens(u, x, g, s + 8, rowscale=dp, rs_div=per_n, rs_mod=g.N)
@@ -316,14 +368,14 @@ class VidHRformerDecoderNAR(nn.Module):
         self.norm = norm
         self.return_intermediate = return_intermediate
 
-    def forward_tokens(self, tgt, g, frame_queries, mem, T1, lw_pos, tpos_f, tpos_p):
+    def forward_tokens(self, tgt, g, frame_queries, mem, T1, lw_pos, tpos_f, tpos_p, Tlw_pos=None):
         HW, C = g.H * g.W, tgt.shape[1]
         qpos_tab = frame_queries.reshape(g.T * HW, C)
         qpos_tpos_tab = (frame_queries.reshape(g.T, HW, C) + tpos_f[:, None, :]).reshape(g.T * HW, C)
         mem_k = ops.add_rowtab(mem, tpos_p, HW, T1)
         x = tgt
         for layer in self.layers:
-            x = layer.forward_tokens(x, g, qpos_tab, qpos_tpos_tab, mem, mem_k, T1, lw_pos, tpos_f)
+            x = layer.forward_tokens(x, g, qpos_tab, qpos_tpos_tab, mem, mem_k, T1, lw_pos, tpos_f, Tlw_pos)
         if self.norm is not None:
             x = ops.layernorm(x, self.norm.weight, self.norm.bias, eps=self.norm.eps)
         return x
@@ -364,7 +416,7 @@ class VidHRFormerNAR(nn.Module):
         mem = self.encoder.forward_tokens(x, Geom(N, Tp, H, W), local_window_pos_embed, temporal_pos_embed[:Tp])
         tgt = torch.zeros((N * Tf * H * W, C), device=src.device, dtype=torch.float32)
         out = self.decoder.forward_tokens(tgt, Geom(N, Tf, H, W), query_pos, mem, Tp, local_window_pos_embed,
-                                          temporal_pos_embed[Tp:], temporal_pos_embed[:Tp])
+                                          temporal_pos_embed[Tp:], temporal_pos_embed[:Tp], TS_local_pos_embed)
         out = ops.tokens_to_nchw(out, N * Tf, C, H, W, relu=True).reshape(N, Tf, C, H, W)
         return out, mem.reshape(N, Tp, H, W, C)
 

@@ -460,6 +460,35 @@ def temporal_attention(q, k, v, Nb, Tq, Tk, HW, nh, causal=False, dropout_p=0.0,
     return _TAttnFn.apply(q, k, v, int(Nb), int(Tq), int(Tk), int(HW), int(nh), int(bool(causal)), float(dropout_p), int(site))
 
 
+class _TSAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, Nb, Tq, Tk, H, W, ws, nh, p, site):
+        q, k, v = _c(q), _c(k), _c(v)
+        C = q.shape[1]
+        o = torch.empty_like(q)
+        ctx.seed = seed_tensor(q.device) if p > 0 else None
+        check(lib.vptr_tsattn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), Nb, Tq, Tk, H, W, ws, C, nh, p, ptr(ctx.seed), site, stream()),
+              "vptr_tsattn_fwd")
+        ctx.save_for_backward(q, k, v)
+        ctx.cfg = (Nb, Tq, Tk, H, W, ws, nh, p, site)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v = ctx.saved_tensors
+        Nb, Tq, Tk, H, W, ws, nh, p, site = ctx.cfg
+        do = _c(do)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        check(lib.vptr_tsattn_bwd(ptr(q), ptr(k), ptr(v), ptr(do), ptr(dq), ptr(dk), ptr(dv), Nb, Tq, Tk, H, W, ws, q.shape[1], nh,
+                                  p, ptr(ctx.seed), site, stream()), "vptr_tsattn_bwd")
+        return dq, dk, dv, None, None, None, None, None, None, None, None, None
+
+
+def temporal_spatial_window_attention(q, k, v, Nb, Tq, Tk, H, W, ws, nh, dropout_p=0.0, site=0):
+    """q [(n,tq,h,w), C] pre-scaled; k, v [(n,tk,h,w), C]: every ws x ws window attends over (time x window) tokens."""
+    return _TSAttnFn.apply(q, k, v, int(Nb), int(Tq), int(Tk), int(H), int(W), int(ws), int(nh), float(dropout_p), int(site))
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # conv-FFN pieces
 # ------------------------------------------------------------------------------------------------------------------
