@@ -274,6 +274,73 @@ def step_case(ref, name, cfg, feat, HW, N, seed, steps=2):
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
 
 
+def nar_gan_step_case(ref, name, cfg, feat, HW, N, seed, steps=2, lam_gan=0.001):
+    """single_iter of train_NAR.py:49-107 WITH its optional adversarial branch (VPTR_Disc, optimizer_D, lam_gan; :66-79)."""
+    enc = ref.VPTREnc(1, feat_dim=feat, n_downsampling=3, padding_type="reflect").eval()
+    dec = ref.VPTRDec(1, feat_dim=feat, n_downsampling=3, out_layer="Tanh", padding_type="reflect").eval()
+    disc = ref.VPTRDisc(1, ndf=64, n_layers=3, norm_layer=torch.nn.BatchNorm2d)
+    T = build_nar(ref, cfg, seed + 20)
+    fill.apply_fill(enc, seed)
+    fill.apply_fill(dec, seed + 10)
+    fill.apply_fill(disc, seed + 30)
+    opt = torch.optim.AdamW(T.parameters(), lr=1e-4)
+    opt_D = torch.optim.Adam(disc.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    mse, gdl = ref.MSELoss(), ref.GDL(alpha=1)
+    nce = ref.BiPatchNCE(N, cfg["Tf"], cfg["H"], cfg["W"], 1.0)
+    gan = ref.GANLoss("vanilla", target_real_label=1.0, target_fake_label=0.0)
+    st = O.NARStep(dict(enc.state_dict()), dict(dec.state_dict()), dict(T.state_dict()), cfg, P_disc=dict(disc.state_dict()),
+                   lam_gan=lam_gan)
+    recs = []
+    for s in range(steps):
+        past = (fill.rand_input((N, cfg["Tp"], 1, HW, HW), seed + 100 + s) - 0.6013795) / 2.7570653
+        fut = (fill.rand_input((N, cfg["Tf"], 1, HW, HW), seed + 200 + s) - 0.6013795) / 2.7570653
+        with torch.no_grad():
+            pf, ff = enc(past), enc(fut)
+        T.train()
+        T.zero_grad(set_to_none=True)
+        dec.zero_grad(set_to_none=True)
+        pred_f = T(pf)
+        pred = dec(pred_f)
+        disc.train()
+        for p in disc.parameters():
+            p.requires_grad_(True)
+        disc.zero_grad(set_to_none=True)
+        l_fake = gan(disc(pred.detach().flatten(0, 1)), False)
+        l_real = gan(disc(fut.flatten(0, 1)), True)
+        loss_D = (l_fake + l_real) * 0.5 * lam_gan
+        loss_D.backward()
+        opt_D.step()
+        for p in disc.parameters():
+            p.requires_grad_(False)
+        a = T.NCE_projector(pred_f.permute(0, 1, 3, 4, 2)).permute(0, 1, 4, 2, 3)
+        b = T.NCE_projector(ff.permute(0, 1, 3, 4, 2)).permute(0, 1, 4, 2, 3)
+        l_mse, l_gdl = mse(pred, fut), gdl(fut, pred)
+        l_pc = nce(F.normalize(b, p=2.0, dim=2), F.normalize(a, p=2.0, dim=2))
+        t_gan = gan(disc(pred.flatten(0, 1)), True)
+        loss = l_gdl + l_mse + 0.1 * l_pc + lam_gan * t_gan
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(T.parameters(), max_norm=1.0, norm_type=2)
+        opt.step()
+        r = st.step(past, fut)
+        rec = {"T_total": loss.item(), "T_GDL": l_gdl.item(), "T_MSE": l_mse.item(), "T_bpc": l_pc.item(), "grad_norm": float(gn),
+               "Dtotal": loss_D.item(), "Dfake": l_fake.item(), "Dreal": l_real.item(), "T_gan": t_gan.item()}
+        for k in rec:
+            assert abs(rec[k] - r[k]) <= 2e-4 * abs(rec[k]) + 1e-7, (k, rec[k], r[k])
+        recs.append(rec)
+    e = max(rel(st.P_T[k], v) for k, v in T.state_dict().items() if v.is_floating_point())
+    ed = max(rel(st.P_disc[k], v) for k, v in disc.state_dict().items() if v.is_floating_point())
+    print(f"[{name}] {steps} NAR+GAN train steps: losses {recs}; post-step params oracle-vs-ref T {e:.2e} disc {ed:.2e}")
+    assert e < 1e-4 and ed < 1e-4
+    save = {"cfg": json.dumps(cfg), "meta": json.dumps(dict(feat=feat, HW=HW, N=N, seed=seed, steps=steps, lam_gan=lam_gan)),
+            "records": json.dumps(recs)}
+    for tag, mod in (("T", T), ("disc", disc)):
+        for k, v in mod.state_dict().items():
+            if v.is_floating_point() and k not in ("temporal_pos", "lw_pos", "Tlw_pos"):
+                flat = v.flatten()
+                save[f"post:{tag}:{k}"] = flat[::max(1, flat.numel() // 4096)].numpy()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
+
+
 def far_step_case(ref, name, cfg, feat, HW, N, seed, steps=2):
     """single_iter recipe of train_FAR.py:48-101 with the real reference modules (VPTR_Disc = None), dropout 0."""
     enc = ref.VPTREnc(1, feat_dim=feat, n_downsampling=3, padding_type="reflect").eval()
@@ -433,6 +500,7 @@ def main():
         ("ae_tiny_zero", lambda n: ae_case(ref, n, 3, 48, 32, 1, 2, "zero", "Sigmoid", 22)),
         ("losses_tiny", lambda n: losses_case(ref, n, 31)),
         ("step_tiny", lambda n: step_case(ref, n, dict(tiny, Tp=2, Tf=2), 48, 64, 2, 41)),
+        ("step_nar_gan_tiny", lambda n: nar_gan_step_case(ref, n, dict(tiny, Tp=2, Tf=2), 48, 64, 2, 91)),
         ("step_far_tiny", lambda n: far_step_case(ref, n, far_tiny, 48, 64, 2, 61)),
         ("step_ae_tiny", lambda n: ae_step_case(ref, n, 1, 48, 32, 2, 2, 81)),
         ("metrics_tiny", lambda n: metrics_case(ref, n)),

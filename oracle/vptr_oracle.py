@@ -435,8 +435,17 @@ class NARStep:
     backward, clip_grad_norm_(1.0) on the transformer params, AdamW(1e-4).  State lives in dicts of leaf tensors."""
 
     def __init__(self, P_enc, P_dec, P_T, cfg, padding_type="reflect", out_layer="Tanh", lr=1e-4, max_grad_norm=1.0,
-                 lam_pc=0.1):
+                 lam_pc=0.1, P_disc=None, lam_gan=None):
         self.cfg, self.padding_type, self.out_layer = cfg, padding_type, out_layer
+        self.lam_gan = lam_gan
+        self.P_disc = None
+        if P_disc is not None:   # optional adversarial branch (train_NAR.py:22-30,37-41,66-79), Adam(lr, betas (0.5, 0.999)) :204
+            self.P_disc = {k: v.detach().clone() for k, v in P_disc.items()}
+            for k, v in self.P_disc.items():
+                if v.is_floating_point() and not (k.endswith("running_mean") or k.endswith("running_var")):
+                    v.requires_grad_(True)
+            self.params_D = [v for v in self.P_disc.values() if v.requires_grad]
+            self.opt_D = torch.optim.Adam(self.params_D, lr=lr, betas=(0.5, 0.999))
         self.P_enc = {k: v.detach().clone() for k, v in P_enc.items()}
         self.P_dec = {k: v.detach().clone() for k, v in P_dec.items()}
         self.P_T = {k: v.detach().clone() for k, v in P_T.items()}
@@ -469,12 +478,27 @@ class NARStep:
         for v in self.P_dec.values():
             if v.requires_grad:
                 v.grad = None
-        loss, l_gdl, l_mse, l_pc, _ = self.forward_losses(past, future)
+        loss, l_gdl, l_mse, l_pc, pred_frames = self.forward_losses(past, future)
+        extra = {}
+        if self.P_disc is not None:
+            for p in self.params_D:
+                p.requires_grad_(True)
+                p.grad = None
+            l_fake = gan_loss_vanilla(disc_forward(self.P_disc, pred_frames.detach().flatten(0, 1), training=True), False)
+            l_real = gan_loss_vanilla(disc_forward(self.P_disc, future.flatten(0, 1), training=True), True)
+            loss_D = (l_fake + l_real) * 0.5 * self.lam_gan
+            loss_D.backward()
+            self.opt_D.step()
+            for p in self.params_D:
+                p.requires_grad_(False)
+            t_gan = gan_loss_vanilla(disc_forward(self.P_disc, pred_frames.flatten(0, 1), training=True), True)
+            loss = loss + self.lam_gan * t_gan
+            extra = {"Dtotal": loss_D.item(), "Dfake": l_fake.item(), "Dreal": l_real.item(), "T_gan": t_gan.item()}
         loss.backward()
         gn = torch.nn.utils.clip_grad_norm_(self.params_T, self.max_grad_norm)
         self.opt.step()
-        return {"T_total": loss.item(), "T_GDL": l_gdl.item(), "T_MSE": l_mse.item(), "T_bpc": l_pc.item(),
-                "grad_norm": float(gn)}
+        return dict({"T_total": loss.item(), "T_GDL": l_gdl.item(), "T_MSE": l_mse.item(), "T_bpc": l_pc.item(),
+                     "grad_norm": float(gn)}, **extra)
 
 
 class FARStep:

@@ -58,3 +58,24 @@ def post_step_params_close(state_dict, z, rel_tol=1e-4, lr=1e-4, max_flip_frac=0
     assert relerr < rel_tol, relerr
     assert bad <= max_flip_frac * tot, (bad, tot)
     return relerr
+
+
+def sampled_post_params_close(state_dicts, z, lr, rel_tol, max_flip_frac=0.03):
+    """as post_step_params_close, for fixtures that keep a strided sample (<= ~4096 elements) of every tensor under
+    `post:<tag>:<name>`; state_dicts maps tag -> state_dict"""
+    num = den = 0.0
+    bad = tot = 0
+    for k in z.files:
+        if not k.startswith("post:"):
+            continue
+        _, tag, name = k.split(":", 2)
+        flat = state_dicts[tag][name].detach().cpu().double().flatten()
+        d = flat[::max(1, flat.numel() // 4096)] - torch.from_numpy(z[k]).double()
+        num += float((d * d).sum())
+        den += float((torch.from_numpy(z[k]).double() ** 2).sum())
+        bad += int((d.abs() > 0.5 * lr).sum())
+        tot += d.numel()
+    relerr = (num / den) ** 0.5
+    assert relerr < rel_tol, relerr
+    assert bad <= max_flip_frac * tot, (bad, tot)
+    return relerr

@@ -369,3 +369,25 @@ def test_metrics_match_reference_golden():
         assert abs(M.MSEScore(x, y) - e["mse"]) < 1e-5 * abs(e["mse"])
         assert abs(float(M.SSIM()(x, y)) - e["ssim"]) < 2e-6
         assert np.allclose(M.SSIM(size_average=False)(x, y).numpy(), np.array(e["ssim_each"]), atol=2e-6)
+
+
+def test_oracle_nar_gan_step_golden():
+    z = load("step_nar_gan_tiny")
+    cfg, meta = jload(z, "cfg"), jload(z, "meta")
+    import vptr_amd.model as M
+    enc = M.VPTREnc(1, meta["feat"], 3, "reflect")
+    dec = M.VPTRDec(1, meta["feat"], 3, "Tanh", "reflect")
+    disc = M.VPTRDisc(1, ndf=64, n_layers=3)
+    T = build_transformer(M, cfg, False)
+    fill.apply_fill(enc, meta["seed"])
+    fill.apply_fill(dec, meta["seed"] + 10)
+    fill.apply_fill(T, meta["seed"] + 20)
+    fill.apply_fill(disc, meta["seed"] + 30)
+    st = O.NARStep(dict(enc.state_dict()), dict(dec.state_dict()), dict(T.state_dict()), cfg, P_disc=dict(disc.state_dict()),
+                   lam_gan=meta["lam_gan"])
+    for s, ref in enumerate(jload(z, "records")):
+        past = (fill.rand_input((meta["N"], cfg["Tp"], 1, meta["HW"], meta["HW"]), meta["seed"] + 100 + s) - 0.6013795) / 2.7570653
+        fut = (fill.rand_input((meta["N"], cfg["Tf"], 1, meta["HW"], meta["HW"]), meta["seed"] + 200 + s) - 0.6013795) / 2.7570653
+        r = st.step(past, fut)
+        for k in ref:
+            assert abs(r[k] - ref[k]) <= 2e-4 * abs(ref[k]) + 1e-7, (k, r[k], ref[k])

@@ -112,8 +112,9 @@ class NARTrainer:
     """One stage-2 NAR training step; see module docstring.  `enc`/`dec` are frozen (eval), `transformer` trains."""
 
     def __init__(self, enc, dec, transformer, batch_size, lr=1e-4, max_grad_norm=1.0, lam_pc=0.1, process_group=None,
-                 bucket_mb=64, dec_weight_grads=True):
+                 bucket_mb=64, dec_weight_grads=True, disc=None, lam_gan=None, gan_mode="vanilla"):
         self.enc, self.dec, self.T = enc.eval(), dec.eval(), transformer
+        self._init_gan(disc, lam_gan, lr, gan_mode)
         # Stage 2 optimises the transformer only (train_NAR.py:205).  The reference nevertheless leaves the decoder's
         # parameters trainable (:190-191), so its backward computes decoder weight gradients nobody consumes; that work
         # is reproduced by default (dec_weight_grads=True) so that the measured step does everything the reference's does.
@@ -133,6 +134,33 @@ class NARTrainer:
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.bucket_elems = bucket_mb * (1 << 20) // 4
         self._graph = None
+
+    # -- optional adversarial branch (train_NAR.py:22-30,37-41,66-79; train_FAR.py:22-45,66-80): off in the reference scripts ----
+    def _init_gan(self, disc, lam_gan, lr, gan_mode):
+        self.disc, self.lam_gan = disc, lam_gan
+        if disc is None:
+            return
+        if lam_gan is None:
+            raise ValueError("a discriminator needs lam_gan (train_NAR.py:67)")
+        for p in disc.parameters():
+            p.requires_grad_(True)
+        self.opt_D = FlatAdamW(list(disc.parameters()), lr=lr, betas=(0.5, 0.999), weight_decay=0.0)  # Adam, :204
+        self.gan = GANLoss(gan_mode, target_real_label=1.0, target_fake_label=0.0).to(self.opt_D.flat.device)
+
+    def _disc_update(self, fake, real):
+        """cal_lossD + optimizer_D.step(), then freeze the discriminator for the generator pass"""
+        self.disc.train()
+        for p in self.disc.parameters():
+            p.requires_grad_(True)
+        self.opt_D.zero_grad()
+        l_fake = self.gan(self.disc(fake.detach().flatten(0, 1)), False)
+        l_real = self.gan(self.disc(real.flatten(0, 1)), True)
+        loss_D = (l_fake + l_real) * 0.5 * self.lam_gan
+        loss_D.backward()
+        self.opt_D.step()
+        for p in self.disc.parameters():
+            p.requires_grad_(False)
+        return {"Dtotal": loss_D.detach(), "Dfake": l_fake.detach(), "Dreal": l_real.detach()}
 
     # -- data-parallel gradient exchange: a few large RCCL all-reduces on the flat gradient slab ---------------------
     def _allreduce_grads(self):
@@ -164,13 +192,20 @@ class NARTrainer:
             self.dec.zero_grad(set_to_none=True)  # train_NAR.py:61
         pred_feats = self.T(past_feats)
         pred_frames = self.dec(pred_feats)
+        extra = {}
+        if self.disc is not None:
+            extra = self._disc_update(pred_frames, future)
         loss, l_gdl, l_mse, l_pc = self.losses(pred_frames, future, pred_feats, future_feats)
+        if self.disc is not None:
+            extra["T_gan"] = self.gan(self.disc(pred_frames.flatten(0, 1)), True)
+            loss = loss + self.lam_gan * extra["T_gan"]
+            extra["T_gan"] = extra["T_gan"].detach()
         loss.backward()
         ops.flush_wgrads()  # no-op: the grouped weight-gradient launch already ran at the end of backward
         self._allreduce_grads()
         self.opt.step()
-        return {"T_total": loss.detach(), "T_GDL": l_gdl.detach(), "T_MSE": l_mse.detach(), "T_bpc": l_pc.detach(),
-                "grad_norm": self.opt.grad_norm()}
+        return dict({"T_total": loss.detach(), "T_GDL": l_gdl.detach(), "T_MSE": l_mse.detach(), "T_bpc": l_pc.detach(),
+                     "grad_norm": self.opt.grad_norm()}, **extra)
 
     def step(self, past, future):
         if self._graph is not None:
@@ -216,8 +251,10 @@ class FARTrainer(NARTrainer):
     kernel flag), Dec, MSE + GDL against cat(past[:, 1:], future), backward, clip_grad_norm_(max_norm), AdamW.  Shares the
     flat-slab optimizer, grouped weight gradients and data-parallel exchange with `NARTrainer`."""
 
-    def __init__(self, enc, dec, transformer, lr=1e-4, max_grad_norm=1.0, process_group=None, bucket_mb=64, dec_weight_grads=True):
+    def __init__(self, enc, dec, transformer, lr=1e-4, max_grad_norm=1.0, process_group=None, bucket_mb=64, dec_weight_grads=True,
+                 disc=None, lam_gan=None, gan_mode="vanilla"):
         self.enc, self.dec, self.T = enc.eval(), dec.eval(), transformer
+        self._init_gan(disc, lam_gan, lr, gan_mode)
         for p in enc.parameters():
             p.requires_grad_(False)
         for p in dec.parameters():
@@ -240,15 +277,23 @@ class FARTrainer(NARTrainer):
         if self.dec_weight_grads:
             self.dec.zero_grad(set_to_none=True)
         pred_frames = self.dec(self.T(gt_feats))
+        extra = {}
+        if self.disc is not None:                                            # cal_lossD(VPTR_Disc, pred_frames, future_frames) :72
+            extra = self._disc_update(pred_frames, future)
         real = torch.cat([past[:, 1:], future], dim=1)                       # :80
         l_mse = self.mse(pred_frames, real)                                  # cal_lossT :32-46
         l_gdl = self.gdl(real, pred_frames)
         loss = l_gdl + l_mse
+        if self.disc is not None:
+            t_gan = self.gan(self.disc(pred_frames.flatten(0, 1)), True)
+            loss = loss + self.lam_gan * t_gan
+            extra["T_gan"] = t_gan.detach()
         loss.backward()
         ops.flush_wgrads()
         self._allreduce_grads()
         self.opt.step()
-        return {"T_total": loss.detach(), "T_GDL": l_gdl.detach(), "T_MSE": l_mse.detach(), "grad_norm": self.opt.grad_norm()}
+        return dict({"T_total": loss.detach(), "T_GDL": l_gdl.detach(), "T_MSE": l_mse.detach(), "grad_norm": self.opt.grad_norm()},
+                    **extra)
 
     @torch.no_grad()
     def predict(self, past, num_pred):
