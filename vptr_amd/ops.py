@@ -545,7 +545,9 @@ class _NormActFn(torch.autograd.Function):
         dy = _c(dy)
         rows, F = x.shape
         dx = torch.empty_like(x)
-        dw, db = torch.zeros_like(w), torch.zeros_like(b)
+        sw, sb = flat_grad_for(w), flat_grad_for(b)   # accumulate straight into the flat gradient slab when both live there
+        in_slab = sw is not None and sb is not None
+        dw, db = (sw, sb) if in_slab else (torch.zeros_like(w), torch.zeros_like(b))
         frames = rows // HW
         scratch = torch.empty((max(2 * F, 2 * frames * (1 + 4 * ((HW * F // 4 + 255) // 256))),), device=x.device, dtype=torch.float32)
         check(lib.vptr_norm_act_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(b), ptr(dx), ptr(dw), ptr(db),
@@ -553,6 +555,8 @@ class _NormActFn(torch.autograd.Function):
                                     ptr(ctx.seed), site, ptr(rowscale), rs_div, rs_mod,
                                     stream()), "vptr_norm_act_bwd")
         dres = dy if has_res else None
+        if in_slab:
+            dw = db = None
         return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None, dres
 
 
@@ -572,6 +576,7 @@ class _DWConvFn(torch.autograd.Function):
         check(lib.vptr_dwconv3x3_fwd(ptr(x), ptr(w9), ptr(b), ptr(y), frames, H, W, F, stream()), "vptr_dwconv3x3_fwd")
         ctx.save_for_backward(x, w9)
         ctx.cfg = (frames, H, W)
+        ctx.bias_ref = b.detach() if b is not None else None
         return y
 
     @staticmethod
@@ -581,10 +586,14 @@ class _DWConvFn(torch.autograd.Function):
         dy = _c(dy)
         F = x.shape[1]
         dx = torch.empty_like(x)
-        dw9 = torch.zeros_like(w9)
-        db = torch.zeros((F,), device=x.device, dtype=torch.float32)
+        sw, sb = flat_grad_for(w9), flat_grad_for(ctx.bias_ref)
+        in_slab = sw is not None and sb is not None
+        dw9 = sw if in_slab else torch.zeros_like(w9)
+        db = sb if in_slab else torch.zeros((F,), device=x.device, dtype=torch.float32)
         check(lib.vptr_dwconv3x3_bwd(ptr(dy), ptr(x), ptr(w9), ptr(dx), ptr(dw9), ptr(db), frames, H, W, F, stream()),
               "vptr_dwconv3x3_bwd")
+        if in_slab:
+            dw9 = db = None
         return dx, dw9, db, None, None, None
 
 

@@ -23,8 +23,13 @@ class FlatAdamW:
     """torch.optim.AdamW semantics (lr, betas, eps, decoupled weight decay, bias correction) on one flat slab, with
     clip_grad_norm_ folded in.  Every parameter must receive a gradient each step (true for the VPTR transformers)."""
 
-    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None):
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None, channel_last=()):
+        """channel_last: ids of [C, ...] parameters that the kernels consume channel-last (the (C,H,W) LayerNorm affines and
+        the depthwise 3x3 weights of MlpDWBN): they are STORED channel-last in the slab and exposed as a permuted view of
+        their usual shape, so no per-step transposes of the parameter or its gradient remain (AdamW is elementwise, the
+        order inside the slab is irrelevant; state_dict / load_state_dict go through strided copies)."""
         self.params = [p for p in params if p.requires_grad]
+        channel_last = set(channel_last)
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
         pad = (-total) % 4
@@ -36,9 +41,18 @@ class FlatAdamW:
         with torch.no_grad():
             for p in self.params:
                 n = p.numel()
-                self.flat[off:off + n].copy_(p.detach().reshape(-1))
-                p.data = self.flat[off:off + n].view(p.shape)
-                p.grad = self.grad[off:off + n].view(p.shape)
+                if id(p) in channel_last and p.dim() >= 2:
+                    perm = list(range(1, p.dim())) + [0]                  # storage order: trailing dims, then channels
+                    inv = [p.dim() - 1] + list(range(p.dim() - 1))
+                    shape_cl = [p.shape[i] for i in perm]
+                    val = p.detach().clone()
+                    p.data = self.flat[off:off + n].view(shape_cl).permute(inv)
+                    p.data.copy_(val)
+                    p.grad = self.grad[off:off + n].view(shape_cl).permute(inv)
+                else:
+                    self.flat[off:off + n].copy_(p.detach().reshape(-1))
+                    p.data = self.flat[off:off + n].view(p.shape)
+                    p.grad = self.grad[off:off + n].view(p.shape)
                 off += n
         self.total = total
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
@@ -108,6 +122,19 @@ class FlatAdamW:
                              float(self.max_grad_norm or 0.0), 1.0, stream()), "vptr_adamw")
 
 
+def _channel_last_ids(transformer):
+    """parameters of the conv-FFNs that the HIP kernels read channel-last: LayerNorm((C,H,W)) affines and depthwise 3x3 weights"""
+    from .model.vidhrformer import MlpDWBN
+    ids = []
+    for m in transformer.modules():
+        if isinstance(m, MlpDWBN):
+            ids.append(id(m.dw3x3.weight))
+            if m.layer_norm:
+                for norm in (m.norm1, m.norm2, m.norm3):
+                    ids += [id(norm.weight), id(norm.bias)]
+    return ids
+
+
 class NARTrainer:
     """One stage-2 NAR training step; see module docstring.  `enc`/`dec` are frozen (eval), `transformer` trains."""
 
@@ -125,7 +152,7 @@ class NARTrainer:
         self.dec_weight_grads = bool(dec_weight_grads)
         for mod in list(self.enc.modules()) + list(self.dec.modules()):
             mod._vptr_frozen = True  # never stepped here: packed conv weights / eval-BN folds are cached (ops.frozen_weights)
-        self.opt = FlatAdamW(self.T.parameters(), lr=lr, max_grad_norm=max_grad_norm)
+        self.opt = FlatAdamW(self.T.parameters(), lr=lr, max_grad_norm=max_grad_norm, channel_last=_channel_last_ids(self.T))
         dev = self.opt.flat.device
         self.mse, self.gdl = MSELoss(), GDL(alpha=1)
         self.bpnce = BiPatchNCE(batch_size, self.T.num_future_frames, self.T.transformer.H, self.T.transformer.W, 1.0).to(dev)
@@ -262,7 +289,7 @@ class FARTrainer(NARTrainer):
         self.dec_weight_grads = bool(dec_weight_grads)
         for mod in list(self.enc.modules()) + list(self.dec.modules()):
             mod._vptr_frozen = True
-        self.opt = FlatAdamW(self.T.parameters(), lr=lr, max_grad_norm=max_grad_norm)
+        self.opt = FlatAdamW(self.T.parameters(), lr=lr, max_grad_norm=max_grad_norm, channel_last=_channel_last_ids(self.T))
         self.mse, self.gdl = MSELoss(), GDL(alpha=1)
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
