@@ -164,9 +164,11 @@ int vptr_tsattn_bwd(const float* q, const float* k, const float* v, const float*
  *   group_rows == rows : BatchNorm2d batch statistics per channel  -> mean[F], var[F] (biased)
  *   group_rows == HW   : LayerNorm((F,H,W)) statistics per frame   -> mean[frames], var[frames]
  * ---------------------------------------------------------------------------------------------- */
-int vptr_colstats(const float* x, float* mean, float* var, float* scratch /* >= 2*F*ceil(rows/256) floats */, int rows,
-                  int F, vptr_stream_t stream);
-int vptr_groupstats(const float* x, float* mean, float* var, int groups, int group_elems, vptr_stream_t stream);
+/* rstd (optional, may be NULL) = 1/sqrt(var + eps), written by the same launch */
+int vptr_colstats(const float* x, float* mean, float* var, float* rstd, float eps,
+                  float* scratch /* >= 2*F*ceil(rows/256) floats */, int rows, int F, vptr_stream_t stream);
+int vptr_groupstats(const float* x, float* mean, float* var, float* rstd, float eps, int groups, int group_elems,
+                    vptr_stream_t stream);
 /* y = rowscale[(row/rs_div)%rs_mod] * dropout(act( (x - mean)*rstd * w + b )) + residual
  * per_col != 0: stats indexed by column (BN), affine [F];
  * per_col == 0: stats indexed by row / HW (LN over (F,H,W)), affine given channel-last as [HW, F].

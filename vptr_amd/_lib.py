@@ -54,8 +54,8 @@ SIGNATURES = {
     "vptr_tattn_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, P, U, P],
     "vptr_tsattn_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, F, P, U, P],
     "vptr_tsattn_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P, U, P],
-    "vptr_colstats": [P, P, P, P, I, I, P],
-    "vptr_groupstats": [P, P, P, I, I, P],
+    "vptr_colstats": [P, P, P, P, F, P, I, I, P],
+    "vptr_groupstats": [P, P, P, P, F, I, I, P],
     "vptr_norm_act_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, P, U, P, I, I, P, P],
     "vptr_norm_act_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, P, I, I, P],
     "vptr_dwconv3x3_fwd": [P, P, P, P, I, I, I, I, P],

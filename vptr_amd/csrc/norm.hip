@@ -325,7 +325,8 @@ __global__ __launch_bounds__(256) void colstats_partial_kernel(const float* __re
   scratch[((int64_t)blockIdx.y * F + c) * 2 + 1] = m2;
 }
 __global__ __launch_bounds__(256) void colstats_final_kernel(const float* __restrict__ scratch, float* __restrict__ mean,
-                                                             float* __restrict__ var, int rows, int F, int nchunk) {
+                                                             float* __restrict__ var, float* __restrict__ rstd, float eps,
+                                                             int rows, int F, int nchunk) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= F) return;
   float n = 0.f, mu = 0.f, m2 = 0.f;
@@ -339,21 +340,24 @@ __global__ __launch_bounds__(256) void colstats_final_kernel(const float* __rest
   }
   mean[c] = mu;
   var[c] = m2 / n;
+  if (rstd) rstd[c] = rsqrtf(m2 / n + eps);
 }
 
-extern "C" int vptr_colstats(const float* x, float* mean, float* var, float* scratch, int rows, int F, vptr_stream_t stream) {
+extern "C" int vptr_colstats(const float* x, float* mean, float* var, float* rstd, float eps, float* scratch, int rows, int F,
+                             vptr_stream_t stream) {
   VPTR_CHECK(rows > 0 && F > 0 && scratch, "colstats: bad arguments");
   const int nchunk = cdiv(rows, 256);
   hipStream_t st = (hipStream_t)stream;
   colstats_partial_kernel<<<dim3(cdiv(F, 256), nchunk), 256, 0, st>>>(x, scratch, rows, F);
-  colstats_final_kernel<<<cdiv(F, 256), 256, 0, st>>>(scratch, mean, var, rows, F, nchunk);
+  colstats_final_kernel<<<cdiv(F, 256), 256, 0, st>>>(scratch, mean, var, rstd, eps, rows, F, nchunk);
   VPTR_LAUNCH_CHECK();
   return 0;
 }
 
 // groupstats: mean / biased variance of each contiguous group of `group_elems` floats (LayerNorm((F,H,W)) per frame).
 __global__ __launch_bounds__(1024) void groupstats_kernel(const float* __restrict__ x, float* __restrict__ mean,
-                                                          float* __restrict__ var, int group_elems) {
+                                                          float* __restrict__ var, float* __restrict__ rstd, float eps,
+                                                          int group_elems) {
   __shared__ float red[16];
   const float* g = x + (int64_t)blockIdx.x * group_elems;
   const int n4 = group_elems >> 2;
@@ -372,12 +376,17 @@ __global__ __launch_bounds__(1024) void groupstats_kernel(const float* __restric
   }
   for (int i = (n4 << 2) + threadIdx.x; i < group_elems; i += 1024) { const float a = g[i] - mu; q += a * a; }
   const float vv = block_sum(q, red) / (float)group_elems;
-  if (threadIdx.x == 0) { mean[blockIdx.x] = mu; var[blockIdx.x] = vv; }
+  if (threadIdx.x == 0) {
+    mean[blockIdx.x] = mu;
+    var[blockIdx.x] = vv;
+    if (rstd) rstd[blockIdx.x] = rsqrtf(vv + eps);
+  }
 }
 
-extern "C" int vptr_groupstats(const float* x, float* mean, float* var, int groups, int group_elems, vptr_stream_t stream) {
+extern "C" int vptr_groupstats(const float* x, float* mean, float* var, float* rstd, float eps, int groups, int group_elems,
+                               vptr_stream_t stream) {
   VPTR_CHECK(groups > 0 && group_elems > 0 && group_elems % 4 == 0, "groupstats: bad arguments");
-  groupstats_kernel<<<groups, 1024, 0, (hipStream_t)stream>>>(x, mean, var, group_elems);
+  groupstats_kernel<<<groups, 1024, 0, (hipStream_t)stream>>>(x, mean, var, rstd, eps, group_elems);
   VPTR_LAUNCH_CHECK();
   return 0;
 }

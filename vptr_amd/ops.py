@@ -515,20 +515,22 @@ class _NormActFn(torch.autograd.Function):
                 var = torch.empty_like(mean)
                 nchunk = (rows + 255) // 256
                 scratch = torch.empty((2 * F * nchunk,), device=dev, dtype=torch.float32)
-                check(lib.vptr_colstats(ptr(x), ptr(mean), ptr(var), ptr(scratch), rows, F, stream()), "vptr_colstats")
+                rstd = torch.empty_like(mean)
+                check(lib.vptr_colstats(ptr(x), ptr(mean), ptr(var), ptr(rstd), eps, ptr(scratch), rows, F, stream()), "vptr_colstats")
                 if running_mean is not None:
                     with torch.no_grad():
                         running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
                         running_var.mul_(1 - momentum).add_(var, alpha=momentum * rows / max(rows - 1, 1))
             else:
                 mean, var = running_mean, running_var
+                rstd = torch.rsqrt(var + eps)
                 const_stats = True
         else:
             frames = rows // HW
             mean = torch.empty((frames,), device=dev, dtype=torch.float32)
             var = torch.empty_like(mean)
-            check(lib.vptr_groupstats(ptr(x), ptr(mean), ptr(var), frames, HW * F, stream()), "vptr_groupstats")
-        rstd = torch.rsqrt(var + eps)
+            rstd = torch.empty_like(mean)
+            check(lib.vptr_groupstats(ptr(x), ptr(mean), ptr(var), ptr(rstd), eps, frames, HW * F, stream()), "vptr_groupstats")
         y = torch.empty_like(x)
         ctx.seed = seed_tensor(dev) if p > 0 else None
         check(lib.vptr_norm_act_fwd(ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(b), ptr(y), rows, F, HW, int(per_col), act, p,
