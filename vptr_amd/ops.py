@@ -145,24 +145,27 @@ def gemm_nfn(N):
 # backward pass's weight gradients run as ONE vptr_gemm_grouped launch, queued on the autograd engine's end-of-backward
 # callback: every tile then runs the full K loop and writes once.
 _wgrad_q = []
-_wgrad_cb = [False]
 
 
 def defer_wgrad(g, x, dW, N, K, M, db=None):
     """record dW[N,K] += g[M,N]^T . x[M,K] (dW, and db if given, must be views of a flat gradient slab); with db the bias
     gradient db[N] += column sums of g rides on the same launch (vptr_gemm_desc::a_rowsum)"""
     _wgrad_q.append((g, x, dW, N, K, M, config.gemm_precision, db))
-    if not _wgrad_cb[0]:
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
-            _wgrad_cb[0] = True
-        except RuntimeError:  # not inside a backward pass: the caller flushes explicitly
-            pass
+    # one end-of-backward callback per recorded call: flush_wgrads is idempotent, and registering every time stays correct
+    # when an earlier backward died before its callbacks ran (a "callback already queued" flag would then be stale)
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+    except RuntimeError:  # not inside a backward pass: the caller flushes explicitly
+        pass
+
+
+def discard_wgrads():
+    """drop recorded weight gradients that were never launched (a backward pass that raised); called by FlatAdamW.zero_grad"""
+    del _wgrad_q[:]
 
 
 def flush_wgrads():
     """launch every recorded weight gradient (idempotent; runs automatically at the end of a backward pass)"""
-    _wgrad_cb[0] = False
     if not _wgrad_q:
         return
     items = list(_wgrad_q)

@@ -103,6 +103,7 @@ class FlatAdamW:
         p0 = self.params[0]
         if p0.grad is None or p0.grad.data_ptr() != self.grad.data_ptr():
             raise RuntimeError("FlatAdamW: a parameter lost its flat gradient view (do not use set_to_none=True)")
+        ops.discard_wgrads()  # leftovers of a backward pass that raised must not leak into this step
         self.grad.zero_()
 
     def grad_norm(self):
