@@ -72,6 +72,166 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// fast paths for 16-token problems (4x4 windows; T <= 16 time steps further down).  The 16 x 16 score matrix is one
+// element per thread (window) or per lane-round (time), so the softmax reductions (max, sum, and sum(dP * P) in the
+// backward) are 16-lane shuffles instead of a serial loop on 16 threads; global loads are float2; the LDS tiles have a
+// 16-byte-aligned pitch of an ODD number of float4 (68 floats for head dim 66, zero padded), which makes the 16 row reads
+// of a score dot product conflict-free ds_read_b128 -- the first versions of these kernels were bound by ds_read_b32 count.
+// ------------------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int att_pitch(int hd) {
+  int q = (hd + 3) / 4;
+  if ((q & 1) == 0) ++q;
+  return q * 4;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64)); v = fmaxf(v, __shfl_xor(v, 4, 64));
+  v = fmaxf(v, __shfl_xor(v, 8, 64));
+  return v;
+}
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+__device__ __forceinline__ void axpy4(float4& y, const float a, const float4 x) { y.x += a * x.x; y.y += a * x.y; y.z += a * x.z; y.w += a * x.w; }
+// rows[l] * C + hoff .. + hd of a token-major tensor -> LDS [nrows][hp] (columns hd .. hp-1 zeroed); hd even
+__device__ __forceinline__ void stage_rows(const float* __restrict__ src, float* dst, const int64_t* rowoff, int nrows, int hoff, int hd,
+                                           int hp, int tid, int nthreads) {
+  const int h2 = hp >> 1, v2 = hd >> 1;
+  for (int e = tid; e < nrows * h2; e += nthreads) {
+    const int l = e / h2, d2 = e - l * h2;
+    float2 v = make_float2(0.f, 0.f);
+    if (d2 < v2) v = *reinterpret_cast<const float2*>(src + rowoff[l] + hoff + 2 * d2);
+    *reinterpret_cast<float2*>(dst + l * hp + 2 * d2) = v;
+  }
+}
+// out rows: dst[rowoff[r] + hoff + d] = acc (hd even; float2 stores)
+__device__ __forceinline__ void store4(float* __restrict__ dst, int64_t base, int d, int hd, const float4 v) {
+  *reinterpret_cast<float2*>(dst + base + d) = make_float2(v.x, v.y);
+  if (d + 2 < hd) *reinterpret_cast<float2*>(dst + base + d + 2) = make_float2(v.z, v.w);
+}
+
+__global__ __launch_bounds__(256) void winattn16_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, const float* __restrict__ table,
+                                                            const int64_t* __restrict__ rel_index, float* __restrict__ o,
+                                                            int nwin, int H, int W, int C, int nh, float p,
+                                                            const uint64_t* seed_dev, uint32_t site, int wpb) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int hd = C / nh, hp = att_pitch(hd), n4 = hp >> 2;
+  float* sq = smem;             // [16][hp]
+  float* sk = sq + 16 * hp;
+  float* sv = sk + 16 * hp;
+  float* sp = sv + 16 * hp;     // [16][20]
+  __shared__ int64_t srow[16];
+  const int h = blockIdx.y, tid = threadIdx.x, i = tid >> 4, j = tid & 15;
+  const int nqh = H / 4, nqw = W / 4;
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  const float bias = table ? table[rel_index[tid] * nh + h] : 0.f;   // element (i, j) of the relative-position bias
+  const int w0 = blockIdx.x * wpb, w1 = min(nwin, w0 + wpb);
+  for (int win = w0; win < w1; ++win) {
+    __syncthreads();
+    if (tid < 16) srow[tid] = (int64_t)win_row(win, tid, H, W, 4, nqh, nqw) * C;
+    __syncthreads();
+    stage_rows(q, sq, srow, 16, h * hd, hd, hp, tid, 256);
+    stage_rows(k, sk, srow, 16, h * hd, hd, hp, tid, 256);
+    stage_rows(v, sv, srow, 16, h * hd, hd, hp, tid, 256);
+    __syncthreads();
+    float a = bias;
+    for (int d = 0; d < n4; ++d)
+      a += dot4(reinterpret_cast<const float4*>(sq + i * hp)[d], reinterpret_cast<const float4*>(sk + j * hp)[d]);
+    const float m = row16_max(a);
+    const float e = __expf(a - m);
+    float pr = e / row16_sum(e);
+    if (p > 0.f) pr *= vptr_drop_scale(seed, site, ((uint64_t)(win * nh + h) * 16 + i) * 16 + j, p);
+    sp[i * 20 + j] = pr;
+    __syncthreads();
+    for (int e2 = tid; e2 < 16 * n4; e2 += 256) {
+      const int r = e2 / n4, d4 = e2 - r * n4;
+      if (d4 * 4 >= hd) continue;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+      for (int c = 0; c < 16; ++c) axpy4(acc, sp[r * 20 + c], reinterpret_cast<const float4*>(sv + c * hp)[d4]);
+      store4(o, srow[r] + h * hd, d4 * 4, hd, acc);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void winattn16_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, const float* __restrict__ table,
+                                                            const int64_t* __restrict__ rel_index, const float* __restrict__ dout,
+                                                            float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+                                                            float* __restrict__ dtable, int nwin, int H, int W, int C, int nh,
+                                                            float p, const uint64_t* seed_dev, uint32_t site, int wpb) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int hd = C / nh, hp = att_pitch(hd), n4 = hp >> 2;
+  float* sq = smem;             // [16][hp]
+  float* sk = sq + 16 * hp;
+  float* sv = sk + 16 * hp;
+  float* sdo = sv + 16 * hp;
+  float* sp = sdo + 16 * hp;    // [16][20]  dropped probabilities (for dV)
+  float* sds = sp + 16 * 20;    // [16][20]  dS
+  __shared__ int64_t srow[16];
+  const int h = blockIdx.y, tid = threadIdx.x, i = tid >> 4, j = tid & 15;
+  const int nqh = H / 4, nqw = W / 4;
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  const int ridx = (table || dtable) ? (int)rel_index[tid] : 0;
+  const float bias = table ? table[ridx * nh + h] : 0.f;
+  float dbias = 0.f;  // this thread's (i, j) element of dS summed over the workgroup's windows
+  const int w0 = blockIdx.x * wpb, w1 = min(nwin, w0 + wpb);
+  for (int win = w0; win < w1; ++win) {
+    __syncthreads();
+    if (tid < 16) srow[tid] = (int64_t)win_row(win, tid, H, W, 4, nqh, nqw) * C;
+    __syncthreads();
+    stage_rows(q, sq, srow, 16, h * hd, hd, hp, tid, 256);
+    stage_rows(k, sk, srow, 16, h * hd, hd, hp, tid, 256);
+    stage_rows(v, sv, srow, 16, h * hd, hd, hp, tid, 256);
+    stage_rows(dout, sdo, srow, 16, h * hd, hd, hp, tid, 256);
+    __syncthreads();
+    float a = bias, b = 0.f;
+    for (int d = 0; d < n4; ++d) {
+      a += dot4(reinterpret_cast<const float4*>(sq + i * hp)[d], reinterpret_cast<const float4*>(sk + j * hp)[d]);
+      b += dot4(reinterpret_cast<const float4*>(sdo + i * hp)[d], reinterpret_cast<const float4*>(sv + j * hp)[d]);
+    }
+    const float m = row16_max(a);
+    const float e = __expf(a - m);
+    const float pr = e / row16_sum(e);
+    const float sc = p > 0.f ? vptr_drop_scale(seed, site, ((uint64_t)(win * nh + h) * 16 + i) * 16 + j, p) : 1.f;
+    const float dpr = b * sc;                       // gradient w.r.t. the softmax probability
+    const float ds = pr * (dpr - row16_sum(dpr * pr));
+    dbias += ds;
+    sp[i * 20 + j] = pr * sc;
+    sds[i * 20 + j] = ds;
+    __syncthreads();
+    for (int e2 = tid; e2 < 16 * n4; e2 += 256) {
+      const int r = e2 / n4, d4 = e2 - r * n4;
+      if (d4 * 4 >= hd) continue;
+      float4 aq = make_float4(0.f, 0.f, 0.f, 0.f), ak = aq, av = aq;
+#pragma unroll 4
+      for (int c = 0; c < 16; ++c) {
+        axpy4(aq, sds[r * 20 + c], reinterpret_cast<const float4*>(sk + c * hp)[d4]);
+        axpy4(ak, sds[c * 20 + r], reinterpret_cast<const float4*>(sq + c * hp)[d4]);
+        axpy4(av, sp[c * 20 + r], reinterpret_cast<const float4*>(sdo + c * hp)[d4]);
+      }
+      const int64_t g = srow[r] + h * hd;
+      store4(dq, g, d4 * 4, hd, aq);
+      store4(dk, g, d4 * 4, hd, ak);
+      store4(dv, g, d4 * 4, hd, av);
+    }
+  }
+  if (dtable) {  // 256 (i, j) elements -> 49 table entries: LDS atomics, then one global atomic per entry
+    __syncthreads();
+    float* stab = sp;  // 49 <= 16 * 20
+    if (tid < 49) stab[tid] = 0.f;
+    __syncthreads();
+    atomicAdd(&stab[ridx], dbias);
+    __syncthreads();
+    if (tid < 49) unsafeAtomicAdd(dtable + (int64_t)tid * nh + h, stab[tid]);
+  }
+}
+
 extern "C" int vptr_winattn_fwd(const float* q, const float* k, const float* v, const float* bias_table,
                                 const int64_t* rel_index, float* o, int B, int H, int W, int C, int nh, int ws,
                                 float dropout_p, const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream) {
@@ -82,6 +242,15 @@ extern "C" int vptr_winattn_fwd(const float* q, const float* k, const float* v, 
   if (bias_table) VPTR_CHECK(rel_index != nullptr, "winattn_fwd: bias table needs rel_index");
   if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "winattn_fwd: dropout needs seed_dev");
   const int L = ws * ws, hd = C / nh;
+  if (ws == 4 && hd % 2 == 0 && C % 2 == 0) {
+    const int nwin = B * (H / 4) * (W / 4);
+    const int wpb = nwin >= 8192 ? 2 : 1;
+    const size_t lds16 = sizeof(float) * (3 * 16 * att_pitch(hd) + 16 * 20);
+    winattn16_fwd_kernel<<<dim3(cdiv(nwin, wpb), nh), 256, lds16, (hipStream_t)stream>>>(q, k, v, bias_table, rel_index, o, nwin, H, W, C,
+                                                                                         nh, dropout_p, seed_dev, site, wpb);
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t lds = sizeof(float) * (3 * L * (hd + 1) + L * (L + 1));
   VPTR_CHECK(lds <= 160 * 1024, "winattn_fwd: LDS budget exceeded (%zu B)", lds);
   if (lds > 64 * 1024)
@@ -199,9 +368,19 @@ extern "C" int vptr_winattn_bwd(const float* q, const float* k, const float* v, 
   if (bias_table || dbias_table) VPTR_CHECK(rel_index != nullptr, "winattn_bwd: bias table needs rel_index");
   if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "winattn_bwd: dropout needs seed_dev");
   const int L = ws * ws, hd = C / nh, ntab = (2 * ws - 1) * (2 * ws - 1);
+  const int nwin = B * (H / ws) * (W / ws);
+  if (ws == 4 && hd % 2 == 0 && C % 2 == 0) {
+    // many windows per workgroup: the 49 bias-table atomics per workgroup hit the same 49*nh addresses from every workgroup
+    const int wpb16 = nwin >= 512 ? 4 : (nwin >= 64 ? 2 : 1);
+    const size_t lds16 = sizeof(float) * (4 * 16 * att_pitch(hd) + 2 * 16 * 20);
+    winattn16_bwd_kernel<<<dim3(cdiv(nwin, wpb16), nh), 256, lds16, (hipStream_t)stream>>>(q, k, v, bias_table, rel_index, dout, dq, dk,
+                                                                                          dv, dbias_table, nwin, H, W, C, nh,
+                                                                                          dropout_p, seed_dev, site, wpb16);
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t lds = sizeof(float) * (4 * L * (hd + 1) + 2 * L * (L + 1) + ntab);
   VPTR_CHECK(lds <= 160 * 1024, "winattn_bwd: LDS budget exceeded (%zu B)", lds);
-  const int nwin = B * (H / ws) * (W / ws);
   const int wpb = nwin >= 2048 ? 4 : 1;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)winattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -269,6 +448,129 @@ __global__ __launch_bounds__(64) void tattn_fwd_kernel(const float* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// fast path for T <= 16 time steps (10 in every shipped configuration): one wave per (n, pixel, head); score element
+// (i, j) sits on lane (i % 4) * 16 + j of round i / 4 (see the window fast path above for the LDS layout).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void tattn16_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, float* __restrict__ o, int Tq, int Tk,
+                                                         int HW, int C, int nh, int causal, float p, const uint64_t* seed_dev,
+                                                         uint32_t site, int NP) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int hd = C / nh, hp = att_pitch(hd), n4 = hp >> 2;
+  float* sq = smem;              // [Tq][hp]
+  float* sk = sq + Tq * hp;      // [Tk][hp]
+  float* sv = sk + Tk * hp;      // [Tk][hp]
+  float* ss = sv + Tk * hp;      // [16][20]
+  __shared__ int64_t rq[16], rk[16];
+  // workgroup b runs on XCD b % 8: the nh heads of a token (which share its cache lines) get the same XCD
+  const int h = (blockIdx.x >> 3) % nh, np = (blockIdx.x / (8 * nh)) * 8 + (blockIdx.x & 7), lane = threadIdx.x;
+  if (np >= NP) return;  // tail when the token count is not a multiple of 8 (the grid is rounded up)
+  const int n = np / HW, pix = np - n * HW;
+  if (lane < Tq) rq[lane] = ((int64_t)(n * Tq + lane) * HW + pix) * C;
+  if (lane < Tk) rk[lane] = ((int64_t)(n * Tk + lane) * HW + pix) * C;
+  __syncthreads();
+  stage_rows(q, sq, rq, Tq, h * hd, hd, hp, lane, 64);
+  stage_rows(k, sk, rk, Tk, h * hd, hd, hp, lane, 64);
+  stage_rows(v, sv, rk, Tk, h * hd, hd, hp, lane, 64);
+  __syncthreads();
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  const int j = lane & 15;
+  for (int i0 = 0; i0 < Tq; i0 += 4) {
+    const int i = i0 + (lane >> 4);
+    const bool ok = i < Tq && j < Tk && !(causal && j > i);
+    const int ic = min(i, Tq - 1), jc = min(j, Tk - 1);
+    float a = 0.f;
+    for (int d = 0; d < n4; ++d)
+      a += dot4(reinterpret_cast<const float4*>(sq + ic * hp)[d], reinterpret_cast<const float4*>(sk + jc * hp)[d]);
+    a = ok ? a : -INFINITY;
+    const float m = row16_max(a);
+    const float e = ok ? __expf(a - m) : 0.f;
+    float pr = e / row16_sum(e);
+    if (p > 0.f) pr *= vptr_drop_scale(seed, site, (((uint64_t)np * nh + h) * Tq + ic) * Tk + jc, p);
+    if (i < Tq) ss[i * 20 + j] = ok ? pr : 0.f;
+  }
+  __syncthreads();
+  for (int e = lane; e < Tq * n4; e += 64) {
+    const int i = e / n4, d4 = e - i * n4;
+    if (d4 * 4 >= hd) continue;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < Tk; ++c) axpy4(acc, ss[i * 20 + c], reinterpret_cast<const float4*>(sv + c * hp)[d4]);
+    store4(o, rq[i] + h * hd, d4 * 4, hd, acc);
+  }
+}
+
+__global__ __launch_bounds__(64) void tattn16_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, const float* __restrict__ dout,
+                                                         float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+                                                         int Tq, int Tk, int HW, int C, int nh, int causal, float p,
+                                                         const uint64_t* seed_dev, uint32_t site, int NP) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int hd = C / nh, hp = att_pitch(hd), n4 = hp >> 2;
+  float* sq = smem;               // [Tq][hp]
+  float* sdo = sq + Tq * hp;      // [Tq][hp]
+  float* sk = sdo + Tq * hp;      // [Tk][hp]
+  float* sv = sk + Tk * hp;       // [Tk][hp]
+  float* sp = sv + Tk * hp;       // [16][20]  dropped probabilities
+  float* sds = sp + 16 * 20;      // [16][20]  dS
+  __shared__ int64_t rq[16], rk[16];
+  const int h = (blockIdx.x >> 3) % nh, np = (blockIdx.x / (8 * nh)) * 8 + (blockIdx.x & 7), lane = threadIdx.x;
+  if (np >= NP) return;
+  const int n = np / HW, pix = np - n * HW;
+  if (lane < Tq) rq[lane] = ((int64_t)(n * Tq + lane) * HW + pix) * C;
+  if (lane < Tk) rk[lane] = ((int64_t)(n * Tk + lane) * HW + pix) * C;
+  __syncthreads();
+  stage_rows(q, sq, rq, Tq, h * hd, hd, hp, lane, 64);
+  stage_rows(dout, sdo, rq, Tq, h * hd, hd, hp, lane, 64);
+  stage_rows(k, sk, rk, Tk, h * hd, hd, hp, lane, 64);
+  stage_rows(v, sv, rk, Tk, h * hd, hd, hp, lane, 64);
+  __syncthreads();
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  const int j = lane & 15;
+  for (int i0 = 0; i0 < Tq; i0 += 4) {
+    const int i = i0 + (lane >> 4);
+    const bool ok = i < Tq && j < Tk && !(causal && j > i);
+    const int ic = min(i, Tq - 1), jc = min(j, Tk - 1);
+    float a = 0.f, b = 0.f;
+    for (int d = 0; d < n4; ++d) {
+      a += dot4(reinterpret_cast<const float4*>(sq + ic * hp)[d], reinterpret_cast<const float4*>(sk + jc * hp)[d]);
+      b += dot4(reinterpret_cast<const float4*>(sdo + ic * hp)[d], reinterpret_cast<const float4*>(sv + jc * hp)[d]);
+    }
+    a = ok ? a : -INFINITY;
+    const float m = row16_max(a);
+    const float e = ok ? __expf(a - m) : 0.f;
+    const float pr = e / row16_sum(e);
+    const float sc = p > 0.f ? vptr_drop_scale(seed, site, (((uint64_t)np * nh + h) * Tq + ic) * Tk + jc, p) : 1.f;
+    const float dpr = ok ? b * sc : 0.f;
+    const float ds = pr * (dpr - row16_sum(dpr * pr));
+    if (i < Tq) {
+      sp[i * 20 + j] = ok ? pr * sc : 0.f;
+      sds[i * 20 + j] = ok ? ds : 0.f;
+    }
+  }
+  __syncthreads();
+  for (int e = lane; e < Tq * n4; e += 64) {
+    const int i = e / n4, d4 = e - i * n4;
+    if (d4 * 4 >= hd) continue;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < Tk; ++c) axpy4(acc, sds[i * 20 + c], reinterpret_cast<const float4*>(sk + c * hp)[d4]);
+    store4(dq, rq[i] + h * hd, d4 * 4, hd, acc);
+  }
+  for (int e = lane; e < Tk * n4; e += 64) {
+    const int c = e / n4, d4 = e - c * n4;
+    if (d4 * 4 >= hd) continue;
+    float4 ak = make_float4(0.f, 0.f, 0.f, 0.f), av = ak;
+    for (int i = 0; i < Tq; ++i) {
+      axpy4(ak, sds[i * 20 + c], reinterpret_cast<const float4*>(sq + i * hp)[d4]);
+      axpy4(av, sp[i * 20 + c], reinterpret_cast<const float4*>(sdo + i * hp)[d4]);
+    }
+    store4(dk, rk[c] + h * hd, d4 * 4, hd, ak);
+    store4(dv, rk[c] + h * hd, d4 * 4, hd, av);
+  }
+}
+
 extern "C" int vptr_tattn_fwd(const float* q, const float* k, const float* v, float* o, int Nb, int Tq, int Tk, int HW, int C,
                               int nh, int causal, float dropout_p, const uint64_t* seed_dev, uint32_t site,
                               vptr_stream_t stream) {
@@ -278,6 +580,13 @@ extern "C" int vptr_tattn_fwd(const float* q, const float* k, const float* v, fl
   if (causal) VPTR_CHECK(Tq == Tk, "tattn_fwd: causal mask needs Tq == Tk");
   if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "tattn_fwd: dropout needs seed_dev");
   const int hd = C / nh;
+  if (Tq <= 16 && Tk <= 16 && hd % 2 == 0 && C % 2 == 0) {
+    const size_t lds16 = sizeof(float) * ((Tq + 2 * Tk) * att_pitch(hd) + 16 * 20);
+    tattn16_fwd_kernel<<<dim3(cdiv(Nb * HW, 8) * 8 * nh), 64, lds16, (hipStream_t)stream>>>(q, k, v, o, Tq, Tk, HW, C, nh, causal,
+                                                                                           dropout_p, seed_dev, site, Nb * HW);
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t lds = sizeof(float) * ((Tq + 2 * Tk) * (hd + 1) + Tq * (Tk + 1));
   VPTR_CHECK(lds <= 64 * 1024, "tattn_fwd: LDS budget exceeded (%zu B)", lds);
   tattn_fwd_kernel<<<dim3(Nb * HW, nh), 64, lds, (hipStream_t)stream>>>(q, k, v, o, Tq, Tk, HW, C, nh, causal, dropout_p, seed_dev,
@@ -380,6 +689,13 @@ extern "C" int vptr_tattn_bwd(const float* q, const float* k, const float* v, co
   if (causal) VPTR_CHECK(Tq == Tk, "tattn_bwd: causal mask needs Tq == Tk");
   if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "tattn_bwd: dropout needs seed_dev");
   const int hd = C / nh;
+  if (Tq <= 16 && Tk <= 16 && hd % 2 == 0 && C % 2 == 0) {
+    const size_t lds16 = sizeof(float) * (2 * (Tq + Tk) * att_pitch(hd) + 2 * 16 * 20);
+    tattn16_bwd_kernel<<<dim3(cdiv(Nb * HW, 8) * 8 * nh), 64, lds16, (hipStream_t)stream>>>(q, k, v, dout, dq, dk, dv, Tq, Tk, HW, C, nh,
+                                                                                           causal, dropout_p, seed_dev, site, Nb * HW);
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t lds = sizeof(float) * (2 * (Tq + Tk) * (hd + 1) + 2 * Tq * (Tk + 1));
   VPTR_CHECK(lds <= 160 * 1024, "tattn_bwd: LDS budget exceeded (%zu B)", lds);
   if (lds > 64 * 1024)
