@@ -311,18 +311,42 @@ extern "C" int vptr_add_rowtab(const float* x, const float* tab, float* y, int r
 // conv-FFN statistics.  colstats: per-channel mean / biased variance over all rows (BatchNorm2d batch stats).
 // Pass 1: each block reduces 256 rows per column to (mean, M2); pass 2 merges the partials with Chan's formula.
 // ---------------------------------------------------------------------------------------------------------------
+// block = 32 float4 columns x 8 row lanes over a chunk of 256 rows, one pass: sums of (x - pivot) and (x - pivot)^2 with the
+// chunk's first row as pivot (keeps the one-pass variance well conditioned), LDS reduction over the row lanes.
 __global__ __launch_bounds__(256) void colstats_partial_kernel(const float* __restrict__ x, float* __restrict__ scratch,
-                                                               int rows, int F) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= F) return;
+                                                               int rows, int F4) {
+  __shared__ float4 rs[8][32], rq[8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c4 = blockIdx.x * 32 + tx;
   const int r0 = blockIdx.y * 256, r1 = min(rows, r0 + 256);
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += x[(int64_t)r * F + c];
-  const float mu = s / (float)(r1 - r0);
-  float m2 = 0.f;
-  for (int r = r0; r < r1; ++r) { const float d = x[(int64_t)r * F + c] - mu; m2 += d * d; }
-  scratch[((int64_t)blockIdx.y * F + c) * 2 + 0] = mu;
-  scratch[((int64_t)blockIdx.y * F + c) * 2 + 1] = m2;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s, pv = s;
+  if (c4 < F4) {
+    pv = reinterpret_cast<const float4*>(x)[(int64_t)r0 * F4 + c4];
+#pragma unroll 4
+    for (int r = r0 + ty; r < r1; r += 8) {
+      const float4 v = reinterpret_cast<const float4*>(x)[(int64_t)r * F4 + c4];
+      const float a = v.x - pv.x, b = v.y - pv.y, c = v.z - pv.z, d = v.w - pv.w;
+      s.x += a; s.y += b; s.z += c; s.w += d;
+      q.x += a * a; q.y += b * b; q.z += c * c; q.w += d * d;
+    }
+  }
+  rs[ty][tx] = s;
+  rq[ty][tx] = q;
+  __syncthreads();
+  if (ty == 0 && c4 < F4) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const float4 u = rs[k][tx], w = rq[k][tx];
+      s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
+      q.x += w.x; q.y += w.y; q.z += w.z; q.w += w.w;
+    }
+    const float n = (float)(r1 - r0);
+    float* o = scratch + ((int64_t)blockIdx.y * F4 * 4 + c4 * 4) * 2;
+    o[0] = pv.x + s.x / n; o[1] = q.x - s.x * s.x / n;
+    o[2] = pv.y + s.y / n; o[3] = q.y - s.y * s.y / n;
+    o[4] = pv.z + s.z / n; o[5] = q.z - s.z * s.z / n;
+    o[6] = pv.w + s.w / n; o[7] = q.w - s.w * s.w / n;
+  }
 }
 __global__ __launch_bounds__(256) void colstats_final_kernel(const float* __restrict__ scratch, float* __restrict__ mean,
                                                              float* __restrict__ var, float* __restrict__ rstd, float eps,
@@ -345,10 +369,10 @@ __global__ __launch_bounds__(256) void colstats_final_kernel(const float* __rest
 
 extern "C" int vptr_colstats(const float* x, float* mean, float* var, float* rstd, float eps, float* scratch, int rows, int F,
                              vptr_stream_t stream) {
-  VPTR_CHECK(rows > 0 && F > 0 && scratch, "colstats: bad arguments");
+  VPTR_CHECK(rows > 0 && F > 0 && F % 4 == 0 && scratch, "colstats: bad arguments (F must be a multiple of 4)");
   const int nchunk = cdiv(rows, 256);
   hipStream_t st = (hipStream_t)stream;
-  colstats_partial_kernel<<<dim3(cdiv(F, 256), nchunk), 256, 0, st>>>(x, scratch, rows, F);
+  colstats_partial_kernel<<<dim3(cdiv(F / 4, 32), nchunk), 256, 0, st>>>(x, scratch, rows, F / 4);
   colstats_final_kernel<<<cdiv(F, 256), 256, 0, st>>>(scratch, mean, var, rstd, eps, rows, F, nchunk);
   VPTR_LAUNCH_CHECK();
   return 0;
@@ -358,26 +382,25 @@ extern "C" int vptr_colstats(const float* x, float* mean, float* var, float* rst
 __global__ __launch_bounds__(1024) void groupstats_kernel(const float* __restrict__ x, float* __restrict__ mean,
                                                           float* __restrict__ var, float* __restrict__ rstd, float eps,
                                                           int group_elems) {
+  // one pass: sums of (x - pivot) and (x - pivot)^2 with the group's first element as pivot
   __shared__ float red[16];
   const float* g = x + (int64_t)blockIdx.x * group_elems;
   const int n4 = group_elems >> 2;
-  float s = 0.f;
+  const float pv = g[0];
+  float s = 0.f, q = 0.f;
+#pragma unroll 4
   for (int i = threadIdx.x; i < n4; i += 1024) {
     const float4 v = reinterpret_cast<const float4*>(g)[i];
-    s += (v.x + v.y) + (v.z + v.w);
-  }
-  for (int i = (n4 << 2) + threadIdx.x; i < group_elems; i += 1024) s += g[i];
-  const float mu = block_sum(s, red) / (float)group_elems;
-  float q = 0.f;
-  for (int i = threadIdx.x; i < n4; i += 1024) {
-    const float4 v = reinterpret_cast<const float4*>(g)[i];
-    const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
+    const float a = v.x - pv, b = v.y - pv, c = v.z - pv, d = v.w - pv;
+    s += (a + b) + (c + d);
     q += (a * a + b * b) + (c * c + d * d);
   }
-  for (int i = (n4 << 2) + threadIdx.x; i < group_elems; i += 1024) { const float a = g[i] - mu; q += a * a; }
-  const float vv = block_sum(q, red) / (float)group_elems;
+  for (int i = (n4 << 2) + threadIdx.x; i < group_elems; i += 1024) { const float a = g[i] - pv; s += a; q += a * a; }
+  const float S = block_sum(s, red), Q = block_sum(q, red);
   if (threadIdx.x == 0) {
-    mean[blockIdx.x] = mu;
+    const float n = (float)group_elems, ms = S / n;
+    const float vv = fmaxf(Q / n - ms * ms, 0.f);
+    mean[blockIdx.x] = pv + ms;
     var[blockIdx.x] = vv;
     if (rstd) rstd[blockIdx.x] = rsqrtf(vv + eps);
   }
