@@ -221,76 +221,91 @@ extern "C" int vptr_conv7_out_bwd_data(const float* dy, const float* y, const fl
   return 0;
 }
 
-// backward-weight of conv7_out: block = (8x8 output tile sweep over a chunk of frames); thread = (ci, tap group).
-// The x tile with its 3-pixel reflected halo and the activation-gradient tile are staged in LDS.
-__global__ __launch_bounds__(256) void conv7_out_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+// backward-weight of conv7_out: block = (8x8 output tile swept over a chunk of frames); thread = (ci, ky) owns the 7 taps
+// (ky, 0..6) of its input channel.  The x tile with its 3-pixel reflected halo and the activation-gradient tile are staged
+// in LDS; per output row a thread reads the 8 gradient values and the 14 x values of its channel ONCE and slides them over
+// the 7 kx taps in registers (56 FMAs per 22 LDS reads; the first version did 2 LDS reads per FMA and was LDS-bound).
+__global__ __launch_bounds__(512) void conv7_out_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                    const float* __restrict__ x, float* __restrict__ dw,
                                                                    float* __restrict__ db, int B, int Cin, int H, int W,
                                                                    int Cimg, int out_act, int frames_per_block) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sx = smem;                    // [14*14][Cin]
-  float* sg = sx + 14 * 14 * Cin;      // [Cimg][64]
+  float* sx = smem;                    // [14*14][64]
+  float* sg = sx + 14 * 14 * 64;       // [Cimg][64]
   __shared__ float red[16];
   const int tid = threadIdx.x;
-  const int ci = tid % Cin;
-  const int tg = tid / Cin, ntg = 256 / Cin;  // tap groups
+  const int ci = tid & 63, ky = tid >> 6;   // ky = 7: idle in the tap phase (512 = 64 x 8 threads, 7 kernel rows)
   const int tiles_x = W / 8, tiles_y = H / 8;
   const int ty = (blockIdx.x / tiles_x) % tiles_y, tx = blockIdx.x % tiles_x;
   const int b0 = blockIdx.y * frames_per_block, b1 = min(B, b0 + frames_per_block);
-  constexpr int MAXT = 13;  // taps per thread when ntg = 4 (49 / 4 rounded up)
-  float acc[3][MAXT];
+  float acc[3][7];
 #pragma unroll
   for (int co = 0; co < 3; ++co)
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[co][t] = 0.f;
+    for (int t = 0; t < 7; ++t) acc[co][t] = 0.f;
   float bsum[3] = {0.f, 0.f, 0.f};
   for (int b = b0; b < b1; ++b) {
     __syncthreads();
-    for (int i = tid; i < 14 * 14 * Cin; i += 256) {
-      const int c = i % Cin, p = i / Cin;
+    for (int i = tid; i < 14 * 14 * 64; i += 512) {
+      const int c = i & 63, p = i >> 6;
       const int iy = reflect_idx(ty * 8 + p / 14 - 3, H), ix = reflect_idx(tx * 8 + p % 14 - 3, W);
-      sx[i] = x[(((int64_t)b * H + iy) * W + ix) * Cin + c];
+      sx[i] = x[(((int64_t)b * H + iy) * W + ix) * 64 + c];
     }
-    for (int i = tid; i < Cimg * 64; i += 256) {
+    for (int i = tid; i < Cimg * 64; i += 512) {
       const int co = i >> 6, p = i & 63;
       const int64_t o = (((int64_t)b * Cimg + co) * H + ty * 8 + (p >> 3)) * W + tx * 8 + (p & 7);
       sg[i] = out_act_grad(dy[o], y[o], out_act);
     }
     __syncthreads();
-    for (int co = 0; co < Cimg; ++co) {
+    if (ky < 7) {
+      for (int py = 0; py < 8; ++py) {
+        float xr[14];
 #pragma unroll
-      for (int t = 0; t < MAXT; ++t) {
-        const int tap = tg + t * ntg;
-        if (tap < 49 && tg < ntg) {
-          const int ky = tap / 7, kx = tap - ky * 7;
-          float a = 0.f;
-          for (int p = 0; p < 64; ++p) a += sg[co * 64 + p] * sx[(((p >> 3) + ky) * 14 + (p & 7) + kx) * Cin + ci];
-          acc[co][t] += a;
+        for (int u = 0; u < 14; ++u) xr[u] = sx[((py + ky) * 14 + u) * 64 + ci];
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+          if (co < Cimg) {
+            float gr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gr[u] = sg[co * 64 + py * 8 + u];
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+              float a = 0.f;
+#pragma unroll
+              for (int u = 0; u < 8; ++u) a += gr[u] * xr[u + kx];
+              acc[co][kx] += a;
+            }
+          }
         }
       }
+    }
+    for (int co = 0; co < Cimg; ++co) {
       float gs = 0.f;
       if (tid < 64) gs = sg[co * 64 + tid];
       gs = block_sum(gs, red);
       bsum[co] += gs;
     }
   }
-  for (int co = 0; co < Cimg; ++co) {
+  if (ky < 7) {
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-      const int tap = tg + t * ntg;
-      if (tap < 49 && tg < ntg) unsafeAtomicAdd(dw + ((int64_t)co * Cin + ci) * 49 + tap, acc[co][t]);
-    }
-    if (tid == 0) unsafeAtomicAdd(db + co, bsum[co]);
+    for (int co = 0; co < 3; ++co)
+      if (co < Cimg) {
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) unsafeAtomicAdd(dw + ((int64_t)co * 64 + ci) * 49 + ky * 7 + kx, acc[co][kx]);
+      }
   }
+  if (tid == 0)
+    for (int co = 0; co < Cimg; ++co) unsafeAtomicAdd(db + co, bsum[co]);
 }
 
 extern "C" int vptr_conv7_out_bwd_weight(const float* dy, const float* y, const float* x, float* dw, float* db, int B, int Cin,
                                          int H, int W, int Cimg, int out_act, vptr_stream_t stream) {
   VPTR_CHECK(B > 0 && Cin == 64 && H % 8 == 0 && W % 8 == 0 && Cimg >= 1 && Cimg <= 3, "conv7_out_bwd_weight: unsupported geometry");
   const size_t lds = sizeof(float) * (14 * 14 * Cin + Cimg * 64);
-  const int fpb = 4;
+  // many frames per workgroup: each workgroup ends with Cimg*64*49 atomics onto the same addresses
+  const int fpb = B >= 64 ? 16 : 4;
   dim3 grid((H / 8) * (W / 8), cdiv(B, fpb));
-  conv7_out_bwd_weight_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(dy, y, x, dw, db, B, Cin, H, W, Cimg, out_act, fpb);
+  conv7_out_bwd_weight_kernel<<<grid, 512, lds, (hipStream_t)stream>>>(dy, y, x, dw, db, B, Cin, H, W, Cimg, out_act, fpb);
   VPTR_LAUNCH_CHECK();
   return 0;
 }
