@@ -33,14 +33,16 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t hmin64(int64_t a, int64_t b) { return a < b ? a : b; }
 
 // ---- counter-based dropout mask: one 32-bit hash per element ------------------------------------
+__device__ __forceinline__ uint32_t vptr_mix32(uint32_t x) {  // "lowbias32" finaliser: full avalanche in 2 multiplies
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+// counter-based random word for element `idx` of dropout site `site` under `seed`.  The key depends only on launch-uniform
+// values (it lives on the scalar unit); the per-element cost is one 32-bit mix (the first version ran three 64-bit
+// multiplies per element, ~3x the VALU work, in every epilogue / normalise / activation-gradient pass with dropout).
 __device__ __forceinline__ uint32_t vptr_hash3(uint64_t seed, uint32_t site, uint64_t idx) {
-  uint64_t x = seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(site + 1)) ^ (idx * 0xD1B54A32D192ED03ull);
-  x ^= x >> 32;
-  x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  return (uint32_t)x;
+  const uint32_t key = vptr_mix32((uint32_t)seed ^ vptr_mix32((uint32_t)(seed >> 32) + (site + 1u) * 0x9E3779B9u));
+  return vptr_mix32(((uint32_t)idx ^ key) + (uint32_t)(idx >> 32) * 0xC2B2AE35u);
 }
 // returns 1/keep if kept, 0 if dropped
 __device__ __forceinline__ float vptr_drop_scale(uint64_t seed, uint32_t site, uint64_t idx, float p) {
