@@ -9,7 +9,12 @@ MI355X-first differences in *how* (not *what*):
     clipping + AdamW are two HIP launches (vptr_sumsq, vptr_adamw) and the data-parallel gradient exchange is a
     handful of large RCCL all-reduces over xGMI instead of 664 small tensors;
   * losses are returned as device tensors (the reference's 8 `.item()` syncs per step are left to the caller);
-  * the whole step can be captured into one hipGraph (`capture()`), removing ~1.5k host launches per step.
+  * the weight (and bias) gradients of every nn.Linear of a backward pass run as ONE grouped MFMA launch at its end
+    (ops.defer_wgrad / vptr_gemm_grouped);
+  * `capture()` (whole step as one hipGraph) is experimental and not used by bench.py.
+
+`FARTrainer` is the same for `single_iter` of train_FAR.py:48-101, `AETrainer` for the stage-1 auto-encoder + PatchGAN step of
+train_AutoEncoder.py:44-78; both NAR and FAR trainers take the optional adversarial branch (`disc=`, `lam_gan=`).
 """
 import torch
 import torch.nn.functional as F
