@@ -4,6 +4,7 @@
 #include "../vptr_amd/csrc/gemm.hip"
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <vector>
 int main(int argc, char** argv) {
   int M = argc > 1 ? atoi(argv[1]) : 10240, N = argc > 2 ? atoi(argv[2]) : 528, K = argc > 3 ? atoi(argv[3]) : 528;
@@ -27,6 +28,26 @@ int main(int argc, char** argv) {
   hipEventRecord(e0); for (int i = 0; i < 10; ++i) vptr_gemm(&d, nullptr); hipEventRecord(e1); hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("variant %d  M %d N %d K %d a%d b%d split %d: %.1f us  %.1f TF/s\n", g_gemm_variant, M, N, K, am, bm, sk, ms * 100, 2.0 * M * N * K / (ms * 1e-4) / 1e12);
+  {  // sampled correctness check against fp64 host dot products
+    hipMemset(D, 0, nd * 4);
+    vptr_gemm(&d, nullptr);
+    hipDeviceSynchronize();
+    std::vector<float> hd(nd);
+    hipMemcpy(hd.data(), D, nd * 4, hipMemcpyDeviceToHost);
+    double worst = 0;
+    for (int sidx = 0; sidx < 256; ++sidx) {
+      const int m = (int)((sidx * 2654435761ull + 12345) % M), n = (int)((sidx * 40503ull + 977) % N);
+      double ref = 0;
+      for (int k = 0; k < K; ++k) {
+        const double a = am == 0 ? h[(size_t)m * K + k] : h[(size_t)k * M + m];
+        const double b = bm == 0 ? h[(size_t)n * K + k] : h[(size_t)k * N + n];
+        ref += a * b;
+      }
+      const double e = fabs(hd[(size_t)m * N + n] - ref) / (fabs(ref) + 0.3 * sqrt((double)K) * 0.29 * 0.29);  // |a|,|b| ~ U(-.5,.5)
+      if (e > worst) worst = e;
+    }
+    printf("sampled max error vs fp64: %.2e %s\n", worst, worst < 1e-4 ? "(ok)" : "(MISMATCH)");
+  }
   std::vector<long long> t(maxblk * 8);
   hipMemcpy(t.data(), tb, t.size() * 8, hipMemcpyDeviceToHost);
   int nblk = 0; while (nblk < maxblk && t[nblk * 8 + 7]) ++nblk;
