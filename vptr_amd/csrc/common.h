@@ -52,11 +52,28 @@ __device__ __forceinline__ float vptr_drop_scale(uint64_t seed, uint32_t site, u
 }
 
 // ---- activations --------------------------------------------------------------------------------
-__device__ __forceinline__ float vptr_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU (nn.GELU()) and its derivative.  Phi(x) = 0.5 * (1 + erf(x / sqrt 2)) is evaluated with Abramowitz-Stegun
+// 7.1.26 (|error| <= 1.5e-7, far inside the fp32 parity budget): one v_rcp, one v_exp and five FMAs, and the exponential
+// e^(-x^2/2) it needs is the one the density term of the derivative needs anyway -- libm's erff cost about as much as
+// everything else in the normalise / activation-gradient passes together.
+__device__ __forceinline__ void vptr_phi(float x, float& cdf, float& pdf) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float e = __expf(-ax * ax);                    // = exp(-x^2 / 2)
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float h = 0.5f * poly * e;                     // 0.5 * erfc(|x| / sqrt 2)
+  cdf = x >= 0.f ? 1.0f - h : h;
+  pdf = 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float vptr_gelu(float x) {
+  float c, d;
+  vptr_phi(x, c, d);
+  return x * c;
+}
 __device__ __forceinline__ float vptr_gelu_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float c, d;
+  vptr_phi(x, c, d);
+  return c + x * d;
 }
 __device__ __forceinline__ float vptr_act(float v, int act) {
   if (act == VPTR_ACT_GELU) return vptr_gelu(v);
