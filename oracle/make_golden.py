@@ -225,7 +225,7 @@ def losses_case(ref, name, seed):
                         nce=np.array(nce(F.normalize(gf, p=2.0, dim=2), F.normalize(pf, p=2.0, dim=2)).item()))
 
 
-def step_case(ref, name, cfg, feat, HW, N, seed, steps=2):
+def step_case(ref, name, cfg, feat, HW, N, seed, steps=2, sample=0):
     """single_iter recipe of train_NAR.py:49-107 with the real reference modules, dropout 0, no GAN."""
     enc = ref.VPTREnc(1, feat_dim=feat, n_downsampling=3, padding_type="reflect").eval()
     dec = ref.VPTRDec(1, feat_dim=feat, n_downsampling=3, out_layer="Tanh", padding_type="reflect").eval()
@@ -270,7 +270,15 @@ def step_case(ref, name, cfg, feat, HW, N, seed, steps=2):
             "dec_template": json.dumps(template_of(dec.state_dict()))}
     for k, v in T.state_dict().items():
         if v.is_floating_point() and k not in ("temporal_pos", "lw_pos", "Tlw_pos"):
-            save["post:" + k] = v.numpy()
+            if sample:  # full-size model: a strided sample of <= ~sample elements per tensor
+                flat = v.flatten()
+                save["post:T:" + k] = flat[::max(1, flat.numel() // sample)].numpy()
+            else:
+                save["post:" + k] = v.numpy()
+    if sample:
+        save["sample"] = np.array(sample)
+        for drop in ("T_template", "enc_template", "dec_template"):
+            save.pop(drop, None)
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
 
 
@@ -500,6 +508,7 @@ def main():
         ("ae_tiny_zero", lambda n: ae_case(ref, n, 3, 48, 32, 1, 2, "zero", "Sigmoid", 22)),
         ("losses_tiny", lambda n: losses_case(ref, n, 31)),
         ("step_tiny", lambda n: step_case(ref, n, dict(tiny, Tp=2, Tf=2), 48, 64, 2, 41)),
+        ("step_k64_digest", lambda n: step_case(ref, n, k64, 528, 64, 1, 101, steps=2, sample=1024)),
         ("step_nar_gan_tiny", lambda n: nar_gan_step_case(ref, n, dict(tiny, Tp=2, Tf=2), 48, 64, 2, 91)),
         ("step_far_tiny", lambda n: far_step_case(ref, n, far_tiny, 48, 64, 2, 61)),
         ("step_ae_tiny", lambda n: ae_step_case(ref, n, 1, 48, 32, 2, 2, 81)),

@@ -65,12 +65,13 @@ def sampled_post_params_close(state_dicts, z, lr, rel_tol, max_flip_frac=0.03):
     `post:<tag>:<name>`; state_dicts maps tag -> state_dict"""
     num = den = 0.0
     bad = tot = 0
+    per = int(z["sample"]) if "sample" in z.files else 4096
     for k in z.files:
         if not k.startswith("post:"):
             continue
         _, tag, name = k.split(":", 2)
         flat = state_dicts[tag][name].detach().cpu().double().flatten()
-        d = flat[::max(1, flat.numel() // 4096)] - torch.from_numpy(z[k]).double()
+        d = flat[::max(1, flat.numel() // per)] - torch.from_numpy(z[k]).double()
         num += float((d * d).sum())
         den += float((torch.from_numpy(z[k]).double() ** 2).sum())
         bad += int((d.abs() > 0.5 * lr).sum())
