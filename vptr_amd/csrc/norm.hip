@@ -194,7 +194,7 @@ extern "C" int vptr_layernorm_bwd(const float* dy, const float* dy2, const float
   VPTR_CHECK(rows > 0 && C > 0, "layernorm_bwd: empty input");
   hipStream_t st = (hipStream_t)stream;
   if (dx && dgamma && dbeta && C % 4 == 0 && C <= 1024) {
-    const int rpb = rows >= 4096 ? 16 : 4;
+    const int rpb = rows >= 4096 ? 32 : 4;  // fewer, longer workgroups: the per-column atomics at the end contend across workgroups
     const int nb = cdiv(rows, rpb);
     if (C <= 256) ln_bwd_fused_kernel<1><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb);
     else if (C <= 768) ln_bwd_fused_kernel<3><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb);
