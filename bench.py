@@ -142,12 +142,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    dev = torch.device("cuda", local_rank)
+    # VPTR_BENCH_SHARE_GPU=1 + VPTR_BENCH_BACKEND=gloo: functional check of the multi-rank path on a ONE-GPU box (every rank
+    # on cuda:0, gradient exchange through gloo); never set by the driver -- its runs use one GPU per rank over RCCL
+    share = os.environ.get("VPTR_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("VPTR_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(dev)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
         pg = torch.distributed.group.WORLD
 
     import vptr_amd.ops as ops
@@ -210,6 +217,7 @@ def main():
         if not args.no_roofline:
             try:
                 trainer._graph = None  # instrumented eager pass
+                trainer.world = 1      # rank 0 alone runs it: no collective may be issued (the other ranks are at the final barrier)
                 res["roofline"] = gemm_roofline(trainer, past, fut, args.precision)
             except Exception as e:  # noqa
                 res["roofline"] = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
