@@ -154,7 +154,7 @@ def defer_wgrad(g, x, dW, N, K, M, db=None):
     # one end-of-backward callback per recorded call: flush_wgrads is idempotent, and registering every time stays correct
     # when an earlier backward died before its callbacks ran (a "callback already queued" flag would then be stale)
     try:
-        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+        torch.autograd.Variable._execution_engine.queue_callback(_auto_flush_wgrads)
     except RuntimeError:  # not inside a backward pass: the caller flushes explicitly
         pass
 
@@ -164,22 +164,40 @@ def discard_wgrads():
     del _wgrad_q[:]
 
 
-def flush_wgrads():
-    """launch every recorded weight gradient (idempotent; runs automatically at the end of a backward pass)"""
-    if not _wgrad_q:
-        return
-    items = list(_wgrad_q)
-    del _wgrad_q[:]
+_wgrad_hold = [False]  # set by hold_wgrads(): the end-of-backward callback leaves the queue to an explicit chunked flush
+
+
+class hold_wgrads:
+    """Scope in which the end-of-backward callback does NOT launch the recorded weight gradients: the data-parallel trainer
+    flushes them itself in a few chunks (flush_wgrads(chunks=..., on_chunk=...)) so that the all-reduce of one chunk's
+    gradient range overlaps the GEMM launch of the next."""
+
+    def __enter__(self):
+        self.prev = _wgrad_hold[0]
+        _wgrad_hold[0] = True
+        return self
+
+    def __exit__(self, *exc):
+        _wgrad_hold[0] = self.prev
+        return False
+
+
+def _auto_flush_wgrads():
+    if not _wgrad_hold[0]:
+        flush_wgrads()
+
+
+def _launch_wgrad_group(its):
     groups = {}
-    for it in items:
+    for it in its:
         groups.setdefault((int(lib.vptr_gemm_tile_cols(it[4])), it[6]), []).append(it)
-    for (cols, prec), its in groups.items():
-        n = len(its)
+    for (cols, prec), grp in groups.items():
+        n = len(grp)
         descs = (GemmDesc * n)()
         starts = []
         total = 0
         flops = 0.0
-        for i, (g, x, dW, N, K, M, _, db) in enumerate(its):
+        for i, (g, x, dW, N, K, M, _, db) in enumerate(grp):
             d = descs[i]
             d.A, d.B, d.D = ptr(g), ptr(x), ptr(dW)
             d.a_rowsum = ptr(db)
@@ -189,7 +207,7 @@ def flush_wgrads():
             starts.append(total)
             total += ((N + 127) // 128) * ((K + cols - 1) // cols)
             flops += 2.0 * M * N * K
-        dev = its[0][0].device
+        dev = grp[0][0].device
         raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
         st = torch.tensor(starts, dtype=torch.int32).to(dev)
         prof = _gemm_prof
@@ -200,6 +218,41 @@ def flush_wgrads():
         if prof is not None:
             e1.record()
             prof.append(((cols // 16, prec, 1, 1, "grouped"), flops, e0, e1))
+
+
+def flush_wgrads(chunks=1, on_chunk=None):
+    """Launch every recorded weight gradient (idempotent; runs automatically at the end of a backward pass).
+
+    chunks > 1: the records are ordered by the address of their destination and launched as `chunks` grouped GEMMs of about
+    equal work; after each launch `on_chunk(first_dW_ptr)` is called with the lowest destination address of the NEXT chunk
+    (None after the last): everything below it is final, so its gradient range can go out to the other ranks while the next
+    chunk computes."""
+    if not _wgrad_q:
+        if on_chunk is not None:
+            on_chunk(None)
+        return
+    items = list(_wgrad_q)
+    del _wgrad_q[:]
+    if chunks <= 1 or len(items) < 2 * chunks:
+        _launch_wgrad_group(items)
+        if on_chunk is not None:
+            on_chunk(None)
+        return
+    items.sort(key=lambda it: it[2].data_ptr())
+    work = [float(it[3]) * it[4] for it in items]
+    per = sum(work) / chunks
+    acc, lo = 0.0, 0
+    bounds = []
+    for i, w in enumerate(work):
+        acc += w
+        if acc >= per * (len(bounds) + 1) and len(bounds) < chunks - 1 and i + 1 < len(items):
+            bounds.append(i + 1)
+    bounds.append(len(items))
+    for hi in bounds:
+        _launch_wgrad_group(items[lo:hi])
+        if on_chunk is not None:
+            on_chunk(items[hi][2].data_ptr() if hi < len(items) else None)
+        lo = hi
 
 
 def _split_k_for(tiles, K):

@@ -16,12 +16,17 @@ MI355X-first differences in *how* (not *what*):
 `FARTrainer` is the same for `single_iter` of train_FAR.py:48-101, `AETrainer` for the stage-1 auto-encoder + PatchGAN step of
 train_AutoEncoder.py:44-78; both NAR and FAR trainers take the optional adversarial branch (`disc=`, `lam_gan=`).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
 from . import ops
 from ._lib import check, lib, ptr, stream
 from .model.criterion import GDL, BiPatchNCE, GANLoss, MSELoss
+
+
+DP_CHUNKS = 4  # grouped weight-gradient launches per step when gradients are exchanged between ranks
 
 
 class FlatAdamW:
@@ -202,6 +207,39 @@ class NARTrainer:
         from .parallel import allreduce_mean_
         allreduce_mean_(self.opt.grad, self.pg, self.bucket_elems)
 
+    def _backward_and_exchange(self, loss):
+        """loss.backward(), the grouped weight-gradient GEMMs and the data-parallel gradient exchange.  With more than one
+        rank the weight gradients are flushed in DP_CHUNKS grouped launches ordered by slab address; as soon as a chunk has
+        been enqueued, the slab range below the next chunk's first destination is final and its all-reduce is issued
+        asynchronously (RCCL runs it on its own stream), overlapping the next chunk's GEMM."""
+        if self.pg is None or self.world == 1 or os.environ.get("VPTR_DP_OVERLAP", "1") == "0":
+            loss.backward()
+            ops.flush_wgrads()  # no-op: the grouped weight-gradient launch already ran at the end of backward
+            self._allreduce_grads()
+            return
+        grad = self.opt.grad
+        base, n = grad.data_ptr(), grad.numel()
+        works, sent = [], [0]
+
+        def send_upto(next_ptr):
+            hi = n if next_ptr is None else max(sent[0], min(n, (next_ptr - base) // 4))
+            off = sent[0]
+            while off < hi:  # sub-ranges of at most bucket_elems, like the non-overlapped path
+                end = min(hi, off + self.bucket_elems)
+                works.append(torch.distributed.all_reduce(grad[off:end], op=torch.distributed.ReduceOp.SUM, group=self.pg,
+                                                          async_op=True))
+                off = end
+            sent[0] = hi
+
+        with ops.hold_wgrads():
+            loss.backward()
+        ops.flush_wgrads(chunks=DP_CHUNKS, on_chunk=send_upto)
+        if sent[0] < n:
+            send_upto(None)
+        for w in works:
+            w.wait()
+        grad.mul_(1.0 / self.world)
+
     def losses(self, pred_frames, future, pred_feats, future_feats):
         a = self.T.NCE_projector(pred_feats.permute(0, 1, 3, 4, 2)).permute(0, 1, 4, 2, 3)
         b = self.T.NCE_projector(future_feats.permute(0, 1, 3, 4, 2)).permute(0, 1, 4, 2, 3)
@@ -233,9 +271,7 @@ class NARTrainer:
             extra["T_gan"] = self.gan(self.disc(pred_frames.flatten(0, 1)), True)
             loss = loss + self.lam_gan * extra["T_gan"]
             extra["T_gan"] = extra["T_gan"].detach()
-        loss.backward()
-        ops.flush_wgrads()  # no-op: the grouped weight-gradient launch already ran at the end of backward
-        self._allreduce_grads()
+        self._backward_and_exchange(loss)
         self.opt.step()
         return dict({"T_total": loss.detach(), "T_GDL": l_gdl.detach(), "T_MSE": l_mse.detach(), "T_bpc": l_pc.detach(),
                      "grad_norm": self.opt.grad_norm()}, **extra)
@@ -321,9 +357,7 @@ class FARTrainer(NARTrainer):
             t_gan = self.gan(self.disc(pred_frames.flatten(0, 1)), True)
             loss = loss + self.lam_gan * t_gan
             extra["T_gan"] = t_gan.detach()
-        loss.backward()
-        ops.flush_wgrads()
-        self._allreduce_grads()
+        self._backward_and_exchange(loss)
         self.opt.step()
         return dict({"T_total": loss.detach(), "T_GDL": l_gdl.detach(), "T_MSE": l_mse.detach(), "grad_norm": self.opt.grad_norm()},
                     **extra)
