@@ -117,7 +117,10 @@ def transformer_case(ref, name, cfg, far, N, seed, full=True, check64=True):
         if k.endswith("running_mean") or k.endswith("running_var"):
             e_bn = max(e_bn, rel(P[k], sd_after[k]))
     print(f"[{name}] fp32 oracle-vs-ref: out {e_out:.2e} dx {e_dx:.2e} dparam(max) {e_g:.2e} eval {e_eval:.2e} bn {e_bn:.2e}")
-    assert max(e_out, e_dx, e_eval, e_bn) < 2e-5 and e_g < 2e-4, name
+    # two fp32 evaluation orders of the same formulas: 2e-5 on the small nets; the full-size digests (windows of 64 tokens,
+    # up to 50 time steps, 12 layers) accumulate a few 1e-5 more -- the fp64 comparison on the tiny cases pins exactness
+    lim = 2e-5 if full else 1e-4
+    assert max(e_out, e_dx, e_eval, e_bn) < lim and e_g < 10 * lim, name
 
     if check64:
         m64 = build_nar(ref, cfg, seed, far).double().train()
@@ -514,6 +517,8 @@ def main():
         ("step_ae_tiny", lambda n: ae_step_case(ref, n, 1, 48, 32, 2, 2, 81)),
         ("metrics_tiny", lambda n: metrics_case(ref, n)),
         ("nar_k64_digest", lambda n: transformer_case(ref, n, k64, False, 1, 51, full=False, check64=False)),
+        ("nar_kth128_digest", lambda n: transformer_case(ref, n, dict(k64, Tf=40, H=16, W=16, window_size=8), False, 1, 53, full=False,
+                                                          check64=False)),
         ("far_bair_digest", lambda n: transformer_case(ref, n, far, True, 1, 52, full=False, check64=False)),
     ]
     only = sys.argv[1:]
