@@ -5,6 +5,7 @@ streams and autograd bookkeeping only.  Activations are token-major, channel-las
 rows = (n, t, h, w) flattened -- the reference's window partition and (T, N*HW, C) permutes never materialise.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -187,6 +188,34 @@ def _auto_flush_wgrads():
         flush_wgrads()
 
 
+_pin_pool = {"slots": [], "next": 0}
+
+
+def _to_device_async(host_bytes, dev):
+    """bytes -> uint8 device tensor through a rotating pool of pinned staging buffers with a non-blocking copy: a pageable
+    `.to(device)` would block the host until every kernel enqueued so far has finished (once per step, right where the host
+    should be running ahead into the optimizer and the next forward pass)."""
+    n = len(host_bytes)
+    if os.environ.get("VPTR_SYNC_UPLOAD") == "1":
+        return torch.frombuffer(bytearray(host_bytes), dtype=torch.uint8).to(dev)
+    pool = _pin_pool
+    i = pool["next"] % 16
+    pool["next"] += 1
+    while len(pool["slots"]) <= i:
+        pool["slots"].append([torch.empty(1 << 16, dtype=torch.uint8).pin_memory(), None])
+    slot = pool["slots"][i]
+    if slot[1] is not None:
+        slot[1].synchronize()  # the copy that last used this staging buffer (16 transfers ago) must have completed
+    if slot[0].numel() < n:
+        slot[0] = torch.empty(2 * n, dtype=torch.uint8).pin_memory()
+    slot[0][:n].copy_(torch.frombuffer(bytearray(host_bytes), dtype=torch.uint8))
+    out = slot[0][:n].to(dev, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    slot[1] = ev
+    return out
+
+
 def _launch_wgrad_group(its):
     groups = {}
     for it in its:
@@ -208,8 +237,9 @@ def _launch_wgrad_group(its):
             total += ((N + 127) // 128) * ((K + cols - 1) // cols)
             flops += 2.0 * M * N * K
         dev = grp[0][0].device
-        raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
-        st = torch.tensor(starts, dtype=torch.int32).to(dev)
+        import struct
+        raw = _to_device_async(bytes(descs), dev)
+        st = _to_device_async(struct.pack("%di" % len(starts), *starts), dev)
         prof = _gemm_prof
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
