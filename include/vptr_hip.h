@@ -80,7 +80,7 @@ typedef struct vptr_gemm_desc {
                      (gather form of ConvTranspose2d, ResNetAutoEncoder.py:74-88). */
   int conv_IH, conv_IW, conv_Cin, conv_OH, conv_OW, conv_KH, conv_KW, conv_stride, conv_pad, conv_pad_mode,
       conv_transposed;
-  /* optional [M], a_mode == VPTR_A_KSTRIDED with the pipelined kernels only: a_rowsum[m] += sum_k op(A)[m, k], taken from
+  /* optional [M], a_mode == VPTR_A_KSTRIDED with the pipelined kernels only: a_rowsum[m] += alpha * sum_k op(A)[m, k], taken from
      the registers of the A staging path by the workgroups of column tile 0.  For a weight gradient dW = dY^T . X this is
      the bias gradient (column sums of dY), which then needs no pass of its own. */
   float* a_rowsum;

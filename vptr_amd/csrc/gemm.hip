@@ -573,7 +573,7 @@ __device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, __bf16* sme
         const int q = ob >> 3, lo8 = ob & 7;
         const float v = sred[((2 * q) * 8 + lo8) * 4 + j] + sred[((2 * q + 1) * 8 + lo8) * 4 + j];
         // rows of a clamped out block (beyond M - 4) hold duplicates of other rows: only in-range rows are written
-        if (m0 + tid < p.M && m0 + ob * 4 <= p.M - 4) unsafeAtomicAdd(p.a_rowsum + m0 + tid, v);
+        if (m0 + tid < p.M && m0 + ob * 4 <= p.M - 4) unsafeAtomicAdd(p.a_rowsum + m0 + tid, v * p.alpha);
       }
     }
   }

@@ -148,10 +148,10 @@ def gemm_nfn(N):
 _wgrad_q = []
 
 
-def defer_wgrad(g, x, dW, N, K, M, db=None):
+def defer_wgrad(g, x, dW, N, K, M, db=None, alpha=1.0):
     """record dW[N,K] += g[M,N]^T . x[M,K] (dW, and db if given, must be views of a flat gradient slab); with db the bias
     gradient db[N] += column sums of g rides on the same launch (vptr_gemm_desc::a_rowsum)"""
-    _wgrad_q.append((g, x, dW, N, K, M, config.gemm_precision, db))
+    _wgrad_q.append((g, x, dW, N, K, M, config.gemm_precision, db, float(alpha)))
     # one end-of-backward callback per recorded call: flush_wgrads is idempotent, and registering every time stays correct
     # when an earlier backward died before its callbacks ran (a "callback already queued" flag would then be stale)
     try:
@@ -226,13 +226,13 @@ def _launch_wgrad_group(its):
         starts = []
         total = 0
         flops = 0.0
-        for i, (g, x, dW, N, K, M, _, db) in enumerate(grp):
+        for i, (g, x, dW, N, K, M, _, db, alpha) in enumerate(grp):
             d = descs[i]
             d.A, d.B, d.D = ptr(g), ptr(x), ptr(dW)
             d.a_rowsum = ptr(db)
             d.lda, d.ldb, d.ldd = g.stride(0), x.stride(0), dW.stride(0)
             d.M, d.N, d.K = N, K, M
-            d.a_mode, d.b_mode, d.precision, d.split_k, d.atomic, d.alpha = 1, 1, prec, 1, 1, 1.0
+            d.a_mode, d.b_mode, d.precision, d.split_k, d.atomic, d.alpha = 1, 1, prec, 1, 1, alpha
             starts.append(total)
             total += ((N + 127) // 128) * ((K + cols - 1) // cols)
             flops += 2.0 * M * N * K
@@ -356,7 +356,14 @@ class _LinearFn(torch.autograd.Function):
         dy = _c(dy)
         M, K = x.shape
         N = W.shape[0]
-        if act != ACT_NONE or alpha != 1.0 or rowscale is not None or p > 0:
+        # a bare output scale (the q projections' head_dim^-0.5) needs no pass of its own when the weight / bias gradients go
+        # through the grouped launch: dx = alpha * (dy . W) and dW = alpha * (dy^T . x) take alpha in their GEMM epilogues
+        wslab = flat_grad_for(W) if ctx.needs_input_grad[1] else None
+        bslab0 = flat_grad_for(ctx.bias_ref) if (has_b and ctx.needs_input_grad[2]) else None
+        fold_alpha = (alpha != 1.0 and act == ACT_NONE and rowscale is None and p == 0 and config.group_wgrads
+                      and ctx.needs_input_grad[1] and wslab is not None and (not (has_b and ctx.needs_input_grad[2]) or bslab0 is not None))
+        galpha = alpha if fold_alpha else 1.0
+        if (act != ACT_NONE or alpha != 1.0 or rowscale is not None or p > 0) and not fold_alpha:
             if act == ACT_RELU and (p > 0 or rowscale is not None):
                 raise RuntimeError("ReLU epilogue with dropout/rowscale is not differentiable from its output")
             g = torch.empty_like(dy)
@@ -367,13 +374,13 @@ class _LinearFn(torch.autograd.Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), device=dy.device, dtype=torch.float32)
-            gemm_raw(g, W, dx, M, K, N, 0, 1)                      # dx[M,K] = g[M,N] . W[N,K]
+            gemm_raw(g, W, dx, M, K, N, 0, 1, alpha=galpha)        # dx[M,K] = g[M,N] . W[N,K]
         bias_done = False
         if ctx.needs_input_grad[1]:
             slab = flat_grad_for(W)          # accumulate straight into the flat gradient slab when there is one
             if slab is not None and config.group_wgrads:
                 bslab = flat_grad_for(ctx.bias_ref) if (has_b and ctx.needs_input_grad[2]) else None
-                defer_wgrad(g, x, slab, N, K, M, db=bslab)         # dW[N,K] += g^T . x (+ db), grouped at the end of backward
+                defer_wgrad(g, x, slab, N, K, M, db=bslab, alpha=galpha)   # dW[N,K] += g^T . x (+ db), grouped at the end of backward
                 bias_done = bslab is not None
             else:
                 dW = slab if slab is not None else torch.zeros((N, K), device=dy.device, dtype=torch.float32)
