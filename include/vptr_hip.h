@@ -84,6 +84,20 @@ typedef struct vptr_gemm_desc {
      the registers of the A staging path by the workgroups of column tile 0.  For a weight gradient dW = dY^T . X this is
      the bias gradient (column sums of dY), which then needs no pass of its own. */
   float* a_rowsum;
+  /* Several same-shaped products in ONE launch (0 / 1 = plain GEMM; at most 3; split_k = 1, no conv operand).  A K = 528
+     projection alone is 240 tiles on 256 CUs and half of its time is prologue + epilogue, so the q/k/v projections of an
+     attention (MultiHeadAttentionRPE.py:543-545; nn.MultiheadAttention's in_proj) and their input gradients are issued as:
+       batch  = b: b independent problems; member i > 0 reads A_x<i>, B_x<i> and writes D_x<i> with bias_x<i>, alpha_x<i>
+                (lda/ldb/ldd, shapes, modes, act and dropout settings are shared; no Dpre/residual/atomic);
+       ksegs  = s: ONE output, D = epilogue( sum_i op(A_i)[M,K] * op(B_i)[K,N] ), segment i > 0 reads A_x<i>, B_x<i>
+                (dX = dQ.Wq + dK.Wk + dV.Wv when q, k and v were projected from the same tensor).
+     batch and ksegs are mutually exclusive. */
+  int batch, ksegs;
+  const float *A_x1, *A_x2; /* scalar fields, not arrays: the kernels select them with uniform compares */
+  const float *B_x1, *B_x2;
+  float *D_x1, *D_x2;
+  const float *bias_x1, *bias_x2;
+  float alpha_x1, alpha_x2;
 } vptr_gemm_desc;
 
 int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream);
@@ -132,10 +146,14 @@ int vptr_add_rowtab(const float* x, const float* tab, float* y, int rows, int C,
 int vptr_winattn_fwd(const float* q, const float* k, const float* v, const float* bias_table, const int64_t* rel_index,
                      float* o, int B, int H, int W, int C, int nh, int ws, float dropout_p, const uint64_t* seed_dev,
                      uint32_t site, vptr_stream_t stream);
-/* dq,dk,dv are written; dbias_table is ACCUMULATED (may be null). */
+/* dq,dk,dv are written; dbias_table is ACCUMULATED (may be null).  dq is multiplied by dq_scale on the way out: with
+ * q = alpha * (x Wq^T + bq) (the head_dim^-0.5 of MultiHeadAttentionRPE.py:586 / nn.MultiheadAttention), dq_scale = alpha
+ * makes dq the gradient of the UNSCALED projection, so dQ, dK, dV can feed one K-segmented input-gradient GEMM
+ * (vptr_gemm_desc.ksegs); 1.0 = plain gradient w.r.t. q. */
 int vptr_winattn_bwd(const float* q, const float* k, const float* v, const float* bias_table, const int64_t* rel_index,
                      const float* dout, float* dq, float* dk, float* dv, float* dbias_table, int B, int H, int W, int C,
-                     int nh, int ws, float dropout_p, const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream);
+                     int nh, int ws, float dropout_p, const uint64_t* seed_dev, uint32_t site, float dq_scale,
+                     vptr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Temporal attention core (nn.MultiheadAttention slow path, VidHRFormer_modules.py:74-84,183-187,199-206):
@@ -146,7 +164,7 @@ int vptr_tattn_fwd(const float* q, const float* k, const float* v, float* o, int
                    int causal, float dropout_p, const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream);
 int vptr_tattn_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk, float* dv,
                    int Nb, int Tq, int Tk, int HW, int C, int nh, int causal, float dropout_p, const uint64_t* seed_dev,
-                   uint32_t site, vptr_stream_t stream);
+                   uint32_t site, float dq_scale /* as in vptr_winattn_bwd */, vptr_stream_t stream);
 
 /* Temporal-spatial window attention (TemporalSpatialLocalMultiheadAttention, VidHRFormer_modules.py:219-284 with the
  * permutes of :444-484 folded into index arithmetic): q [(n,tq,h,w), C] (pre-scaled), k, v [(n,tk,h,w), C]; for every

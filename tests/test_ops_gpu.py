@@ -91,6 +91,43 @@ def test_gemm_grouped_wgrad_with_bias_rowsum(ops, dev):
     assert rel(db, g.double().sum(0)) < TOL3
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 528, 528), (5000, 528, 528), (130, 100, 72)])
+def test_gemm_batched_members(ops, dev, M, N, K):
+    """vptr_gemm_desc.batch: three same-shaped problems (own A, B, D, bias, alpha) in one launch == three launches."""
+    xs = [rn((M, K), 200 + i).to(dev) for i in range(3)]
+    Ws = [rn((N, K), 210 + i, K ** -0.5).to(dev) for i in range(3)]
+    bs = [rn((N,), 220 + i).to(dev) for i in range(3)]
+    al = [0.25, 1.0, 2.0]
+    ys = [torch.empty((M, N), device=dev) for _ in range(3)]
+    ops.gemm_raw(xs[0], Ws[0], ys[0], M, N, K, 0, 0, bias=bs[0], alpha=al[0],
+                 batch_extra=[(xs[1], Ws[1], ys[1], bs[1], al[1]), (xs[2], Ws[2], ys[2], None, al[2])])
+    for i in range(3):
+        ref = (xs[i].double().cpu() @ Ws[i].double().cpu().t() + (bs[i].double().cpu() if i < 2 else 0.0)) * al[i]
+        assert rel(ys[i], ref) < TOL3
+    # two members, k-strided B (the input-gradient orientation)
+    gs = [rn((M, N), 230 + i).to(dev) for i in range(2)]
+    ds = [torch.empty((M, K), device=dev) for _ in range(2)]
+    ops.gemm_raw(gs[0], Ws[0], ds[0], M, K, N, 0, 1, batch_extra=[(gs[1], Ws[1], ds[1], None, 1.0)])
+    for i in range(2):
+        assert rel(ds[i], gs[i].double().cpu() @ Ws[i].double().cpu()) < TOL3
+
+
+@pytest.mark.parametrize("M,N,K,nseg", [(300, 528, 528, 3), (5000, 528, 528, 2), (130, 72, 100, 3), (1000, 528, 48, 2)])
+def test_gemm_k_segments(ops, dev, M, N, K, nseg):
+    """vptr_gemm_desc.ksegs: D = sum_s A_s[M,K] . B_s[K,N] (+ epilogue), every segment with its own K tail."""
+    gs = [rn((M, K), 240 + i).to(dev) for i in range(nseg)]
+    Ws = [rn((K, N), 250 + i, K ** -0.5).to(dev) for i in range(nseg)]      # k-strided B: [K, N]
+    r = rn((M, N), 260).to(dev)
+    y = torch.empty((M, N), device=dev)
+    ops.gemm_raw(gs[0], Ws[0], y, M, N, K, 0, 1, alpha=0.5, residual=r, kseg_extra=[(gs[i], Ws[i]) for i in range(1, nseg)])
+    ref = sum(g.double().cpu() @ W.double().cpu() for g, W in zip(gs, Ws)) * 0.5 + r.double().cpu()
+    assert rel(y, ref) < TOL3
+    # k-contiguous B as well
+    Wt = [W.t().contiguous() for W in Ws]
+    ops.gemm_raw(gs[0], Wt[0], y, M, N, K, 0, 0, kseg_extra=[(gs[i], Wt[i]) for i in range(1, nseg)])
+    assert rel(y, (ref - r.double().cpu()) * 2.0) < TOL3
+
+
 def test_gemm_epilogue_variants(ops, dev):
     M, N, K = 200, 176, 64
     x, W = rn((M, K), 9), rn((N, K), 10, K ** -0.5)
@@ -245,6 +282,74 @@ def test_temporal_attention(ops, dev, Tq, Tk, causal):
     assert rel(od, o) < TOLV
     for a, c in zip(ds, ins):
         assert rel(a.grad, c.grad) < 5e-5
+
+
+def _proj_ref(ops, xq, xk, xv, Ws, bs, nh, attend):
+    """composition of the separate nodes: three linears (alpha on q) + the attention core"""
+    C = Ws[0].shape[0]
+    q = ops.linear(xq, Ws[0], bs[0], alpha=float(C // nh) ** -0.5)
+    k = ops.linear(xk, Ws[1], bs[1])
+    v = ops.linear(xv, Ws[2], bs[2])
+    return attend(q, k, v)
+
+
+@pytest.mark.parametrize("variant", ["same_all", "same_qk", "merge_v"])
+def test_proj_window_attention_matches_composition(ops, dev, variant):
+    """fused q/k/v-projection + window-attention node (batched GEMM, dq_scale, K-segmented input gradient) == separate nodes"""
+    B, H, W, C, nh, ws = 5, 8, 8, 48, 8, 4
+    M = B * H * W
+    idx = O.rpe_index(ws).to(dev)
+    go = rn((M, C), 300).to(dev)
+    tab = rn((H * W, C), 301, 0.3).to(dev)
+
+    def run(fused):
+        x = rn((M, C), 302).to(dev).requires_grad_(True)
+        Ws = [rn((C, C), 303 + i, C ** -0.5).to(dev).requires_grad_(True) for i in range(3)]
+        bs = [rn((C,), 306 + i).to(dev).requires_grad_(True) for i in range(3)]
+        table = rn(((2 * ws - 1) ** 2, nh), 309, 0.5).to(dev).requires_grad_(True)
+        xqk = x if variant == "same_all" else ops.add_rowtab(x, tab, 1, H * W)
+        if fused:
+            o = ops.proj_window_attention(xqk, x, Ws[0], bs[0], Ws[1], bs[1], Ws[2], bs[2], table, idx, B, H, W, nh, ws,
+                                          merge_v_grad=(variant == "merge_v"))
+        else:
+            o = _proj_ref(ops, xqk, xqk, x, Ws, bs, nh, lambda q, k, v: ops.window_attention(q, k, v, table, idx, B, H, W, nh, ws))
+        (o * go).sum().backward()
+        return [o.detach(), x.grad, table.grad] + [w.grad for w in Ws] + [b.grad for b in bs]
+    for a, c in zip(run(True), run(False)):
+        assert rel(a, c.double().cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("variant,Tq,Tk", [("self_merge", 5, 5), ("self", 5, 5), ("cross", 5, 5), ("cross", 3, 7)])
+def test_proj_temporal_attention_matches_composition(ops, dev, variant, Tq, Tk):
+    N, HW, C, nh = 2, 40, 48, 8
+    Mq, Mk = N * Tq * HW, N * Tk * HW
+    go = rn((Mq, C), 320).to(dev)
+    tab = rn((Tq, C), 321, 0.3).to(dev)
+
+    def run(fused):
+        xq = rn((Mq, C), 322).to(dev).requires_grad_(True)
+        xk = rn((Mk, C), 323).to(dev).requires_grad_(True)
+        xv = rn((Mk, C), 324).to(dev).requires_grad_(True)
+        w = rn((3 * C, C), 325, C ** -0.5).to(dev).requires_grad_(True)      # packed in_proj of nn.MultiheadAttention
+        b = rn((3 * C,), 326).to(dev).requires_grad_(True)
+        Ws, bs = [w[:C], w[C:2 * C], w[2 * C:]], [b[:C], b[C:2 * C], b[2 * C:]]
+        if variant == "cross":
+            a_q, a_k, a_v = xq, xk, xv
+        else:
+            a_q = a_k = ops.add_rowtab(xq, tab, HW, Tq)
+            a_v = xq
+        if fused:
+            o = ops.proj_temporal_attention(a_q, a_k, a_v, Ws[0], bs[0], Ws[1], bs[1], Ws[2], bs[2], N, Tq, Tk, HW, nh,
+                                            merge_v_grad=(variant == "self_merge"))
+        else:
+            o = _proj_ref(ops, a_q, a_k, a_v, Ws, bs, nh, lambda q, k, v: ops.temporal_attention(q, k, v, N, Tq, Tk, HW, nh))
+        (o * go).sum().backward()
+        out = [o.detach(), xq.grad, w.grad, b.grad]
+        if variant == "cross":
+            out += [xk.grad, xv.grad]
+        return out
+    for a, c in zip(run(True), run(False)):
+        assert rel(a, c.double().cpu()) < 2e-5
 
 
 # ------------------------------------------------------------------------------------------------------ conv-FFN pieces

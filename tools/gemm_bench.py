@@ -12,6 +12,9 @@ shapes = [
     ("dgrd 528x528", 0, 1, Mtok, 528, 528), ("dgrd 528<-2112", 0, 1, Mtok, 528, 2112), ("dgrd 2112<-528", 0, 1, Mtok, 2112, 528),
     ("wgrd 528x528", 1, 1, 528, 528, Mtok), ("wgrd 2112x528", 1, 1, 2112, 528, Mtok), ("wgrd 528x2112", 1, 1, 528, 2112, Mtok),
 ]
+if os.environ.get("EXTRA"):
+    shapes += [("fwd  1056x528", 0, 0, Mtok, 1056, 528), ("fwd  1584x528", 0, 0, Mtok, 1584, 528),
+               ("dgrd 528<-1056", 0, 1, Mtok, 528, 1056), ("dgrd 528<-1584", 0, 1, Mtok, 528, 1584)]
 precs = [int(p) for p in os.environ.get("PRECS", "3,1").split(",")]
 res = []
 only = os.environ.get("ONLY")

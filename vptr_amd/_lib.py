@@ -33,6 +33,9 @@ class GemmDesc(ctypes.Structure):
         ("conv_KH", c_int), ("conv_KW", c_int), ("conv_stride", c_int), ("conv_pad", c_int), ("conv_pad_mode", c_int),
         ("conv_transposed", c_int),
         ("a_rowsum", c_void_p),
+        ("batch", c_int), ("ksegs", c_int),
+        ("A_x1", c_void_p), ("A_x2", c_void_p), ("B_x1", c_void_p), ("B_x2", c_void_p), ("D_x1", c_void_p), ("D_x2", c_void_p),
+        ("bias_x1", c_void_p), ("bias_x2", c_void_p), ("alpha_x1", c_float), ("alpha_x2", c_float),
     ]
 
 
@@ -49,9 +52,9 @@ SIGNATURES = {
     "vptr_window_copy": [P, P, I, I, I, I, I, I, I, I, P],
     "vptr_add_rowtab": [P, P, P, I, I, I, I, P],
     "vptr_winattn_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, P],
-    "vptr_winattn_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, P],
+    "vptr_winattn_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, F, P],
     "vptr_tattn_fwd": [P, P, P, P, I, I, I, I, I, I, I, F, P, U, P],
-    "vptr_tattn_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, P, U, P],
+    "vptr_tattn_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, P, U, F, P],
     "vptr_tsattn_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, F, P, U, P],
     "vptr_tsattn_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P, U, P],
     "vptr_colstats": [P, P, P, P, F, P, I, I, P],
@@ -93,7 +96,7 @@ def _load():
         fn.restype = c_int
     lib.vptr_abi_version.restype = c_int
     lib.vptr_last_error.restype = ctypes.c_char_p
-    if lib.vptr_abi_version() != 1:
+    if lib.vptr_abi_version() != 2:
         raise ImportError("vptr_amd: ABI version mismatch in %s" % LIB_PATH)
     return lib
 

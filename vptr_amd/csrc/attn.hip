@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void winattn16_bwd_kernel(const float* __restr
                                                             const int64_t* __restrict__ rel_index, const float* __restrict__ dout,
                                                             float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
                                                             float* __restrict__ dtable, int nwin, int H, int W, int C, int nh,
-                                                            float p, const uint64_t* seed_dev, uint32_t site, int wpb) {
+                                                            float p, const uint64_t* seed_dev, uint32_t site, int wpb,
+                                                            float dq_scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int hd = C / nh, hp = att_pitch(hd), n4 = hp >> 2;
   float* sq = smem;             // [16][hp]
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void winattn16_bwd_kernel(const float* __restr
         axpy4(av, sp[c * 20 + r], reinterpret_cast<const float4*>(sdo + c * hp)[d4]);
       }
       const int64_t g = srow[r] + h * hd;
-      store4(dq, g, d4 * 4, hd, aq);
+      store4(dq, g, d4 * 4, hd, make_float4(aq.x * dq_scale, aq.y * dq_scale, aq.z * dq_scale, aq.w * dq_scale));
       store4(dk, g, d4 * 4, hd, ak);
       store4(dv, g, d4 * 4, hd, av);
     }
@@ -270,7 +271,8 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const float* __restric
                                                           const int64_t* __restrict__ rel_index, const float* __restrict__ dout,
                                                           float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
                                                           float* __restrict__ dtable, int nwin, int H, int W, int C, int nh,
-                                                          int ws, float p, const uint64_t* seed_dev, uint32_t site, int wpb) {
+                                                          int ws, float p, const uint64_t* seed_dev, uint32_t site, int wpb,
+                                                          float dq_scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int L = ws * ws, hd = C / nh, hp = hd + 1, Lp = L + 1;
   const int ntab = (2 * ws - 1) * (2 * ws - 1);
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const float* __restric
         av += sp[j * Lp + i] * sdo[j * hp + d];
       }
       const int64_t g = (int64_t)srow[i] * C + h * hd + d;
-      dq[g] = aq;
+      dq[g] = aq * dq_scale;
       dk[g] = ak;
       dv[g] = av;
     }
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const float* __restric
 extern "C" int vptr_winattn_bwd(const float* q, const float* k, const float* v, const float* bias_table,
                                 const int64_t* rel_index, const float* dout, float* dq, float* dk, float* dv,
                                 float* dbias_table, int B, int H, int W, int C, int nh, int ws, float dropout_p,
-                                const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream) {
+                                const uint64_t* seed_dev, uint32_t site, float dq_scale, vptr_stream_t stream) {
   VPTR_CHECK(B > 0 && H > 0 && W > 0 && C > 0 && nh > 0 && ws > 0, "winattn_bwd: bad arguments");
   VPTR_CHECK(C % nh == 0 && H % ws == 0 && W % ws == 0 && ws * ws <= ATT_MAXL, "winattn_bwd: unsupported geometry");
   if (bias_table || dbias_table) VPTR_CHECK(rel_index != nullptr, "winattn_bwd: bias table needs rel_index");
@@ -375,7 +377,7 @@ extern "C" int vptr_winattn_bwd(const float* q, const float* k, const float* v, 
     const size_t lds16 = sizeof(float) * (4 * 16 * att_pitch(hd) + 2 * 16 * 20);
     winattn16_bwd_kernel<<<dim3(cdiv(nwin, wpb16), nh), 256, lds16, (hipStream_t)stream>>>(q, k, v, bias_table, rel_index, dout, dq, dk,
                                                                                           dv, dbias_table, nwin, H, W, C, nh,
-                                                                                          dropout_p, seed_dev, site, wpb16);
+                                                                                          dropout_p, seed_dev, site, wpb16, dq_scale);
     VPTR_LAUNCH_CHECK();
     return 0;
   }
@@ -386,7 +388,7 @@ extern "C" int vptr_winattn_bwd(const float* q, const float* k, const float* v, 
     (void)hipFuncSetAttribute((const void*)winattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   winattn_bwd_kernel<<<dim3(cdiv(nwin, wpb), nh), 256, lds, (hipStream_t)stream>>>(q, k, v, bias_table, rel_index, dout, dq, dk, dv,
                                                                                  dbias_table, nwin, H, W, C, nh, ws, dropout_p,
-                                                                                 seed_dev, site, wpb);
+                                                                                 seed_dev, site, wpb, dq_scale);
   VPTR_LAUNCH_CHECK();
   return 0;
 }
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(64) void tattn16_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ v, const float* __restrict__ dout,
                                                          float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
                                                          int Tq, int Tk, int HW, int C, int nh, int causal, float p,
-                                                         const uint64_t* seed_dev, uint32_t site, int NP) {
+                                                         const uint64_t* seed_dev, uint32_t site, int NP, float dq_scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int hd = C / nh, hp = att_pitch(hd), n4 = hp >> 2;
   float* sq = smem;               // [Tq][hp]
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(64) void tattn16_bwd_kernel(const float* __restrict
     if (d4 * 4 >= hd) continue;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c = 0; c < Tk; ++c) axpy4(acc, sds[i * 20 + c], reinterpret_cast<const float4*>(sk + c * hp)[d4]);
-    store4(dq, rq[i] + h * hd, d4 * 4, hd, acc);
+    store4(dq, rq[i] + h * hd, d4 * 4, hd, make_float4(acc.x * dq_scale, acc.y * dq_scale, acc.z * dq_scale, acc.w * dq_scale));
   }
   for (int e = lane; e < Tk * n4; e += 64) {
     const int c = e / n4, d4 = e - c * n4;
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(64) void tattn_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ v, const float* __restrict__ dout,
                                                        float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
                                                        int Tq, int Tk, int HW, int C, int nh, int causal, float p,
-                                                       const uint64_t* seed_dev, uint32_t site) {
+                                                       const uint64_t* seed_dev, uint32_t site, float dq_scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int hd = C / nh, hp = hd + 1, Tp = Tk + 1;
   float* sq = smem;              // [Tq][hp]
@@ -666,7 +668,7 @@ __global__ __launch_bounds__(64) void tattn_bwd_kernel(const float* __restrict__
     const int i = e / hd, d = e - i * hd;
     float a = 0.f;
     for (int j = 0; j < Tk; ++j) a += sds[i * Tp + j] * sk[j * hp + d];
-    dq[((int64_t)(n * Tq + i) * HW + pix) * C + h * hd + d] = a;
+    dq[((int64_t)(n * Tq + i) * HW + pix) * C + h * hd + d] = a * dq_scale;
   }
   for (int e = lane; e < Tk * hd; e += 64) {
     const int j = e / hd, d = e - j * hd;
@@ -683,7 +685,7 @@ __global__ __launch_bounds__(64) void tattn_bwd_kernel(const float* __restrict__
 
 extern "C" int vptr_tattn_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,
                               float* dv, int Nb, int Tq, int Tk, int HW, int C, int nh, int causal, float dropout_p,
-                              const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream) {
+                              const uint64_t* seed_dev, uint32_t site, float dq_scale, vptr_stream_t stream) {
   VPTR_CHECK(Nb > 0 && Tq > 0 && Tk > 0 && HW > 0 && C > 0 && nh > 0, "tattn_bwd: bad arguments");
   VPTR_CHECK(C % nh == 0 && Tq <= ATT_MAXT && Tk <= ATT_MAXT, "tattn_bwd: unsupported geometry");
   if (causal) VPTR_CHECK(Tq == Tk, "tattn_bwd: causal mask needs Tq == Tk");
@@ -692,7 +694,7 @@ extern "C" int vptr_tattn_bwd(const float* q, const float* k, const float* v, co
   if (Tq <= 16 && Tk <= 16 && hd % 2 == 0 && C % 2 == 0) {
     const size_t lds16 = sizeof(float) * (2 * (Tq + Tk) * att_pitch(hd) + 2 * 16 * 20);
     tattn16_bwd_kernel<<<dim3(cdiv(Nb * HW, 8) * 8 * nh), 64, lds16, (hipStream_t)stream>>>(q, k, v, dout, dq, dk, dv, Tq, Tk, HW, C, nh,
-                                                                                           causal, dropout_p, seed_dev, site, Nb * HW);
+                                                                                           causal, dropout_p, seed_dev, site, Nb * HW, dq_scale);
     VPTR_LAUNCH_CHECK();
     return 0;
   }
@@ -701,7 +703,7 @@ extern "C" int vptr_tattn_bwd(const float* q, const float* k, const float* v, co
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)tattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   tattn_bwd_kernel<<<dim3(Nb * HW, nh), 64, lds, (hipStream_t)stream>>>(q, k, v, dout, dq, dk, dv, Tq, Tk, HW, C, nh, causal,
-                                                                       dropout_p, seed_dev, site);
+                                                                       dropout_p, seed_dev, site, dq_scale);
   VPTR_LAUNCH_CHECK();
   return 0;
 }

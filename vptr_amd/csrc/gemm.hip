@@ -277,9 +277,101 @@ struct StageConv {
   }
 };
 
-// ---- epilogue (shared by both main-loop variants)
-template <int NFN>
+// ---- epilogue of the pipelined loop (one workgroup per CU: nothing else hides its latencies)
+template <int NFN, int NGRP>  // NGRP: column-fragment groups, each = all its loads, then its stores (2 under a 128-VGPR cap)
 __device__ __forceinline__ void gemm_epilogue(const vptr_gemm_desc& p, f32x4 (&acc)[2][(NFN + 1) / 2], const int m0, const int n0,
+                                              const int wm, const int wn, const int lr, const int lq, const bool first_split,
+                                              const bool use_atomic) {
+  constexpr int NFW = (NFN + 1) / 2;
+  // ---- epilogue: C/D fragment layout of v_mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg.
+  // Every acc index is a compile-time constant (fully unrolled, no `continue`).
+  // Phase 0 issues EVERY load of the epilogue (bias, column / row scales, the residual tile) before the first store: D may
+  // alias the residual, so hipcc keeps loads behind earlier stores, and the first version's load -> add -> store chain per
+  // element cost 48 dependent HBM round trips per lane (+40 us on a 34 us K = 528 GEMM with a residual).
+  const bool plain = !p.colscale && !p.Dpre && p.act == VPTR_ACT_NONE && !p.rowscale && p.dropout_p == 0.f && !p.act_after &&
+                     p.alpha == 1.f;
+  const int row_base = m0 + wm * 32 + lq * 4;
+  const bool has_res = p.residual && first_split;
+  int col[NFW];
+  bool colok[NFW];
+  constexpr int GW = (NFW + NGRP - 1) / NGRP;
+  float bs[NFW], cs[NFW], rsv[2][4], res[GW][2][4];
+#pragma unroll
+  for (int ni = 0; ni < NFW; ++ni) {
+    const int nf = wn * NFW + ni;
+    col[ni] = n0 + nf * 16 + lr;
+    colok[ni] = (nf < NFN) & (col[ni] < p.N);
+    bs[ni] = (p.bias && first_split && colok[ni]) ? p.bias[col[ni]] : 0.f;
+    cs[ni] = (p.colscale && colok[ni]) ? p.colscale[col[ni]] : 1.f;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row_base + mi * 16 + r;
+      rsv[mi][r] = (p.rowscale && row < p.M) ? p.rowscale[(row / p.rs_div) % p.rs_mod] : 1.f;
+    }
+  uint64_t seed = 0;
+  if (p.dropout_p > 0.f) seed = *p.seed_dev;
+#pragma unroll
+  for (int g0 = 0; g0 < NFW; g0 += GW) {
+#pragma unroll
+  for (int ni = g0; ni < g0 + GW && ni < NFW; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row_base + mi * 16 + r;
+        res[ni - g0][mi][r] = (has_res && colok[ni] && row < p.M) ? p.residual[(int64_t)row * p.ldr + col[ni]] : 0.f;
+      }
+  if (plain) {  // kernel-uniform fast path: bias (+ residual), store or atomic accumulate
+#pragma unroll
+    for (int ni = g0; ni < g0 + GW && ni < NFW; ++ni) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row_base + mi * 16 + r;
+          if (colok[ni] && row < p.M) {
+            const float v = acc[mi][ni][r] + bs[ni] + res[ni - g0][mi][r];
+            float* dst = p.D + (int64_t)row * p.ldd + col[ni];
+            if (use_atomic) unsafeAtomicAdd(dst, v);
+            else *dst = v;
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int ni = g0; ni < g0 + GW && ni < NFW; ++ni) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row_base + mi * 16 + r;
+          if (colok[ni] && row < p.M) {
+            float v = (acc[mi][ni][r] * cs[ni] + bs[ni]) * p.alpha;
+            if (p.Dpre) p.Dpre[(int64_t)row * p.ldd + col[ni]] = v;
+            v = vptr_act(v, p.act) * rsv[mi][r];
+            if (p.dropout_p > 0.f) v *= vptr_drop_scale(seed, p.site, (uint64_t)row * (uint64_t)p.N + col[ni], p.dropout_p);
+            v += res[ni - g0][mi][r];
+            if (p.act_after) v = v > 0.f ? v : 0.f;
+            float* dst = p.D + (int64_t)row * p.ldd + col[ni];
+            if (use_atomic) unsafeAtomicAdd(dst, v);
+            else *dst = v;
+          }
+        }
+      }
+    }
+  }
+  }
+}
+
+
+// ---- epilogue of the single-image loop: element by element (load -> compute -> store).  Two workgroups share the CU there and
+// cover each other's latencies, and under its 128-VGPR cap the batched-load form below spills (measured: fc1 156 -> 200 us).
+template <int NFN>
+__device__ __forceinline__ void gemm_epilogue_serial(const vptr_gemm_desc& p, f32x4 (&acc)[2][(NFN + 1) / 2], const int m0, const int n0,
                                               const int wm, const int wn, const int lr, const int lq, const bool first_split,
                                               const bool use_atomic) {
   constexpr int NFW = (NFN + 1) / 2;
@@ -343,8 +435,49 @@ __device__ __forceinline__ void gemm_epilogue(const vptr_gemm_desc& p, f32x4 (&a
   }
 }
 
+// Batched launches (desc.batch > 1): member b > 0 of the grid reads A_x<b>/B_x<b> and writes D_x<b> with bias_x<b> / alpha_x<b>.
+__device__ __forceinline__ vptr_gemm_desc member_view(const vptr_gemm_desc& p, const int member) {
+  vptr_gemm_desc q = p;
+  if (member > 0) {  // workgroup-uniform
+    const bool one = member == 1;
+    q.A = one ? p.A_x1 : p.A_x2;
+    q.B = one ? p.B_x1 : p.B_x2;
+    q.D = one ? p.D_x1 : p.D_x2;
+    q.bias = one ? p.bias_x1 : p.bias_x2;
+    q.alpha = one ? p.alpha_x1 : p.alpha_x2;
+  }
+  return q;
+}
+// K-segment cursor (desc.ksegs > 1: D = sum_s op(A_s) op(B_s), every segment K long): K-step kt of the virtual K range
+// -> operand pointers and the k offset inside the segment.  Steps beyond the last segment (prefetch) land at k >= K of the
+// last one, i.e. fully masked.  Two compares instead of a division: ksegs <= 3.
+struct KSeg {
+  int spk, last;  // K-steps per segment; index of the last segment
+  __device__ __forceinline__ KSeg(const vptr_gemm_desc& p) {
+    last = p.ksegs > 1 ? p.ksegs - 1 : 0;
+    spk = last ? (p.K + GBK - 1) / GBK : (1 << 26);
+  }
+  __device__ __forceinline__ int steps(const int kbeg, const int kend) const {
+    return last ? (last + 1) * spk : (kend - kbeg + GBK - 1) / GBK;
+  }
+  // segment index and k offset of K-step kt
+  __device__ __forceinline__ int seg(const int kbeg, const int kt, int& k0) const {
+    const int s = min((int)(kt >= spk) + (int)(kt >= 2 * spk), last);
+    k0 = kbeg + (kt - s * spk) * GBK;
+    return s;
+  }
+};
+// operand of segment s as base + element offset (offsets are plain integers: selecting between POINTERS read from the
+// descriptor made hipcc keep the descriptor in scratch)
+#define KSEG_OFFSETS(p)                                                                  \
+  const int64_t ksA1 = (p).ksegs > 1 ? (p).A_x1 - (p).A : 0, ksA2 = (p).ksegs > 2 ? (p).A_x2 - (p).A : 0; \
+  const int64_t ksB1 = (p).ksegs > 1 ? (p).B_x1 - (p).B : 0, ksB2 = (p).ksegs > 2 ? (p).B_x2 - (p).B : 0;
+#define KSEG_PTRS(p, s, Ak, Bk)                                           \
+  const float* Ak = (p).A + ((s) == 0 ? (int64_t)0 : ((s) == 1 ? ksA1 : ksA2)); \
+  const float* Bk = (p).B + ((s) == 0 ? (int64_t)0 : ((s) == 1 ? ksB1 : ksB2));
+
 template <int NFN, int NPASS, int AMODE, int BMODE>
-__global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc p, const int k_chunk) {
+__global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc p0, const int k_chunk) {
   constexpr int BN = 16 * NFN;
   constexpr int NFW = (NFN + 1) / 2;     // column fragments per wave
   constexpr int BROWS = 2 * NFW * 16;    // LDS rows of the B image (>= BN; the surplus rows feed never-stored fragments)
@@ -362,14 +495,19 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc 
   // range of the (split, tile_m, tile_n) order, so the A row panel of a tile_m is fetched by one L2 instead of all eight.
   const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
   const int logical = xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles = tiles_n * ((p.M + GBM - 1) / GBM);
-  const int split = logical / tiles, tile = logical - split * tiles;
+  const int tiles_n = (p0.N + BN - 1) / BN;
+  const int tiles = tiles_n * ((p0.M + GBM - 1) / GBM);
+  const int grp = logical / tiles, tile = logical - grp * tiles;
+  const bool batched = p0.batch > 1;                 // the grid's outer index is the batch member or the K split
+  const int split = batched ? 0 : grp;
+  const vptr_gemm_desc p = member_view(p0, batched ? grp : 0);
   const int tn = tile % tiles_n, tm = tile / tiles_n;
   const int m0 = tm * GBM, n0 = tn * BN;
   const int kbeg = split * k_chunk;
   const int kend = min(p.K, kbeg + k_chunk);
-  const int nkt = (kend - kbeg + GBK - 1) / GBK;
+  const KSeg ks(p);
+  KSEG_OFFSETS(p)
+  const int nkt = ks.steps(kbeg, kend);
 
   f32x4 acc[2][NFW];
 #pragma unroll
@@ -382,9 +520,15 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc 
   TS_DECL
   // K-step j+1 is fetched into registers while step j is multiplied out of LDS (single LDS image, two barriers per step);
   // the other resident waves of the SIMD cover what is left of the HBM / LDS latencies.
-  if constexpr (AMODE == VPTR_A_CONV) stA.load(p, m0, kbeg, kend, tid);
-  else stA.load(p.A, p.lda, m0, p.M, kbeg, kend, tid);
-  stB.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid);
+  auto load_step = [&](const int kt) {
+    int k0;
+    const int sg = ks.seg(kbeg, kt, k0);
+    KSEG_PTRS(p, sg, Ak, Bk)
+    if constexpr (AMODE == VPTR_A_CONV) stA.load(p, m0, k0, kend, tid);
+    else stA.load(Ak, p.lda, m0, p.M, k0, kend, tid);
+    stB.load(Bk, p.ldb, n0, p.N, k0, kend, tid);
+  };
+  load_step(0);
 
   TS(0)
   for (int kt = 0; kt < nkt; ++kt) {
@@ -393,12 +537,7 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc 
     TS(1)
     __syncthreads();
     TS(2)
-    {  // unconditional prefetch of the next step (clamped + masked beyond the K range)
-      const int k1 = kbeg + (kt + 1) * GBK;
-      if constexpr (AMODE == VPTR_A_CONV) stA.load(p, m0, k1, kend, tid);
-      else stA.load(p.A, p.lda, m0, p.M, k1, kend, tid);
-      stB.load(p.B, p.ldb, n0, p.N, k1, kend, tid);
-    }
+    load_step(kt + 1);  // unconditional prefetch of the next step (clamped + masked beyond the K range)
     TS(3)
     bf16x8 ah[2], al[2];
 #pragma unroll
@@ -427,7 +566,7 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc 
     TS(2)
   }
 
-  gemm_epilogue<NFN>(p, acc, m0, n0, wm, wn, lr, lq, split == 0, p.atomic || nblk > tiles);
+  gemm_epilogue_serial<NFN>(p, acc, m0, n0, wm, wn, lr, lq, split == 0, p.atomic || (!batched && nblk > tiles));
   TS(5)
   TS_FLUSH
 }
@@ -452,7 +591,9 @@ __device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, __bf16* sme
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 15, lq = lane >> 4;
-  const int nkt = (kend - kbeg + GBK - 1) / GBK;
+  const KSeg ks(p);
+  KSEG_OFFSETS(p)
+  const int nkt = ks.steps(kbeg, kend);
 
   f32x4 acc[2][NFW];
 #pragma unroll
@@ -464,18 +605,16 @@ __device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, __bf16* sme
   StB stB0, stB1;
   TS_DECL
   // VPTR_EXP_NOLOAD / VPTR_EXP_NOCVT: elimination experiments of tools/gemm_probe.hip (results in DESIGN.md section 4)
-  auto loadA = [&](StA& st, const int k0) {
+  auto loadAB = [&](StA& sa, StB& sb, const int kt) {  // operands of K-step kt into a register set
 #ifdef VPTR_EXP_NOLOAD
-    if (k0 > kbeg + 2 * GBK) return;
+    if (kt > 2) return;
 #endif
-    if constexpr (AMODE == VPTR_A_CONV) st.load(p, m0, k0, kend, tid);
-    else st.load(p.A, p.lda, m0, p.M, k0, kend, tid);
-  };
-  auto loadB = [&](StB& st, const int k0) {
-#ifdef VPTR_EXP_NOLOAD
-    if (k0 > kbeg + 2 * GBK) return;
-#endif
-    st.load(p.B, p.ldb, n0, p.N, k0, kend, tid);
+    int k0;
+    const int sg = ks.seg(kbeg, kt, k0);
+    KSEG_PTRS(p, sg, Ak, Bk)
+    if constexpr (AMODE == VPTR_A_CONV) sa.load(p, m0, k0, kend, tid);
+    else sa.load(Ak, p.lda, m0, p.M, k0, kend, tid);
+    sb.load(Bk, p.ldb, n0, p.N, k0, kend, tid);
   };
   // fragment read offsets (bf16 elements inside one plane)
   int offA[2], offB[NFW];
@@ -523,10 +662,8 @@ __device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, __bf16* sme
     }
   };
 
-  loadA(stA0, kbeg);
-  loadB(stB0, kbeg);
-  loadA(stA1, kbeg + GBK);
-  loadB(stB1, kbeg + GBK);
+  loadAB(stA0, stB0, 0);
+  loadAB(stA1, stB1, 1);
   TS(0)
   stA0.template store<NPASS>(smem, smem + (NPL - 1) * A_EL, tid);
   stB0.template store<NPASS>(smem + NPL * A_EL, smem + NPL * A_EL + (NPL - 1) * B_EL, tid);
@@ -535,8 +672,7 @@ __device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, __bf16* sme
   TS(2)
   for (int kt = 0; kt < nkt; kt += 2) {
     // even step: buffer 0 holds step kt, set 1 holds step kt+1, set 0 is free -> fetch step kt+2 into it
-    loadA(stA0, kbeg + (kt + 2) * GBK);
-    loadB(stB0, kbeg + (kt + 2) * GBK);
+    loadAB(stA0, stB0, kt + 2);
     __builtin_amdgcn_sched_barrier(0);  // keep the loads up here: hipcc otherwise sinks them to the end of the step
     TS(3)
     step(0, stA1, stB1);
@@ -544,8 +680,7 @@ __device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, __bf16* sme
     __syncthreads();
     TS(2)
     if (kt + 1 < nkt) {  // workgroup-uniform
-      loadA(stA1, kbeg + (kt + 3) * GBK);
-      loadB(stB1, kbeg + (kt + 3) * GBK);
+      loadAB(stA1, stB1, kt + 3);
       __builtin_amdgcn_sched_barrier(0);
       TS(3)
       step(1, stA0, stB0);
@@ -554,7 +689,7 @@ __device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, __bf16* sme
       TS(2)
     }
   }
-  gemm_epilogue<NFN>(p, acc, m0, n0, wm, wn, lr, lq, first_split, use_atomic);
+  gemm_epilogue<NFN, 1>(p, acc, m0, n0, wm, wn, lr, lq, first_split, use_atomic);
   if constexpr (AMODE == VPTR_A_KSTRIDED) {
     if (p.a_rowsum && n0 == 0) {  // workgroup-uniform: column tile 0 owns the row sums of its A panel
       // thread (kb2, ob) summed k = kb2*2 + {0,1} (mod 32) of rows ob*4 + j: fold the 8 kb2 lanes, then the wave pair
@@ -589,15 +724,18 @@ __device__ __forceinline__ int xcd_logical_block() {
 }
 
 template <int NFN, int NPASS, int AMODE, int BMODE>
-__global__ __launch_bounds__(GNT, 2) void vptr_gemm_kernel_p(const vptr_gemm_desc p, const int k_chunk) {
+__global__ __launch_bounds__(GNT, 2) void vptr_gemm_kernel_p(const vptr_gemm_desc p0, const int k_chunk) {
   extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
   const int logical = xcd_logical_block();
-  const int tiles_n = (p.N + 16 * NFN - 1) / (16 * NFN);
-  const int tiles = tiles_n * ((p.M + GBM - 1) / GBM);
-  const int split = logical / tiles, tile = logical - split * tiles;
+  const int tiles_n = (p0.N + 16 * NFN - 1) / (16 * NFN);
+  const int tiles = tiles_n * ((p0.M + GBM - 1) / GBM);
+  const int grp = logical / tiles, tile = logical - grp * tiles;
+  const bool batched = p0.batch > 1;
+  const int split = batched ? 0 : grp;
+  const vptr_gemm_desc p = member_view(p0, batched ? grp : 0);
   const int kbeg = split * k_chunk;
   gemm_tile_p<NFN, NPASS, AMODE, BMODE>(p, smem, (tile / tiles_n) * GBM, (tile % tiles_n) * 16 * NFN, kbeg, min(p.K, kbeg + k_chunk),
-                                        split == 0, p.atomic || (int)gridDim.x > tiles);
+                                        split == 0, p.atomic || (!batched && (int)gridDim.x > tiles));
 }
 
 // Grouped launch: `count` independent problems (same operand modes / precision / NFN class) in one grid, no split-K.
@@ -718,6 +856,22 @@ extern "C" int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream) {
   if (d.dropout_p > 0.f) VPTR_CHECK(d.seed_dev != nullptr && d.dropout_p < 1.f, "vptr_gemm: dropout needs seed_dev and p < 1");
   if (d.rowscale) VPTR_CHECK(d.rs_div >= 1 && d.rs_mod >= 1, "vptr_gemm: rowscale needs rs_div, rs_mod >= 1");
   if (d.alpha == 0.f) d.alpha = 1.f;
+  if (d.batch < 1) d.batch = 1;
+  if (d.ksegs < 1) d.ksegs = 1;
+  VPTR_CHECK(d.batch <= 3 && d.ksegs <= 3, "vptr_gemm: at most 3 batch members / K segments");
+  if (d.batch > 1 || d.ksegs > 1) {
+    VPTR_CHECK(d.batch == 1 || d.ksegs == 1, "vptr_gemm: batch and ksegs are mutually exclusive");
+    VPTR_CHECK(d.split_k == 1 && d.a_mode != VPTR_A_CONV && !d.a_rowsum, "vptr_gemm: batched / K-segmented launches need split_k = 1, no conv operand, no a_rowsum");
+    const int extra = (d.batch > 1 ? d.batch : d.ksegs) - 1;
+    VPTR_CHECK(d.A_x1 && d.B_x1 && al16(d.A_x1) && al16(d.B_x1), "vptr_gemm: member/segment 1 needs 16-byte aligned A_x1, B_x1");
+    if (extra > 1) VPTR_CHECK(d.A_x2 && d.B_x2 && al16(d.A_x2) && al16(d.B_x2), "vptr_gemm: member/segment 2 needs 16-byte aligned A_x2, B_x2");
+    if (d.batch > 1) {
+      VPTR_CHECK(d.D_x1 && (extra < 2 || d.D_x2), "vptr_gemm: every batch member needs its D_x");
+      if (d.alpha_x1 == 0.f) d.alpha_x1 = 1.f;
+      if (d.alpha_x2 == 0.f) d.alpha_x2 = 1.f;
+    }
+    if (d.batch > 1) VPTR_CHECK(!d.Dpre && !d.residual && !d.atomic, "vptr_gemm: batched launches support bias / alpha / act / dropout epilogues only");
+  }
   if (d.a_rowsum) VPTR_CHECK(d.a_mode == VPTR_A_KSTRIDED && g_gemm_variant != 0, "vptr_gemm: a_rowsum needs a k-strided A operand");
 
   // k range per split, multiple of the K tile
@@ -727,7 +881,7 @@ extern "C" int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream) {
   const int nfn = nfn_for(d.N);
   const int bn = 16 * nfn;
   const int tiles_m = (d.M + GBM - 1) / GBM, tiles_n = (d.N + bn - 1) / bn;
-  dim3 grid((unsigned)(tiles_m * tiles_n * splits), 1, 1);
+  dim3 grid((unsigned)(tiles_m * tiles_n * splits * d.batch), 1, 1);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int rc;
   if (nfn == 11) rc = launch_prec<11>(d, grid, k_chunk, st);

@@ -121,7 +121,6 @@ class SpatialLocalMultiheadAttention(nn.Module):
     def forward_tokens(self, xqk, xv, residual, g, lw_pos, site, rowscale=None, rs_div=1, rs_mod=1):
         C, nh, ws = self.dim, self.num_heads, self.window_size
         p = self.dropout if self.training else 0.0
-        scale = float(C // nh) ** -0.5
         a = self.attn
         frames, H, W = g.N * g.T, g.H, g.W
         padded = bool(H % ws or W % ws)
@@ -139,10 +138,8 @@ class SpatialLocalMultiheadAttention(nn.Module):
             Wq, Wk, Wv = a.in_proj_weight[:C], a.in_proj_weight[C:2 * C], a.in_proj_weight[2 * C:]
             bq, bk, bv = a.in_proj_bias[:C], a.in_proj_bias[C:2 * C], a.in_proj_bias[2 * C:]
             table, index = None, None
-        q = ops.linear(xin, Wq, bq, alpha=scale)
-        k = ops.linear(xin, Wk, bk)
-        v = ops.linear(xv, Wv, bv)
-        o = ops.window_attention(q, k, v, table, index, frames, H, W, nh, ws, p, site)
+        # q/k/v projections (one batched launch) + attention core; q is scaled by head_dim^-0.5 in the GEMM epilogue
+        o = ops.proj_window_attention(xin, xv, Wq, bq, Wk, bk, Wv, bv, table, index, frames, H, W, nh, ws, p, site)
         if padded:  # the out-projection is per token, so cropping first is equivalent to depad_if_needed after it (:347-351)
             o = ops.crop_tokens(o, frames, H, W, g.H, g.W)
         return ops.linear(o, a.out_proj.weight, a.out_proj.bias, residual=residual, rowscale=rowscale, rs_div=rs_div,
@@ -249,14 +246,13 @@ class MlpDWBN(nn.Module):
 
 
 def _mha_tokens(mha, q_in, k_in, v_in, residual, Nb, Tq, Tk, HW, causal, p_attn, site, out_dropout=0.0, out_site=0,
-                rowscale=None, rs_div=1, rs_mod=1):
-    """Stock nn.MultiheadAttention (packed in_proj) over time on token-major inputs (VidHRFormer_modules.py:79-84)."""
+                rowscale=None, rs_div=1, rs_mod=1, merge_v_grad=False):
+    """Stock nn.MultiheadAttention (packed in_proj) over time on token-major inputs (VidHRFormer_modules.py:79-84).
+    merge_v_grad: q_in is k_in = v_in + a table that needs no gradient, so the three input gradients may be returned as one."""
     C, nh = mha.embed_dim, mha.num_heads
     w, b = mha.in_proj_weight, mha.in_proj_bias
-    q = ops.linear(q_in, w[:C], b[:C], alpha=float(C // nh) ** -0.5)
-    k = ops.linear(k_in, w[C:2 * C], b[C:2 * C])
-    v = ops.linear(v_in, w[2 * C:], b[2 * C:])
-    o = ops.temporal_attention(q, k, v, Nb, Tq, Tk, HW, nh, causal, p_attn, site)
+    o = ops.proj_temporal_attention(q_in, k_in, v_in, w[:C], b[:C], w[C:2 * C], b[C:2 * C], w[2 * C:], b[2 * C:], Nb, Tq, Tk, HW, nh,
+                                    causal, p_attn, site, merge_v_grad=merge_v_grad)
     return ops.linear(o, mha.out_proj.weight, mha.out_proj.bias, residual=residual, dropout_p=out_dropout, site=out_site,
                       rowscale=rowscale, rs_div=rs_div, rs_mod=rs_mod)
 
@@ -301,7 +297,8 @@ class VidHRFormerBlockEnc(nn.Module):
         u = ops.layernorm(x, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps)
         x = self.SpatialFFN.forward_tokens(u, x, g, s + 1, rowscale=dp, rs_div=per_n, rs_mod=g.N)
         u, uq = ops.layernorm(x, self.norm3.weight, self.norm3.bias, tab=tpos, tab_div=HW, tab_mod=g.T, eps=self.norm3.eps)
-        x = _mha_tokens(self.temporal_MHSA, uq, uq, u, x, g.N, g.T, g.T, HW, self.far, p, s + 3, out_dropout=p, out_site=s + 4)
+        x = _mha_tokens(self.temporal_MHSA, uq, uq, u, x, g.N, g.T, g.T, HW, self.far, p, s + 3, out_dropout=p, out_site=s + 4,
+                        merge_v_grad=not tpos.requires_grad)
         u = ops.layernorm(x, self.norm4.weight, self.norm4.bias, eps=self.norm4.eps)
         h = ops.linear(u, self.linear1.weight, self.linear1.bias, act=ops.ACT_GELU, dropout_p=p, site=s + 5)
         return ops.linear(h, self.linear2.weight, self.linear2.bias, residual=x, dropout_p=p, site=s + 6)
@@ -373,7 +370,8 @@ class VidHRFormerBlockDecNAR(nn.Module):
         u = ops.layernorm(x, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps)
         x = self.SpatialFFN.forward_tokens(u, x, g, s + 1, rowscale=dp, rs_div=per_n, rs_mod=g.N)
         u, uq = ops.layernorm(x, self.norm3.weight, self.norm3.bias, tab=tpos_f, tab_div=HW, tab_mod=T2, eps=self.norm3.eps)
-        x = _mha_tokens(self.temporal_MHSA, uq, uq, u, x, g.N, T2, T2, HW, False, p, s + 3, out_dropout=p, out_site=s + 4)
+        x = _mha_tokens(self.temporal_MHSA, uq, uq, u, x, g.N, T2, T2, HW, False, p, s + 3, out_dropout=p, out_site=s + 4,
+                        merge_v_grad=not tpos_f.requires_grad)
         u = ops.layernorm(x, self.norm4.weight, self.norm4.bias, eps=self.norm4.eps)
         h = ops.linear(u, self.linear1.weight, self.linear1.bias, act=ops.ACT_GELU, dropout_p=p, site=s + 5)
         x = ops.linear(h, self.linear2.weight, self.linear2.bias, residual=x, dropout_p=p, site=s + 6)

@@ -84,8 +84,20 @@ def _c(t):
 # ------------------------------------------------------------------------------------------------------------------
 def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None, colscale=None, alpha=1.0, act=ACT_NONE,
              Dpre=None, rowscale=None, rs_div=1, rs_mod=1, dropout_p=0.0, site=0, residual=None, act_after=False,
-             atomic=False, split_k=1, conv=None, precision=None, seed=None, a_rowsum=None):
+             atomic=False, split_k=1, conv=None, precision=None, seed=None, a_rowsum=None, batch_extra=None, kseg_extra=None):
+    """One vptr_gemm launch.  batch_extra = [(A, B, D, bias, alpha), ...] adds up to two same-shaped independent problems to
+    the grid; kseg_extra = [(A, B), ...] adds up to two K-segments accumulated into the same D (include/vptr_hip.h)."""
     d = GemmDesc()
+    if batch_extra:
+        d.batch = 1 + len(batch_extra)
+        for i, (A2, B2, D2, bias2, alpha2) in enumerate(batch_extra, 1):
+            setattr(d, "A_x%d" % i, A2.data_ptr()), setattr(d, "B_x%d" % i, B2.data_ptr()), setattr(d, "D_x%d" % i, D2.data_ptr())
+            setattr(d, "bias_x%d" % i, bias2.data_ptr() if bias2 is not None else None)
+            setattr(d, "alpha_x%d" % i, alpha2)
+    if kseg_extra:
+        d.ksegs = 1 + len(kseg_extra)
+        for i, (A2, B2) in enumerate(kseg_extra, 1):
+            setattr(d, "A_x%d" % i, A2.data_ptr()), setattr(d, "B_x%d" % i, B2.data_ptr())
     d.a_rowsum = ptr(a_rowsum)
     d.A, d.B, d.D, d.Dpre = ptr(A), ptr(B), ptr(D), ptr(Dpre)
     d.lda = lda if lda is not None else (A.stride(0) if a_mode != 2 else 0)
@@ -116,7 +128,7 @@ def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None
     check(lib.vptr_gemm(ctypes.byref(d), stream()), "vptr_gemm")
     if prof is not None:
         e1.record()
-        prof.append(((gemm_nfn(N), d.precision, a_mode, b_mode), 2.0 * M * N * K, e0, e1))
+        prof.append(((gemm_nfn(N), d.precision, a_mode, b_mode), 2.0 * M * N * K * max(d.batch, d.ksegs, 1), e0, e1))
     return D
 
 
@@ -322,6 +334,39 @@ def flat_grad_for(t):
     return None
 
 
+def _linear_param_grads(g, x, W, bias_ref, need_w, need_b, alpha=1.0):
+    """dW[N,K] (+)= alpha * g^T . x and db (+)= alpha * column sums of g for y = x W^T + b with g = dL/dy [M, N].  With a flat
+    gradient slab the products are recorded for the grouped end-of-backward launch (which also takes the bias gradient from
+    its A staging registers) and (None, None) is returned; otherwise fresh tensors are."""
+    N, K = W.shape
+    M = x.shape[0]
+    dW = db = None
+    bias_done = False
+    if need_w:
+        slab = flat_grad_for(W)          # accumulate straight into the flat gradient slab when there is one
+        if slab is not None and config.group_wgrads:
+            bslab = flat_grad_for(bias_ref) if (bias_ref is not None and need_b) else None
+            defer_wgrad(g, x, slab, N, K, M, db=bslab, alpha=alpha)   # grouped at the end of backward
+            bias_done = bslab is not None
+        else:
+            if alpha != 1.0:
+                raise RuntimeError("an output scale is only folded into grouped weight gradients")
+            dW = slab if slab is not None else torch.zeros((N, K), device=g.device, dtype=torch.float32)
+            tiles = ((N + 127) // 128) * ((K + 175) // 176)
+            gemm_raw(g, x, dW, N, K, M, 1, 1, atomic=True, split_k=_split_k_for(tiles, M))
+            if slab is not None:
+                dW = None
+    if bias_ref is not None and need_b and not bias_done:
+        if alpha != 1.0:
+            raise RuntimeError("an output scale is only folded into grouped weight gradients")
+        slab = flat_grad_for(bias_ref)
+        db = slab if slab is not None else torch.zeros((N,), device=g.device, dtype=torch.float32)
+        check(lib.vptr_colsum(ptr(g), ptr(db), M, N, stream()), "vptr_colsum")
+        if slab is not None:
+            db = None
+    return dW, db
+
+
 class _LinearFn(torch.autograd.Function):
     """y = dropout(rowscale * act((x W^T + b) * alpha)) + residual   -- one GEMM launch with a fused epilogue.
 
@@ -375,26 +420,7 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), device=dy.device, dtype=torch.float32)
             gemm_raw(g, W, dx, M, K, N, 0, 1, alpha=galpha)        # dx[M,K] = g[M,N] . W[N,K]
-        bias_done = False
-        if ctx.needs_input_grad[1]:
-            slab = flat_grad_for(W)          # accumulate straight into the flat gradient slab when there is one
-            if slab is not None and config.group_wgrads:
-                bslab = flat_grad_for(ctx.bias_ref) if (has_b and ctx.needs_input_grad[2]) else None
-                defer_wgrad(g, x, slab, N, K, M, db=bslab, alpha=galpha)   # dW[N,K] += g^T . x (+ db), grouped at the end of backward
-                bias_done = bslab is not None
-            else:
-                dW = slab if slab is not None else torch.zeros((N, K), device=dy.device, dtype=torch.float32)
-                tiles = ((N + 127) // 128) * ((K + 175) // 176)
-                gemm_raw(g, x, dW, N, K, M, 1, 1, atomic=True, split_k=_split_k_for(tiles, M))
-                if slab is not None:
-                    dW = None
-        if has_b and ctx.needs_input_grad[2] and not bias_done:
-            b_t = ctx.bias_ref
-            slab = flat_grad_for(b_t)
-            db = slab if slab is not None else torch.zeros((N,), device=dy.device, dtype=torch.float32)
-            check(lib.vptr_colsum(ptr(g), ptr(db), M, N, stream()), "vptr_colsum")
-            if slab is not None:
-                db = None
+        dW, db = _linear_param_grads(g, x, W, ctx.bias_ref if has_b else None, ctx.needs_input_grad[1], ctx.needs_input_grad[2], galpha)
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
         return dx, dW, db, dres, None, None, None, None, None, None, None
 
@@ -411,6 +437,7 @@ class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, tab, tab_div, tab_mod, eps):
         _lib.require_cuda(x)
+        ctx.set_materialize_grads(False)  # an unused output (e.g. y when only y + tab is consumed) arrives as None, not zeros
         x = _c(x)
         rows, C = x.shape
         y = torch.empty_like(x)
@@ -512,7 +539,7 @@ class _WinAttnFn(torch.autograd.Function):
         slab = flat_grad_for(table)
         dtable = slab if slab is not None else (torch.zeros_like(table) if table is not None else None)
         check(lib.vptr_winattn_bwd(ptr(q), ptr(k), ptr(v), ptr(table), ptr(rel_index), ptr(do), ptr(dq), ptr(dk), ptr(dv),
-                                   ptr(dtable), B, H, W, q.shape[1], nh, ws, p, ptr(ctx.seed), site, stream()),
+                                   ptr(dtable), B, H, W, q.shape[1], nh, ws, p, ptr(ctx.seed), site, 1.0, stream()),
               "vptr_winattn_bwd")
         if slab is not None:
             dtable = None
@@ -544,13 +571,139 @@ class _TAttnFn(torch.autograd.Function):
         do = _c(do)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         check(lib.vptr_tattn_bwd(ptr(q), ptr(k), ptr(v), ptr(do), ptr(dq), ptr(dk), ptr(dv), Nb, Tq, Tk, HW, q.shape[1], nh,
-                                 causal, p, ptr(ctx.seed), site, stream()), "vptr_tattn_bwd")
+                                 causal, p, ptr(ctx.seed), site, 1.0, stream()), "vptr_tattn_bwd")
         return dq, dk, dv, None, None, None, None, None, None, None, None
 
 
 def temporal_attention(q, k, v, Nb, Tq, Tk, HW, nh, causal=False, dropout_p=0.0, site=0):
     """q [(n,tq,p), C] pre-scaled; k, v [(n,tk,p), C]; attends over time for every (n, pixel, head)."""
     return _TAttnFn.apply(q, k, v, int(Nb), int(Tq), int(Tk), int(HW), int(nh), int(bool(causal)), float(dropout_p), int(site))
+
+
+class _ProjAttnFn(torch.autograd.Function):
+    """o = attention(alpha * (xq Wq^T + bq), xk Wk^T + bk, xv Wv^T + bv), alpha = head_dim^-0.5: the q/k/v projections
+    (MultiHeadAttentionRPE.py:543-545,586; nn.MultiheadAttention's in_proj, VidHRFormer_modules.py:79-84) and the attention
+    core as one autograd node.
+
+    A 528 x 528 projection of 10 240 tokens alone is 240 tiles on 256 CUs and spends half of its time in prologue and
+    epilogue, so the three projections run as ONE batched launch (vptr_gemm_desc.batch: 720 tiles, two workgroups per CU),
+    and the input gradients as one K-segmented GEMM dX = dQ.Wq + dK.Wk + dV.Wv (vptr_gemm_desc.ksegs) when q, k and v come
+    from the same tensor, dXqk = dQ.Wq + dK.Wk plus dXv when only q and k do, a batched launch of three otherwise.  The
+    attention backward kernels emit dQ already multiplied by alpha (dq_scale), i.e. w.r.t. the unscaled projection.
+
+    kind 0: local-window attention with relative-position bias, geom = (B, H, W, ws);
+    kind 1: temporal attention, geom = (Nb, Tq, Tk, HW, causal).
+    same_qk / same_v: xk is xq / xv is xq.  merge_v: the CALLER guarantees that xv's gradient is only ever added to xq's
+    (xq = xv + a constant table): the whole input gradient is then returned for xq and None for xv."""
+
+    @staticmethod
+    def forward(ctx, xq, xk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, kind, geom, nh, p, site, same_qk, same_v, merge_v):
+        _lib.require_cuda(xq, xk, xv, Wq)
+        xq, xk, xv = _c(xq), _c(xk), _c(xv)
+        Wq, Wk, Wv = _c(Wq), _c(Wk), _c(Wv)
+        Mq, K = xq.shape
+        Mk = xk.shape[0]
+        N = Wq.shape[0]
+        alpha = float(N // nh) ** -0.5
+        dev = xq.device
+        q = torch.empty((Mq, N), device=dev, dtype=torch.float32)
+        k = torch.empty((Mk, N), device=dev, dtype=torch.float32)
+        v = torch.empty((Mk, N), device=dev, dtype=torch.float32)
+        if Mq == Mk:
+            gemm_raw(xq, Wq, q, Mq, N, K, 0, 0, bias=bq, alpha=alpha, batch_extra=[(xk, Wk, k, bk, 1.0), (xv, Wv, v, bv, 1.0)])
+        else:
+            gemm_raw(xq, Wq, q, Mq, N, K, 0, 0, bias=bq, alpha=alpha)
+            gemm_raw(xk, Wk, k, Mk, N, K, 0, 0, bias=bk, batch_extra=[(xv, Wv, v, bv, 1.0)])
+        o = torch.empty_like(q)
+        ctx.seed = seed_tensor(dev) if p > 0 else None
+        if kind == 0:
+            B, H, W, ws = geom
+            check(lib.vptr_winattn_fwd(ptr(q), ptr(k), ptr(v), ptr(table), ptr(rel_index), ptr(o), B, H, W, N, nh, ws, p,
+                                       ptr(ctx.seed), site, stream()), "vptr_winattn_fwd")
+        else:
+            Nb, Tq, Tk, HW, causal = geom
+            check(lib.vptr_tattn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), Nb, Tq, Tk, HW, N, nh, causal, p, ptr(ctx.seed), site,
+                                     stream()), "vptr_tattn_fwd")
+        ctx.save_for_backward(xq, xk, xv, Wq, Wk, Wv, q, k, v, table, rel_index)
+        ctx.bias_refs = tuple(b.detach() if b is not None else None for b in (bq, bk, bv))
+        ctx.cfg = (kind, geom, nh, p, site, alpha, same_qk, same_v, merge_v)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        xq, xk, xv, Wq, Wk, Wv, q, k, v, table, rel_index = ctx.saved_tensors
+        kind, geom, nh, p, site, alpha, same_qk, same_v, merge_v = ctx.cfg
+        do = _c(do)
+        Mq, K = xq.shape
+        Mk = xk.shape[0]
+        N = Wq.shape[0]
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dtable = None
+        if kind == 0:
+            B, H, W, ws = geom
+            slab = flat_grad_for(table) if table is not None else None
+            dtable = slab if slab is not None else (torch.zeros_like(table) if table is not None else None)
+            check(lib.vptr_winattn_bwd(ptr(q), ptr(k), ptr(v), ptr(table), ptr(rel_index), ptr(do), ptr(dq), ptr(dk), ptr(dv),
+                                       ptr(dtable), B, H, W, N, nh, ws, p, ptr(ctx.seed), site, alpha, stream()), "vptr_winattn_bwd")
+            if slab is not None:
+                dtable = None
+        else:
+            Nb, Tq, Tk, HW, causal = geom
+            check(lib.vptr_tattn_bwd(ptr(q), ptr(k), ptr(v), ptr(do), ptr(dq), ptr(dk), ptr(dv), Nb, Tq, Tk, HW, N, nh, causal, p,
+                                     ptr(ctx.seed), site, alpha, stream()), "vptr_tattn_bwd")
+        need = ctx.needs_input_grad
+        rq, rk, rv = ctx.bias_refs
+        dWq, dbq = _linear_param_grads(dq, xq, Wq, rq, need[3], need[4])
+        dWk, dbk = _linear_param_grads(dk, xk, Wk, rk, need[5], need[6])
+        dWv, dbv = _linear_param_grads(dv, xv, Wv, rv, need[7], need[8])
+
+        def new(M):
+            return torch.empty((M, K), device=do.device, dtype=torch.float32)
+        dxq = dxk = dxv = None
+        if same_qk and (same_v or merge_v):
+            if need[0] or need[1] or need[2]:
+                dxq = gemm_raw(dq, Wq, new(Mq), Mq, K, N, 0, 1, kseg_extra=[(dk, Wk), (dv, Wv)])
+        elif same_qk:
+            if need[0] or need[1]:
+                dxq = gemm_raw(dq, Wq, new(Mq), Mq, K, N, 0, 1, kseg_extra=[(dk, Wk)])
+            if need[2]:
+                dxv = gemm_raw(dv, Wv, new(Mk), Mk, K, N, 0, 1)
+        elif need[0] and need[1] and need[2] and Mq == Mk:
+            dxq, dxk, dxv = new(Mq), new(Mk), new(Mk)
+            gemm_raw(dq, Wq, dxq, Mq, K, N, 0, 1, batch_extra=[(dk, Wk, dxk, None, 1.0), (dv, Wv, dxv, None, 1.0)])
+        else:
+            if need[0]:
+                dxq = gemm_raw(dq, Wq, new(Mq), Mq, K, N, 0, 1)
+            if need[1] and need[2]:
+                dxk, dxv = new(Mk), new(Mk)
+                gemm_raw(dk, Wk, dxk, Mk, K, N, 0, 1, batch_extra=[(dv, Wv, dxv, None, 1.0)])
+            elif need[1]:
+                dxk = gemm_raw(dk, Wk, new(Mk), Mk, K, N, 0, 1)
+            elif need[2]:
+                dxv = gemm_raw(dv, Wv, new(Mk), Mk, K, N, 0, 1)
+        return (dxq, dxk, dxv, dWq, dbq, dWk, dbk, dWv, dbv, dtable) + (None,) * 9
+
+
+def _proj_attention(xq, xk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, kind, geom, nh, p, site, merge_v_grad):
+    same_qk = xk is xq
+    same_v = same_qk and xv is xq
+    return _ProjAttnFn.apply(xq, xk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, kind, geom, int(nh), float(p), int(site),
+                             same_qk, same_v, bool(merge_v_grad) and same_qk)
+
+
+def proj_window_attention(xqk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, B, H, W, nh, ws, dropout_p=0.0, site=0,
+                          merge_v_grad=False):
+    """Window attention INCLUDING its q/k/v projections (q and k from xqk, v from xv; [B*H*W, C] tokens); returns the
+    [B*H*W, C] heads before out_proj.  merge_v_grad: see _ProjAttnFn."""
+    return _proj_attention(xqk, xqk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, 0, (int(B), int(H), int(W), int(ws)), nh,
+                           dropout_p, site, merge_v_grad)
+
+
+def proj_temporal_attention(q_in, k_in, v_in, Wq, bq, Wk, bk, Wv, bv, Nb, Tq, Tk, HW, nh, causal=False, dropout_p=0.0, site=0,
+                            merge_v_grad=False):
+    """Temporal attention INCLUDING its q/k/v projections; q_in [(n,tq,p), C], k_in, v_in [(n,tk,p), C]."""
+    return _proj_attention(q_in, k_in, v_in, Wq, bq, Wk, bk, Wv, bv, None, None, 1,
+                           (int(Nb), int(Tq), int(Tk), int(HW), int(bool(causal))), nh, dropout_p, site, merge_v_grad)
 
 
 class _TSAttnFn(torch.autograd.Function):
