@@ -277,9 +277,58 @@ struct StageConv {
   }
 };
 
+// Batched launches (desc.batch > 1): member b > 0 of the grid reads A_x<b>/B_x<b> and writes D_x<b> with bias_x<b> / alpha_x<b>.
+// (Five scalars handed to the loaders and the epilogue: a patched COPY of the descriptor ended up partly in scratch.)
+struct Member {
+  const float* A;
+  const float* B;
+  float* D;
+  const float* bias;
+  float alpha;
+};
+__device__ __forceinline__ Member member_of(const vptr_gemm_desc& p, const int member) {
+  Member m = {p.A, p.B, p.D, p.bias, p.alpha};
+  if (member > 0) {  // workgroup-uniform
+    const bool one = member == 1;
+    m.A = one ? p.A_x1 : p.A_x2;
+    m.B = one ? p.B_x1 : p.B_x2;
+    m.D = one ? p.D_x1 : p.D_x2;
+    m.bias = one ? p.bias_x1 : p.bias_x2;
+    m.alpha = one ? p.alpha_x1 : p.alpha_x2;
+  }
+  return m;
+}
+// K-segment cursor (desc.ksegs > 1: D = sum_s op(A_s) op(B_s), every segment K long): K-step kt of the virtual K range
+// -> operand pointers and the k offset inside the segment.  Steps beyond the last segment (prefetch) land at k >= K of the
+// last one, i.e. fully masked.  Two compares instead of a division: ksegs <= 3.
+struct KSeg {
+  int spk, last;  // K-steps per segment; index of the last segment
+  __device__ __forceinline__ KSeg(const vptr_gemm_desc& p) {
+    last = p.ksegs > 1 ? p.ksegs - 1 : 0;
+    spk = last ? (p.K + GBK - 1) / GBK : (1 << 26);
+  }
+  __device__ __forceinline__ int steps(const int kbeg, const int kend) const {
+    return last ? (last + 1) * spk : (kend - kbeg + GBK - 1) / GBK;
+  }
+  // segment index and k offset of K-step kt
+  __device__ __forceinline__ int seg(const int kbeg, const int kt, int& k0) const {
+    const int s = min((int)(kt >= spk) + (int)(kt >= 2 * spk), last);
+    k0 = kbeg + (kt - s * spk) * GBK;
+    return s;
+  }
+};
+// operand of segment s as base + element offset (offsets are plain integers: selecting between POINTERS read from the
+// descriptor made hipcc keep the descriptor in scratch)
+#define KSEG_OFFSETS(p)                                                                  \
+  const int64_t ksA1 = (p).ksegs > 1 ? (p).A_x1 - (p).A : 0, ksA2 = (p).ksegs > 2 ? (p).A_x2 - (p).A : 0; \
+  const int64_t ksB1 = (p).ksegs > 1 ? (p).B_x1 - (p).B : 0, ksB2 = (p).ksegs > 2 ? (p).B_x2 - (p).B : 0;
+#define KSEG_PTRS(mb, s, Ak, Bk)                                           \
+  const float* Ak = (mb).A + ((s) == 0 ? (int64_t)0 : ((s) == 1 ? ksA1 : ksA2)); \
+  const float* Bk = (mb).B + ((s) == 0 ? (int64_t)0 : ((s) == 1 ? ksB1 : ksB2));
+
 // ---- epilogue of the pipelined loop (one workgroup per CU: nothing else hides its latencies)
 template <int NFN, int NGRP>  // NGRP: column-fragment groups, each = all its loads, then its stores (2 under a 128-VGPR cap)
-__device__ __forceinline__ void gemm_epilogue(const vptr_gemm_desc& p, f32x4 (&acc)[2][(NFN + 1) / 2], const int m0, const int n0,
+__device__ __forceinline__ void gemm_epilogue(const vptr_gemm_desc& p, const Member& mb, f32x4 (&acc)[2][(NFN + 1) / 2], const int m0, const int n0,
                                               const int wm, const int wn, const int lr, const int lq, const bool first_split,
                                               const bool use_atomic) {
   constexpr int NFW = (NFN + 1) / 2;
@@ -289,7 +338,7 @@ __device__ __forceinline__ void gemm_epilogue(const vptr_gemm_desc& p, f32x4 (&a
   // alias the residual, so hipcc keeps loads behind earlier stores, and the first version's load -> add -> store chain per
   // element cost 48 dependent HBM round trips per lane (+40 us on a 34 us K = 528 GEMM with a residual).
   const bool plain = !p.colscale && !p.Dpre && p.act == VPTR_ACT_NONE && !p.rowscale && p.dropout_p == 0.f && !p.act_after &&
-                     p.alpha == 1.f;
+                     mb.alpha == 1.f;
   const int row_base = m0 + wm * 32 + lq * 4;
   const bool has_res = p.residual && first_split;
   int col[NFW];
@@ -301,7 +350,7 @@ __device__ __forceinline__ void gemm_epilogue(const vptr_gemm_desc& p, f32x4 (&a
     const int nf = wn * NFW + ni;
     col[ni] = n0 + nf * 16 + lr;
     colok[ni] = (nf < NFN) & (col[ni] < p.N);
-    bs[ni] = (p.bias && first_split && colok[ni]) ? p.bias[col[ni]] : 0.f;
+    bs[ni] = (mb.bias && first_split && colok[ni]) ? mb.bias[col[ni]] : 0.f;
     cs[ni] = (p.colscale && colok[ni]) ? p.colscale[col[ni]] : 1.f;
   }
 #pragma unroll
@@ -334,7 +383,7 @@ __device__ __forceinline__ void gemm_epilogue(const vptr_gemm_desc& p, f32x4 (&a
           const int row = row_base + mi * 16 + r;
           if (colok[ni] && row < p.M) {
             const float v = acc[mi][ni][r] + bs[ni] + res[ni - g0][mi][r];
-            float* dst = p.D + (int64_t)row * p.ldd + col[ni];
+            float* dst = mb.D + (int64_t)row * p.ldd + col[ni];
             if (use_atomic) unsafeAtomicAdd(dst, v);
             else *dst = v;
           }
@@ -350,13 +399,13 @@ __device__ __forceinline__ void gemm_epilogue(const vptr_gemm_desc& p, f32x4 (&a
         for (int r = 0; r < 4; ++r) {
           const int row = row_base + mi * 16 + r;
           if (colok[ni] && row < p.M) {
-            float v = (acc[mi][ni][r] * cs[ni] + bs[ni]) * p.alpha;
+            float v = (acc[mi][ni][r] * cs[ni] + bs[ni]) * mb.alpha;
             if (p.Dpre) p.Dpre[(int64_t)row * p.ldd + col[ni]] = v;
             v = vptr_act(v, p.act) * rsv[mi][r];
             if (p.dropout_p > 0.f) v *= vptr_drop_scale(seed, p.site, (uint64_t)row * (uint64_t)p.N + col[ni], p.dropout_p);
             v += res[ni - g0][mi][r];
             if (p.act_after) v = v > 0.f ? v : 0.f;
-            float* dst = p.D + (int64_t)row * p.ldd + col[ni];
+            float* dst = mb.D + (int64_t)row * p.ldd + col[ni];
             if (use_atomic) unsafeAtomicAdd(dst, v);
             else *dst = v;
           }
@@ -368,17 +417,172 @@ __device__ __forceinline__ void gemm_epilogue(const vptr_gemm_desc& p, f32x4 (&a
 }
 
 
+// ---- row-major epilogue of the pipelined loop: the accumulator tile goes through LDS (free after the K loop) so that every
+// thread then owns float4 pieces of full output rows: 16-byte coalesced stores (and residual / Dpre accesses) of whole
+// 704-byte rows instead of 4-byte stores in 64-byte segments, all loads issued before the first store.  Needs N, ldd, ldr
+// multiples of 4 and 16-byte aligned pointers (epi_vec_ok); otherwise the fragment-layout epilogue above runs.
+// Tile pitch BN + 4 floats: the four 16-lane row groups of a fragment store land in four different 16-bank windows.
+template <int NFN>
+constexpr int epi_lds_bytes() { return GBM * (16 * NFN + 4) * (int)sizeof(float); }
+
+__device__ __forceinline__ bool epi_vec_ok(const vptr_gemm_desc& p) {
+  uintptr_t bits = reinterpret_cast<uintptr_t>(p.D) | reinterpret_cast<uintptr_t>(p.Dpre) | reinterpret_cast<uintptr_t>(p.residual) |
+                   reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.colscale);
+  if (p.batch > 1) bits |= reinterpret_cast<uintptr_t>(p.D_x1) | reinterpret_cast<uintptr_t>(p.D_x2) | reinterpret_cast<uintptr_t>(p.bias_x1) |
+                           reinterpret_cast<uintptr_t>(p.bias_x2);
+  return ((bits & 15) == 0) && ((p.N & 3) == 0) && ((p.ldd & 3) == 0) && ((p.ldr & 3) == 0);
+}
+
+template <int NFN>
+__device__ __forceinline__ void gemm_epilogue_rows(const vptr_gemm_desc& p, const Member& mb, f32x4 (&acc)[2][(NFN + 1) / 2], float* sE, const int m0,
+                                                   const int n0, const int wm, const int wn, const int lr, const int lq, const int tid,
+                                                   const bool first_split, const bool use_atomic) {
+  constexpr int NFW = (NFN + 1) / 2, BN = 16 * NFN, PITCH = BN + 4, C4 = BN / 4;
+  // fragments -> LDS tile [128][PITCH]  (C/D layout of v_mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg)
+#pragma unroll
+  for (int ni = 0; ni < NFW; ++ni) {
+    const int nf = wn * NFW + ni;
+    if (nf < NFN) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sE[(wm * 32 + mi * 16 + lq * 4 + r) * PITCH + nf * 16 + lr] = acc[mi][ni][r];
+    }
+  }
+  __syncthreads();
+  // thread -> NFN float4 pieces: piece = it * 512 + tid, row = piece / C4, c4 = piece % C4
+  const bool has_res = p.residual && first_split;
+  const bool has_bias = mb.bias && first_split;
+  f32x4 res[NFN], bs[NFN];
+  float rsv[NFN];
+#pragma unroll
+  for (int it = 0; it < NFN; ++it) {
+    const int piece = it * GNT + tid;
+    const int rl = piece / C4;
+    const int row = m0 + rl, col = n0 + (piece - rl * C4) * 4;
+    const bool ok = row < p.M && col < p.N;
+    bs[it] = res[it] = (f32x4){0.f, 0.f, 0.f, 0.f};   // (`cond ? *ptr : zero` made hipcc park the zero vector in scratch)
+    rsv[it] = 1.f;
+    if (has_bias && ok) bs[it] = *reinterpret_cast<const f32x4*>(mb.bias + col);
+    if (p.rowscale && ok) rsv[it] = p.rowscale[(row / p.rs_div) % p.rs_mod];
+    if (has_res && ok) res[it] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)row * p.ldr + col);
+  }
+  uint64_t seed = 0;
+  if (p.dropout_p > 0.f) seed = *p.seed_dev;
+  const bool plain = !p.colscale && !p.Dpre && p.act == VPTR_ACT_NONE && !p.rowscale && p.dropout_p == 0.f && !p.act_after &&
+                     mb.alpha == 1.f;
+#pragma unroll
+  for (int it = 0; it < NFN; ++it) {
+    const int piece = it * GNT + tid;
+    const int rl = piece / C4;
+    const int row = m0 + rl, col = n0 + (piece - rl * C4) * 4;
+    if (row < p.M && col < p.N) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(&sE[rl * PITCH + (piece - rl * C4) * 4]);
+      if (plain) {
+        v = v + bs[it] + res[it];
+      } else {
+        if (p.colscale) v = v * *reinterpret_cast<const f32x4*>(p.colscale + col);   // conv + folded BatchNorm only
+        v = (v + bs[it]) * mb.alpha;
+        if (p.Dpre) *reinterpret_cast<f32x4*>(p.Dpre + (int64_t)row * p.ldd + col) = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = vptr_act(v[e], p.act) * rsv[it];
+          if (p.dropout_p > 0.f) t *= vptr_drop_scale(seed, p.site, (uint64_t)row * (uint64_t)p.N + col + e, p.dropout_p);
+          t += res[it][e];
+          if (p.act_after) t = t > 0.f ? t : 0.f;
+          v[e] = t;
+        }
+      }
+      float* dst = mb.D + (int64_t)row * p.ldd + col;
+      if (use_atomic) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e, v[e]);
+      } else {
+        *reinterpret_cast<f32x4*>(dst) = v;
+      }
+    }
+  }
+  __syncthreads();  // the tile is LDS the caller may reuse (a_rowsum reduction)
+}
+
+
+// The same for the single-image loop (40 KB of LDS per workgroup, two workgroups per CU): the tile goes through LDS in two
+// 64-row halves, and the pieces are handled one by one (load -> compute -> store: the other workgroup covers the latency,
+// and the 128-VGPR cap leaves no room for a batch of residual vectors next to the accumulators of the waiting half).
+template <int NFN>
+constexpr int epi_half_lds_bytes() { return (GBM / 2) * (16 * NFN + 4) * (int)sizeof(float); }
+
+template <int NFN>
+__device__ __forceinline__ void gemm_epilogue_rows_halves(const vptr_gemm_desc& p, const Member& mb, f32x4 (&acc)[2][(NFN + 1) / 2], float* sE,
+                                                          const int m0, const int n0, const int wm, const int wn, const int lr, const int lq,
+                                                          const int tid, const bool first_split, const bool use_atomic) {
+  constexpr int NFW = (NFN + 1) / 2, BN = 16 * NFN, PITCH = BN + 4, C4 = BN / 4, HR = GBM / 2, NPIECE = HR * C4;
+  const bool has_res = p.residual && first_split;
+  const bool has_bias = mb.bias && first_split;
+  uint64_t seed = 0;
+  if (p.dropout_p > 0.f) seed = *p.seed_dev;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if ((wm >> 1) == h) {  // wave-uniform: the four waves of this row half spill their fragments
+#pragma unroll
+      for (int ni = 0; ni < NFW; ++ni) {
+        const int nf = wn * NFW + ni;
+        if (nf < NFN) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sE[((wm & 1) * 32 + mi * 16 + lq * 4 + r) * PITCH + nf * 16 + lr] = acc[mi][ni][r];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < (NPIECE + GNT - 1) / GNT; ++it) {
+      const int piece = it * GNT + tid;
+      const int rl = piece / C4;
+      const int row = m0 + h * HR + rl, col = n0 + (piece - rl * C4) * 4;
+      if (piece < NPIECE && row < p.M && col < p.N) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&sE[rl * PITCH + (piece - rl * C4) * 4]);
+        if (p.colscale) v = v * *reinterpret_cast<const f32x4*>(p.colscale + col);
+        if (has_bias) v = v + *reinterpret_cast<const f32x4*>(mb.bias + col);
+        v = v * mb.alpha;
+        if (p.Dpre) *reinterpret_cast<f32x4*>(p.Dpre + (int64_t)row * p.ldd + col) = v;
+        f32x4 res = {0.f, 0.f, 0.f, 0.f};
+        if (has_res) res = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)row * p.ldr + col);
+        const float rs = p.rowscale ? p.rowscale[(row / p.rs_div) % p.rs_mod] : 1.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = vptr_act(v[e], p.act) * rs;
+          if (p.dropout_p > 0.f) t *= vptr_drop_scale(seed, p.site, (uint64_t)row * (uint64_t)p.N + col + e, p.dropout_p);
+          t += res[e];
+          if (p.act_after) t = t > 0.f ? t : 0.f;
+          v[e] = t;
+        }
+        float* dst = mb.D + (int64_t)row * p.ldd + col;
+        if (use_atomic) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e, v[e]);
+        } else {
+          *reinterpret_cast<f32x4*>(dst) = v;
+        }
+      }
+    }
+    if (h == 0) __syncthreads();
+  }
+}
+
+
 // ---- epilogue of the single-image loop: element by element (load -> compute -> store).  Two workgroups share the CU there and
 // cover each other's latencies, and under its 128-VGPR cap the batched-load form below spills (measured: fc1 156 -> 200 us).
 template <int NFN>
-__device__ __forceinline__ void gemm_epilogue_serial(const vptr_gemm_desc& p, f32x4 (&acc)[2][(NFN + 1) / 2], const int m0, const int n0,
+__device__ __forceinline__ void gemm_epilogue_serial(const vptr_gemm_desc& p, const Member& mb, f32x4 (&acc)[2][(NFN + 1) / 2], const int m0, const int n0,
                                               const int wm, const int wn, const int lr, const int lq, const bool first_split,
                                               const bool use_atomic) {
   constexpr int NFW = (NFN + 1) / 2;
   // ---- epilogue: C/D fragment layout of v_mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg.
   // Every acc index is a compile-time constant (fully unrolled, no `continue`).
   const bool plain = !p.colscale && !p.Dpre && p.act == VPTR_ACT_NONE && !p.rowscale && p.dropout_p == 0.f && !p.act_after &&
-                     p.alpha == 1.f;
+                     mb.alpha == 1.f;
   const int row_base = m0 + wm * 32 + lq * 4;
   if (plain) {  // kernel-uniform fast path: bias (+ residual), store or atomic accumulate
 #pragma unroll
@@ -386,7 +590,7 @@ __device__ __forceinline__ void gemm_epilogue_serial(const vptr_gemm_desc& p, f3
       const int nf = wn * NFW + ni;
       const int col = n0 + nf * 16 + lr;
       const bool colok = (nf < NFN) & (col < p.N);
-      const float bs = (p.bias && first_split && colok) ? p.bias[col] : 0.f;
+      const float bs = (mb.bias && first_split && colok) ? mb.bias[col] : 0.f;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -395,7 +599,7 @@ __device__ __forceinline__ void gemm_epilogue_serial(const vptr_gemm_desc& p, f3
           if (colok && row < p.M) {
             float v = acc[mi][ni][r] + bs;
             if (p.residual && first_split) v += p.residual[(int64_t)row * p.ldr + col];
-            float* dst = p.D + (int64_t)row * p.ldd + col;
+            float* dst = mb.D + (int64_t)row * p.ldd + col;
             if (use_atomic) unsafeAtomicAdd(dst, v);
             else *dst = v;
           }
@@ -410,7 +614,7 @@ __device__ __forceinline__ void gemm_epilogue_serial(const vptr_gemm_desc& p, f3
       const int nf = wn * NFW + ni;
       const int col = n0 + nf * 16 + lr;
       const bool colok = (nf < NFN) & (col < p.N);
-      const float bs = (p.bias && first_split && colok) ? p.bias[col] : 0.f;
+      const float bs = (mb.bias && first_split && colok) ? mb.bias[col] : 0.f;
       const float cs = (p.colscale && colok) ? p.colscale[col] : 1.f;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
@@ -418,14 +622,14 @@ __device__ __forceinline__ void gemm_epilogue_serial(const vptr_gemm_desc& p, f3
         for (int r = 0; r < 4; ++r) {
           const int row = row_base + mi * 16 + r;
           if (colok && row < p.M) {
-            float v = (acc[mi][ni][r] * cs + bs) * p.alpha;
+            float v = (acc[mi][ni][r] * cs + bs) * mb.alpha;
             if (p.Dpre) p.Dpre[(int64_t)row * p.ldd + col] = v;
             v = vptr_act(v, p.act);
             if (p.rowscale) v *= p.rowscale[(row / p.rs_div) % p.rs_mod];
             if (p.dropout_p > 0.f) v *= vptr_drop_scale(seed, p.site, (uint64_t)row * (uint64_t)p.N + col, p.dropout_p);
             if (p.residual && first_split) v += p.residual[(int64_t)row * p.ldr + col];
             if (p.act_after) v = v > 0.f ? v : 0.f;
-            float* dst = p.D + (int64_t)row * p.ldd + col;
+            float* dst = mb.D + (int64_t)row * p.ldd + col;
             if (use_atomic) unsafeAtomicAdd(dst, v);
             else *dst = v;
           }
@@ -435,49 +639,8 @@ __device__ __forceinline__ void gemm_epilogue_serial(const vptr_gemm_desc& p, f3
   }
 }
 
-// Batched launches (desc.batch > 1): member b > 0 of the grid reads A_x<b>/B_x<b> and writes D_x<b> with bias_x<b> / alpha_x<b>.
-__device__ __forceinline__ vptr_gemm_desc member_view(const vptr_gemm_desc& p, const int member) {
-  vptr_gemm_desc q = p;
-  if (member > 0) {  // workgroup-uniform
-    const bool one = member == 1;
-    q.A = one ? p.A_x1 : p.A_x2;
-    q.B = one ? p.B_x1 : p.B_x2;
-    q.D = one ? p.D_x1 : p.D_x2;
-    q.bias = one ? p.bias_x1 : p.bias_x2;
-    q.alpha = one ? p.alpha_x1 : p.alpha_x2;
-  }
-  return q;
-}
-// K-segment cursor (desc.ksegs > 1: D = sum_s op(A_s) op(B_s), every segment K long): K-step kt of the virtual K range
-// -> operand pointers and the k offset inside the segment.  Steps beyond the last segment (prefetch) land at k >= K of the
-// last one, i.e. fully masked.  Two compares instead of a division: ksegs <= 3.
-struct KSeg {
-  int spk, last;  // K-steps per segment; index of the last segment
-  __device__ __forceinline__ KSeg(const vptr_gemm_desc& p) {
-    last = p.ksegs > 1 ? p.ksegs - 1 : 0;
-    spk = last ? (p.K + GBK - 1) / GBK : (1 << 26);
-  }
-  __device__ __forceinline__ int steps(const int kbeg, const int kend) const {
-    return last ? (last + 1) * spk : (kend - kbeg + GBK - 1) / GBK;
-  }
-  // segment index and k offset of K-step kt
-  __device__ __forceinline__ int seg(const int kbeg, const int kt, int& k0) const {
-    const int s = min((int)(kt >= spk) + (int)(kt >= 2 * spk), last);
-    k0 = kbeg + (kt - s * spk) * GBK;
-    return s;
-  }
-};
-// operand of segment s as base + element offset (offsets are plain integers: selecting between POINTERS read from the
-// descriptor made hipcc keep the descriptor in scratch)
-#define KSEG_OFFSETS(p)                                                                  \
-  const int64_t ksA1 = (p).ksegs > 1 ? (p).A_x1 - (p).A : 0, ksA2 = (p).ksegs > 2 ? (p).A_x2 - (p).A : 0; \
-  const int64_t ksB1 = (p).ksegs > 1 ? (p).B_x1 - (p).B : 0, ksB2 = (p).ksegs > 2 ? (p).B_x2 - (p).B : 0;
-#define KSEG_PTRS(p, s, Ak, Bk)                                           \
-  const float* Ak = (p).A + ((s) == 0 ? (int64_t)0 : ((s) == 1 ? ksA1 : ksA2)); \
-  const float* Bk = (p).B + ((s) == 0 ? (int64_t)0 : ((s) == 1 ? ksB1 : ksB2));
-
 template <int NFN, int NPASS, int AMODE, int BMODE>
-__global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc p0, const int k_chunk) {
+__global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc p, const int k_chunk, const int epi_rows) {
   constexpr int BN = 16 * NFN;
   constexpr int NFW = (NFN + 1) / 2;     // column fragments per wave
   constexpr int BROWS = 2 * NFW * 16;    // LDS rows of the B image (>= BN; the surplus rows feed never-stored fragments)
@@ -485,8 +648,13 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc 
   using StA = typename std::conditional<AMODE == VPTR_A_KCONTIG, StageKC<GBM, GBM, true>,
                                         typename std::conditional<AMODE == VPTR_A_KSTRIDED, StageKS2<true>, StageConv>::type>::type;
   using StB = typename std::conditional<BMODE == VPTR_B_KCONTIG, StageKC<BN, BROWS, false>, StageKS<BROWS, false>>::type;
-  __shared__ __attribute__((aligned(16))) __bf16 sA[NPL][GBM * GLP];
-  __shared__ __attribute__((aligned(16))) __bf16 sB[NPL][BROWS * GLP];
+  constexpr int LOOP_BYTES = NPL * (GBM + BROWS) * GLP * (int)sizeof(__bf16);
+  constexpr int LDS_BYTES = LOOP_BYTES > epi_half_lds_bytes<NFN>() ? LOOP_BYTES : epi_half_lds_bytes<NFN>();
+  __shared__ __attribute__((aligned(16))) unsigned char sraw[LDS_BYTES];   // [A hi, A lo, B hi, B lo] / epilogue half tile
+  __bf16* const sA0 = reinterpret_cast<__bf16*>(sraw);
+  __bf16* const sA1 = sA0 + (NPL - 1) * GBM * GLP;
+  __bf16* const sB0 = sA0 + NPL * GBM * GLP;
+  __bf16* const sB1 = sB0 + (NPL - 1) * BROWS * GLP;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -495,12 +663,12 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc 
   // range of the (split, tile_m, tile_n) order, so the A row panel of a tile_m is fetched by one L2 instead of all eight.
   const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
   const int logical = xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
-  const int tiles_n = (p0.N + BN - 1) / BN;
-  const int tiles = tiles_n * ((p0.M + GBM - 1) / GBM);
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles = tiles_n * ((p.M + GBM - 1) / GBM);
   const int grp = logical / tiles, tile = logical - grp * tiles;
-  const bool batched = p0.batch > 1;                 // the grid's outer index is the batch member or the K split
+  const bool batched = p.batch > 1;                 // the grid's outer index is the batch member or the K split
   const int split = batched ? 0 : grp;
-  const vptr_gemm_desc p = member_view(p0, batched ? grp : 0);
+  const Member mb = member_of(p, batched ? grp : 0);
   const int tn = tile % tiles_n, tm = tile / tiles_n;
   const int m0 = tm * GBM, n0 = tn * BN;
   const int kbeg = split * k_chunk;
@@ -523,7 +691,7 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc 
   auto load_step = [&](const int kt) {
     int k0;
     const int sg = ks.seg(kbeg, kt, k0);
-    KSEG_PTRS(p, sg, Ak, Bk)
+    KSEG_PTRS(mb, sg, Ak, Bk)
     if constexpr (AMODE == VPTR_A_CONV) stA.load(p, m0, k0, kend, tid);
     else stA.load(Ak, p.lda, m0, p.M, k0, kend, tid);
     stB.load(Bk, p.ldb, n0, p.N, k0, kend, tid);
@@ -532,8 +700,8 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc 
 
   TS(0)
   for (int kt = 0; kt < nkt; ++kt) {
-    stA.template store<NPASS>(sA[0], sA[NPL - 1], tid);
-    stB.template store<NPASS>(sB[0], sB[NPL - 1], tid);
+    stA.template store<NPASS>(sA0, sA1, tid);
+    stB.template store<NPASS>(sB0, sB1, tid);
     TS(1)
     __syncthreads();
     TS(2)
@@ -543,15 +711,15 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc 
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int off = lds_off(wm * 32 + mi * 16 + lr, lq * 2);
-      ah[mi] = *reinterpret_cast<const bf16x8*>(&sA[0][off]);
-      if constexpr (NPASS == 3) al[mi] = *reinterpret_cast<const bf16x8*>(&sA[NPL - 1][off]);
+      ah[mi] = *reinterpret_cast<const bf16x8*>(&sA0[off]);
+      if constexpr (NPASS == 3) al[mi] = *reinterpret_cast<const bf16x8*>(&sA1[off]);
     }
 #pragma unroll
     for (int ni = 0; ni < NFW; ++ni) {
       const int off = lds_off((wn * NFW + ni) * 16 + lr, lq * 2);
-      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&sB[0][off]);
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&sB0[off]);
       bf16x8 bl;
-      if constexpr (NPASS == 3) bl = *reinterpret_cast<const bf16x8*>(&sB[NPL - 1][off]);
+      if constexpr (NPASS == 3) bl = *reinterpret_cast<const bf16x8*>(&sB1[off]);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         if constexpr (NPASS == 3) {
@@ -566,7 +734,9 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc 
     TS(2)
   }
 
-  gemm_epilogue_serial<NFN>(p, acc, m0, n0, wm, wn, lr, lq, split == 0, p.atomic || (!batched && nblk > tiles));
+  const bool use_atomic = p.atomic || (!batched && nblk > tiles);
+  if (epi_rows && epi_vec_ok(p)) gemm_epilogue_rows_halves<NFN>(p, mb, acc, reinterpret_cast<float*>(sraw), m0, n0, wm, wn, lr, lq, tid, split == 0, use_atomic);
+  else gemm_epilogue_serial<NFN>(p, mb, acc, m0, n0, wm, wn, lr, lq, split == 0, use_atomic);
   TS(5)
   TS_FLUSH
 }
@@ -578,8 +748,8 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc 
 // buffered (80 KB), global loads run two K-steps ahead in two register sets, and the fp32 -> bf16 hi/lo conversion of step
 // j+1 is interleaved, unit by unit, between the MFMA groups of step j: one barrier per step, one workgroup per CU.
 template <int NFN, int NPASS, int AMODE, int BMODE>
-__device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, __bf16* smem, const int m0, const int n0, const int kbeg,
-                                            const int kend, const bool first_split, const bool use_atomic) {
+__device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, const Member& mb, __bf16* smem, const int m0, const int n0, const int kbeg,
+                                            const int kend, const bool first_split, const bool use_atomic, const bool epi_rows = true) {
   constexpr int BN = 16 * NFN;
   constexpr int NFW = (NFN + 1) / 2;
   constexpr int BROWS = 2 * NFW * 16;
@@ -611,7 +781,7 @@ __device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, __bf16* sme
 #endif
     int k0;
     const int sg = ks.seg(kbeg, kt, k0);
-    KSEG_PTRS(p, sg, Ak, Bk)
+    KSEG_PTRS(mb, sg, Ak, Bk)
     if constexpr (AMODE == VPTR_A_CONV) sa.load(p, m0, k0, kend, tid);
     else sa.load(Ak, p.lda, m0, p.M, k0, kend, tid);
     sb.load(Bk, p.ldb, n0, p.N, k0, kend, tid);
@@ -689,7 +859,8 @@ __device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, __bf16* sme
       TS(2)
     }
   }
-  gemm_epilogue<NFN, 1>(p, acc, m0, n0, wm, wn, lr, lq, first_split, use_atomic);
+  if (epi_rows && epi_vec_ok(p)) gemm_epilogue_rows<NFN>(p, mb, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, lr, lq, tid, first_split, use_atomic);
+  else gemm_epilogue<NFN, 1>(p, mb, acc, m0, n0, wm, wn, lr, lq, first_split, use_atomic);
   if constexpr (AMODE == VPTR_A_KSTRIDED) {
     if (p.a_rowsum && n0 == 0) {  // workgroup-uniform: column tile 0 owns the row sums of its A panel
       // thread (kb2, ob) summed k = kb2*2 + {0,1} (mod 32) of rows ob*4 + j: fold the 8 kb2 lanes, then the wave pair
@@ -724,18 +895,18 @@ __device__ __forceinline__ int xcd_logical_block() {
 }
 
 template <int NFN, int NPASS, int AMODE, int BMODE>
-__global__ __launch_bounds__(GNT, 2) void vptr_gemm_kernel_p(const vptr_gemm_desc p0, const int k_chunk) {
+__global__ __launch_bounds__(GNT, 2) void vptr_gemm_kernel_p(const vptr_gemm_desc p, const int k_chunk, const int epi_rows) {
   extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
   const int logical = xcd_logical_block();
-  const int tiles_n = (p0.N + 16 * NFN - 1) / (16 * NFN);
-  const int tiles = tiles_n * ((p0.M + GBM - 1) / GBM);
+  const int tiles_n = (p.N + 16 * NFN - 1) / (16 * NFN);
+  const int tiles = tiles_n * ((p.M + GBM - 1) / GBM);
   const int grp = logical / tiles, tile = logical - grp * tiles;
-  const bool batched = p0.batch > 1;
+  const bool batched = p.batch > 1;
   const int split = batched ? 0 : grp;
-  const vptr_gemm_desc p = member_view(p0, batched ? grp : 0);
+  const Member mb = member_of(p, batched ? grp : 0);
   const int kbeg = split * k_chunk;
-  gemm_tile_p<NFN, NPASS, AMODE, BMODE>(p, smem, (tile / tiles_n) * GBM, (tile % tiles_n) * 16 * NFN, kbeg, min(p.K, kbeg + k_chunk),
-                                        split == 0, p.atomic || (!batched && (int)gridDim.x > tiles));
+  gemm_tile_p<NFN, NPASS, AMODE, BMODE>(p, mb, smem, (tile / tiles_n) * GBM, (tile % tiles_n) * 16 * NFN, kbeg, min(p.K, kbeg + k_chunk),
+                                        split == 0, p.atomic || (!batched && (int)gridDim.x > tiles), epi_rows != 0);
 }
 
 // Grouped launch: `count` independent problems (same operand modes / precision / NFN class) in one grid, no split-K.
@@ -756,7 +927,8 @@ __global__ __launch_bounds__(GNT, 2) void vptr_gemm_grouped_kernel(const vptr_ge
   const vptr_gemm_desc p = descs[lo];
   const int tile = logical - tile_start[lo];
   const int tiles_n = (p.N + 16 * NFN - 1) / (16 * NFN);
-  gemm_tile_p<NFN, NPASS, AMODE, BMODE>(p, smem, (tile / tiles_n) * GBM, (tile % tiles_n) * 16 * NFN, 0, p.K, true, p.atomic != 0);
+  gemm_tile_p<NFN, NPASS, AMODE, BMODE>(p, member_of(p, 0), smem, (tile / tiles_n) * GBM, (tile % tiles_n) * 16 * NFN, 0, p.K, true,
+                                        p.atomic != 0);
 }
 
 
@@ -765,6 +937,16 @@ __global__ __launch_bounds__(GNT, 2) void vptr_gemm_grouped_kernel(const vptr_ge
 // workgroups per CU in the grid the single-image loop wins (N = 2112: 228 vs 179 TFLOP/s); with ~1 per CU the pipelined
 // one does (N = 528, K = 2112: 237 vs 186).  2 = choose by grid size (default); 0 / 1 force one (tools/gemm_probe.hip).
 static int g_gemm_variant = 2;
+// VPTR_GEMM_EPI_ROWS: bit 0 = row-major epilogue in the pipelined kernels, bit 1 = in the single-image kernel (default 3;
+// 0 = fragment-layout epilogues everywhere; tools/ab_epi.sh A/B runs)
+static int epi_rows_flag() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VPTR_GEMM_EPI_ROWS");
+    v = e ? atoi(e) : 3;
+  }
+  return v;
+}
 static int v4_min_tiles() {
   static int v = -1;
   if (v < 0) {
@@ -779,7 +961,8 @@ static int launch_one(const vptr_gemm_desc& d, dim3 grid, int k_chunk, hipStream
   const bool pipelined = g_gemm_variant == 1 || (g_gemm_variant == 2 && ((int)grid.x < v4_min_tiles() || d.a_rowsum != nullptr));
   if (pipelined) {
     constexpr int NFW = (NFN + 1) / 2, BROWS = 2 * NFW * 16, NPL = (NPASS == 3) ? 2 : 1;
-    constexpr int LDS_BYTES = 2 * NPL * (GBM + BROWS) * GLP * (int)sizeof(__bf16);
+    constexpr int LOOP_BYTES = 2 * NPL * (GBM + BROWS) * GLP * (int)sizeof(__bf16);
+    constexpr int LDS_BYTES = LOOP_BYTES > epi_lds_bytes<NFN>() ? LOOP_BYTES : epi_lds_bytes<NFN>();
     static bool attr_set = false;
     if (!attr_set) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_kernel_p<NFN, NPASS, AM, BM>),
@@ -789,9 +972,9 @@ static int launch_one(const vptr_gemm_desc& d, dim3 grid, int k_chunk, hipStream
       }
       attr_set = true;
     }
-    vptr_gemm_kernel_p<NFN, NPASS, AM, BM><<<grid, GNT, LDS_BYTES, st>>>(d, k_chunk);
+    vptr_gemm_kernel_p<NFN, NPASS, AM, BM><<<grid, GNT, LDS_BYTES, st>>>(d, k_chunk, epi_rows_flag() & 1);
   } else {
-    vptr_gemm_kernel<NFN, NPASS, AM, BM><<<grid, GNT, 0, st>>>(d, k_chunk);
+    vptr_gemm_kernel<NFN, NPASS, AM, BM><<<grid, GNT, 0, st>>>(d, k_chunk, epi_rows_flag() & 2);
   }
   return 0;
 }
@@ -897,7 +1080,8 @@ extern "C" int vptr_gemm_tile_cols(int N) { return 16 * nfn_for(N); }
 template <int NFN, int NPASS>
 static int launch_grouped(const vptr_gemm_desc* descs, const int* tile_start, int count, int total_tiles, hipStream_t st) {
   constexpr int NFW = (NFN + 1) / 2, BROWS = 2 * NFW * 16, NPL = (NPASS == 3) ? 2 : 1;
-  constexpr int LDS_BYTES = 2 * NPL * (GBM + BROWS) * GLP * (int)sizeof(__bf16);
+  constexpr int LOOP_BYTES = 2 * NPL * (GBM + BROWS) * GLP * (int)sizeof(__bf16);
+  constexpr int LDS_BYTES = LOOP_BYTES > epi_lds_bytes<NFN>() ? LOOP_BYTES : epi_lds_bytes<NFN>();
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_grouped_kernel<NFN, NPASS, VPTR_A_KSTRIDED, VPTR_B_KSTRIDED>),
