@@ -522,18 +522,23 @@ __global__ __launch_bounds__(256) void norm_act_bwd_col_reduce(const float* __re
   unsafeAtomicAdd(acc + F + c, ab);
 }
 // phase 1 (fused 1a + 1b, one pass over dy and x instead of two): affine gradients dw[e] += sum_f g*xhat, db[e] += sum_f g
-// (thread per float4 of the frame, loop over a frame chunk) AND the frame sums s1[f] += sum_e g*w, s2[f] += sum_e g*w*xhat
-// (wave reduction per frame, one atomic pair per wave).  The threads past E4 keep running with zero weight so that every
+// AND the frame sums s1[f] += sum_e g*w, s2[f] += sum_e g*w*xhat (wave reduction per frame, stored as per-wave partials).
+// Workgroup = 64 float4 positions of the frame x 4 waves that take every fourth frame of the chunk: 8 waves per SIMD in
+// flight instead of 2 (the first version -- thread per position, 40 frames in sequence -- ran its ~50 VALU ops per element
+// and its two loads per frame back to back: 64 us against a 35 us HBM time), and the four waves' affine sums meet in LDS
+// so that the atomic count does not grow with the parallelism.  Lanes past E4 keep running with zero weight so that every
 // wave takes part in the shuffles.
 __global__ __launch_bounds__(256) void norm_act_bwd_frame_affine(const float* __restrict__ dy, const float* __restrict__ x,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ w, const float* __restrict__ b,
                                                                  float* __restrict__ dw, float* __restrict__ db,
-                                                                 float* __restrict__ fsum /* [gridDim.x*4, frames, 2] partials */, int E4, int F,
+                                                                 float* __restrict__ fsum /* [gridDim.x, frames, 2] partials */, int E4, int F,
                                                                  int HW, int act, float p, const uint64_t* seed_dev,
                                                                  uint32_t site, int frames, int fpb,
                                                                  const float* __restrict__ rowscale, int rs_div, int rs_mod) {
-  const int e_raw = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float sred[3][64][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e_raw = blockIdx.x * 64 + lane;
   const bool live = e_raw < E4;
   const int e = live ? e_raw : E4 - 1;
   const float lv = live ? 1.f : 0.f;
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_frame_affine(const float* __
   const float ws[4] = {wv.x, wv.y, wv.z, wv.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
   float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
   const int hw = (e * 4) / F;
-  for (int f = f0; f < f1; ++f) {
+  for (int f = f0 + wave; f < f1; f += 4) {
     float t1 = 0.f, t2 = 0.f;
     const float4 d = reinterpret_cast<const float4*>(dy)[(int64_t)f * E4 + e];
     const float4 xv = reinterpret_cast<const float4*>(x)[(int64_t)f * E4 + e];
@@ -566,18 +571,26 @@ __global__ __launch_bounds__(256) void norm_act_bwd_frame_affine(const float* __
     if (fsum) {  // per-wave partials, no atomics: 500+ waves adding into the same 2*frames words serialise badly
       t1 = wave_sum(t1);
       t2 = wave_sum(t2);
-      if ((threadIdx.x & 63) == 0) {
-        float* dst = fsum + ((int64_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * frames + f) * 2;
+      if (lane == 0) {
+        float* dst = fsum + ((int64_t)blockIdx.x * frames + f) * 2;
         dst[0] = t1;
         dst[1] = t2;
       }
     }
   }
-  if (!live) return;
+  if (wave > 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      sred[wave - 1][lane][q] = aw[q];
+      sred[wave - 1][lane][4 + q] = ab[q];
+    }
+  }
+  __syncthreads();
+  if (wave > 0 || !live) return;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    unsafeAtomicAdd(dw + (int64_t)e * 4 + q, aw[q]);
-    unsafeAtomicAdd(db + (int64_t)e * 4 + q, ab[q]);
+    unsafeAtomicAdd(dw + (int64_t)e * 4 + q, aw[q] + sred[0][lane][q] + sred[1][lane][q] + sred[2][lane][q]);
+    unsafeAtomicAdd(db + (int64_t)e * 4 + q, ab[q] + sred[0][lane][4 + q] + sred[1][lane][4 + q] + sred[2][lane][4 + q]);
   }
 }
 // phase 2: dx = rstd * (g*w - S1/n - xhat*S2/n)
@@ -662,9 +675,9 @@ extern "C" int vptr_norm_act_bwd(const float* dy, const float* x, const float* m
     VPTR_CHECK(F % 4 == 0, "norm_act_bwd: F must be a multiple of 4");
     const int E4 = HW * F / 4;
     const int fpb = frames >= 64 ? (frames + 3) / 4 : frames;
-    const int nparts = cdiv(E4, 256) * 4;  // scratch: [2*frames] sums followed by [nparts, frames, 2] per-wave partials
+    const int nparts = cdiv(E4, 64);  // scratch: [2*frames] sums followed by [nparts, frames, 2] per-wave partials
     float* part = scratch + 2 * frames;
-    norm_act_bwd_frame_affine<<<dim3(cdiv(E4, 256), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, mean, rstd, w, b, dw, db, part, E4, F, HW, act,
+    norm_act_bwd_frame_affine<<<dim3(nparts, cdiv(frames, fpb)), 256, 0, st>>>(dy, x, mean, rstd, w, b, dw, db, part, E4, F, HW, act,
                                                                                      dropout_p, seed_dev, site, frames, fpb, rowscale,
                                                                                      rs_div, rs_mod);
     norm_act_bwd_frame_final<<<frames, 64, 0, st>>>(part, scratch, nparts, frames);
