@@ -29,7 +29,8 @@ def rn(shape, seed, scale=1.0):
 
 # ---------------------------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("prec,tol", [(3, TOL3), (1, TOL1)])
-@pytest.mark.parametrize("M,N,K", [(300, 528, 528), (257, 100, 72), (128, 352, 2112), (64, 48, 48), (1000, 1584, 528)])
+@pytest.mark.parametrize("M,N,K", [(300, 528, 528), (257, 100, 72), (128, 352, 2112), (64, 48, 48), (1000, 1584, 528),
+                                   (200, 50, 48), (5000, 530, 64), (20000, 530, 64)])   # N % 4 != 0: fragment-layout epilogues (both loops)
 def test_gemm_nt_epilogue(ops, dev, M, N, K, prec, tol):
     x, W, b, r = rn((M, K), 1), rn((N, K), 2, K ** -0.5), rn((N,), 3), rn((M, N), 4)
     ref = F.gelu((x.double() @ W.double().t() + b.double()) * 0.5) + r.double()

@@ -326,8 +326,9 @@ struct KSeg {
   const float* Ak = (mb).A + ((s) == 0 ? (int64_t)0 : ((s) == 1 ? ksA1 : ksA2)); \
   const float* Bk = (mb).B + ((s) == 0 ? (int64_t)0 : ((s) == 1 ? ksB1 : ksB2));
 
-// ---- epilogue of the pipelined loop (one workgroup per CU: nothing else hides its latencies)
-template <int NFN, int NGRP>  // NGRP: column-fragment groups, each = all its loads, then its stores (2 under a 128-VGPR cap)
+// ---- fragment-layout epilogue of the pipelined loop, used when the row-major one below cannot be (N % 4 != 0, unaligned
+// pointers).  One workgroup per CU: nothing else hides its latencies, so all loads are issued before the first store.
+template <int NFN, int NGRP>  // NGRP: column-fragment groups, each = all its loads, then its stores
 __device__ __forceinline__ void gemm_epilogue(const vptr_gemm_desc& p, const Member& mb, f32x4 (&acc)[2][(NFN + 1) / 2], const int m0, const int n0,
                                               const int wm, const int wn, const int lr, const int lq, const bool first_split,
                                               const bool use_atomic) {
