@@ -265,9 +265,11 @@ def test_window_attention(ops, dev, ws, H, W):
     assert rel(od2, O.win_reverse(o2, B, H, W, ws).reshape(B * H * W, C)) < TOLV
 
 
-@pytest.mark.parametrize("Tq,Tk,causal", [(5, 5, False), (5, 5, True), (3, 7, False), (29, 29, True)])
-def test_temporal_attention(ops, dev, Tq, Tk, causal):
-    N, HW, C, nh = 2, 6, 48, 8
+@pytest.mark.parametrize("Tq,Tk,causal,N,HW", [(5, 5, False, 2, 6), (5, 5, True, 2, 6), (3, 7, False, 2, 6), (29, 29, True, 2, 6),
+                                               # >= 256 pixel problems: the variant with 4 pixels per wave + register prefetch
+                                               (5, 5, True, 3, 90), (3, 7, False, 3, 90), (10, 10, False, 2, 129)])
+def test_temporal_attention(ops, dev, Tq, Tk, causal, N, HW):
+    C, nh = 48, 8
     q, k, v = rn((N * Tq * HW, C), 60, 0.5), rn((N * Tk * HW, C), 61, 0.5), rn((N * Tk * HW, C), 62)
     go = rn((N * Tq * HW, C), 63)
     ins = [t.double().clone().requires_grad_(True) for t in (q, k, v)]

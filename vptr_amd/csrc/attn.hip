@@ -106,6 +106,32 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ src, float*
     *reinterpret_cast<float2*>(dst + l * hp + 2 * d2) = v;
   }
 }
+// The same in two halves for a 256-thread workgroup and 16-row tiles: the global loads of the NEXT tile are issued into
+// registers before the current tile is computed and written to LDS afterwards (the kernels spent ~70 % of their wave
+// cycles waiting: load -> barrier -> compute -> store per window, 4-5 workgroups per CU deep).
+struct Rows16 {
+  float2 v[3];  // items tid, tid + 256, tid + 512 of the 16 x (hp / 2) float2 tile
+};
+__device__ __forceinline__ void rows16_load(Rows16& r, const float* __restrict__ src, int win, int H, int W, int C, int nqh, int nqw,
+                                            int hoff, int hd, int hp, int tid) {
+  const int h2 = hp >> 1, v2 = hd >> 1;
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const int e = tid + it * 256;
+    const int l = e / h2, d2 = e - l * h2;
+    r.v[it] = make_float2(0.f, 0.f);
+    if (l < 16 && d2 < v2) r.v[it] = *reinterpret_cast<const float2*>(src + (int64_t)win_row(win, l, H, W, 4, nqh, nqw) * C + hoff + 2 * d2);
+  }
+}
+__device__ __forceinline__ void rows16_store(const Rows16& r, float* dst, int hp, int tid) {
+  const int h2 = hp >> 1;
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const int e = tid + it * 256;
+    const int l = e / h2, d2 = e - l * h2;
+    if (l < 16) *reinterpret_cast<float2*>(dst + l * hp + 2 * d2) = r.v[it];
+  }
+}
 // out rows: dst[rowoff[r] + hoff + d] = acc (hd even; float2 stores)
 __device__ __forceinline__ void store4(float* __restrict__ dst, int64_t base, int d, int hd, const float4 v) {
   *reinterpret_cast<float2*>(dst + base + d) = make_float2(v.x, v.y);
@@ -130,13 +156,23 @@ __global__ __launch_bounds__(256) void winattn16_fwd_kernel(const float* __restr
   if (p > 0.f) seed = *seed_dev;
   const float bias = table ? table[rel_index[tid] * nh + h] : 0.f;   // element (i, j) of the relative-position bias
   const int w0 = blockIdx.x * wpb, w1 = min(nwin, w0 + wpb);
+  Rows16 rq, rk, rv;
+  if (w0 < w1) {
+    rows16_load(rq, q, w0, H, W, C, nqh, nqw, h * hd, hd, hp, tid);
+    rows16_load(rk, k, w0, H, W, C, nqh, nqw, h * hd, hd, hp, tid);
+    rows16_load(rv, v, w0, H, W, C, nqh, nqw, h * hd, hd, hp, tid);
+  }
   for (int win = w0; win < w1; ++win) {
     __syncthreads();
     if (tid < 16) srow[tid] = (int64_t)win_row(win, tid, H, W, 4, nqh, nqw) * C;
-    __syncthreads();
-    stage_rows(q, sq, srow, 16, h * hd, hd, hp, tid, 256);
-    stage_rows(k, sk, srow, 16, h * hd, hd, hp, tid, 256);
-    stage_rows(v, sv, srow, 16, h * hd, hd, hp, tid, 256);
+    rows16_store(rq, sq, hp, tid);
+    rows16_store(rk, sk, hp, tid);
+    rows16_store(rv, sv, hp, tid);
+    if (win + 1 < w1) {  // workgroup-uniform: next window's rows fly while this one is computed
+      rows16_load(rq, q, win + 1, H, W, C, nqh, nqw, h * hd, hd, hp, tid);
+      rows16_load(rk, k, win + 1, H, W, C, nqh, nqw, h * hd, hd, hp, tid);
+      rows16_load(rv, v, win + 1, H, W, C, nqh, nqw, h * hd, hd, hp, tid);
+    }
     __syncthreads();
     float a = bias;
     for (int d = 0; d < n4; ++d)
@@ -182,14 +218,26 @@ __global__ __launch_bounds__(256) void winattn16_bwd_kernel(const float* __restr
   const float bias = table ? table[ridx * nh + h] : 0.f;
   float dbias = 0.f;  // this thread's (i, j) element of dS summed over the workgroup's windows
   const int w0 = blockIdx.x * wpb, w1 = min(nwin, w0 + wpb);
+  Rows16 rq, rk, rv, rdo;
+  if (w0 < w1) {
+    rows16_load(rq, q, w0, H, W, C, nqh, nqw, h * hd, hd, hp, tid);
+    rows16_load(rk, k, w0, H, W, C, nqh, nqw, h * hd, hd, hp, tid);
+    rows16_load(rv, v, w0, H, W, C, nqh, nqw, h * hd, hd, hp, tid);
+    rows16_load(rdo, dout, w0, H, W, C, nqh, nqw, h * hd, hd, hp, tid);
+  }
   for (int win = w0; win < w1; ++win) {
     __syncthreads();
     if (tid < 16) srow[tid] = (int64_t)win_row(win, tid, H, W, 4, nqh, nqw) * C;
-    __syncthreads();
-    stage_rows(q, sq, srow, 16, h * hd, hd, hp, tid, 256);
-    stage_rows(k, sk, srow, 16, h * hd, hd, hp, tid, 256);
-    stage_rows(v, sv, srow, 16, h * hd, hd, hp, tid, 256);
-    stage_rows(dout, sdo, srow, 16, h * hd, hd, hp, tid, 256);
+    rows16_store(rq, sq, hp, tid);
+    rows16_store(rk, sk, hp, tid);
+    rows16_store(rv, sv, hp, tid);
+    rows16_store(rdo, sdo, hp, tid);
+    if (win + 1 < w1) {  // workgroup-uniform: next window's rows fly while this one is computed
+      rows16_load(rq, q, win + 1, H, W, C, nqh, nqw, h * hd, hd, hp, tid);
+      rows16_load(rk, k, win + 1, H, W, C, nqh, nqw, h * hd, hd, hp, tid);
+      rows16_load(rv, v, win + 1, H, W, C, nqh, nqw, h * hd, hd, hp, tid);
+      rows16_load(rdo, dout, win + 1, H, W, C, nqh, nqw, h * hd, hd, hp, tid);
+    }
     __syncthreads();
     float a = bias, b = 0.f;
     for (int d = 0; d < n4; ++d) {
@@ -245,7 +293,7 @@ extern "C" int vptr_winattn_fwd(const float* q, const float* k, const float* v, 
   const int L = ws * ws, hd = C / nh;
   if (ws == 4 && hd % 2 == 0 && C % 2 == 0) {
     const int nwin = B * (H / 4) * (W / 4);
-    const int wpb = nwin >= 8192 ? 2 : 1;
+    const int wpb = nwin >= 64 ? 2 : 1;   // two windows per workgroup: the second one's loads overlap the first one's math
     const size_t lds16 = sizeof(float) * (3 * 16 * att_pitch(hd) + 16 * 20);
     winattn16_fwd_kernel<<<dim3(cdiv(nwin, wpb), nh), 256, lds16, (hipStream_t)stream>>>(q, k, v, bias_table, rel_index, o, nwin, H, W, C,
                                                                                          nh, dropout_p, seed_dev, site, wpb);
@@ -373,7 +421,8 @@ extern "C" int vptr_winattn_bwd(const float* q, const float* k, const float* v, 
   const int nwin = B * (H / ws) * (W / ws);
   if (ws == 4 && hd % 2 == 0 && C % 2 == 0) {
     // many windows per workgroup: the 49 bias-table atomics per workgroup hit the same 49*nh addresses from every workgroup
-    const int wpb16 = nwin >= 512 ? 4 : (nwin >= 64 ? 2 : 1);
+    // with a bias-table gradient, fewer and longer workgroups (their 49 atomics per head all hit the same 392 words)
+    const int wpb16 = nwin >= 512 ? (dbias_table ? 8 : 4) : (nwin >= 64 ? 2 : 1);
     const size_t lds16 = sizeof(float) * (4 * 16 * att_pitch(hd) + 2 * 16 * 20);
     winattn16_bwd_kernel<<<dim3(cdiv(nwin, wpb16), nh), 256, lds16, (hipStream_t)stream>>>(q, k, v, bias_table, rel_index, dout, dq, dk,
                                                                                           dv, dbias_table, nwin, H, W, C, nh,
@@ -454,6 +503,34 @@ __global__ __launch_bounds__(64) void tattn_fwd_kernel(const float* __restrict__
 // fast path for T <= 16 time steps (10 in every shipped configuration): one wave per (n, pixel, head); score element
 // (i, j) sits on lane (i % 4) * 16 + j of round i / 4 (see the window fast path above for the LDS layout).
 // ------------------------------------------------------------------------------------------------------------
+// Temporal fast path, register-staged rows: T x (hp / 2) float2 items over one wave, at most TR_NIT per lane (T = 10,
+// head dim 66: 340 items = 6 per lane).  Used to fetch the NEXT pixel's rows while the current pixel is computed.
+#define TR_NIT 6
+#define TR_PPW 4   // consecutive pixels per wave in the prefetching variant
+struct TRows {
+  float2 v[TR_NIT];
+};
+__device__ __forceinline__ void trows_load(TRows& r, const float* __restrict__ src, int n, int T, int HW, int pix, int C, int hoff, int hd,
+                                           int hp, int lane) {
+  const int h2 = hp >> 1, v2 = hd >> 1;
+#pragma unroll
+  for (int it = 0; it < TR_NIT; ++it) {
+    const int e = lane + it * 64;
+    const int l = e / h2, d2 = e - l * h2;
+    r.v[it] = make_float2(0.f, 0.f);
+    if (l < T && d2 < v2) r.v[it] = *reinterpret_cast<const float2*>(src + ((int64_t)(n * T + l) * HW + pix) * C + hoff + 2 * d2);
+  }
+}
+__device__ __forceinline__ void trows_store(const TRows& r, float* dst, int T, int hp, int lane) {
+  const int h2 = hp >> 1;
+#pragma unroll
+  for (int it = 0; it < TR_NIT; ++it) {
+    const int e = lane + it * 64;
+    const int l = e / h2, d2 = e - l * h2;
+    if (l < T) *reinterpret_cast<float2*>(dst + l * hp + 2 * d2) = r.v[it];
+  }
+}
+template <bool PF>  // PF: TR_PPW pixels per wave, the next pixel's rows prefetched into registers
 __global__ __launch_bounds__(64) void tattn16_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, float* __restrict__ o, int Tq, int Tk,
                                                          int HW, int C, int nh, int causal, float p, const uint64_t* seed_dev,
@@ -466,43 +543,67 @@ __global__ __launch_bounds__(64) void tattn16_fwd_kernel(const float* __restrict
   float* ss = sv + Tk * hp;      // [16][20]
   __shared__ int64_t rq[16], rk[16];
   // workgroup b runs on XCD b % 8: the nh heads of a token (which share its cache lines) get the same XCD
-  const int h = (blockIdx.x >> 3) % nh, np = (blockIdx.x / (8 * nh)) * 8 + (blockIdx.x & 7), lane = threadIdx.x;
-  if (np >= NP) return;  // tail when the token count is not a multiple of 8 (the grid is rounded up)
-  const int n = np / HW, pix = np - n * HW;
-  if (lane < Tq) rq[lane] = ((int64_t)(n * Tq + lane) * HW + pix) * C;
-  if (lane < Tk) rk[lane] = ((int64_t)(n * Tk + lane) * HW + pix) * C;
-  __syncthreads();
-  stage_rows(q, sq, rq, Tq, h * hd, hd, hp, lane, 64);
-  stage_rows(k, sk, rk, Tk, h * hd, hd, hp, lane, 64);
-  stage_rows(v, sv, rk, Tk, h * hd, hd, hp, lane, 64);
-  __syncthreads();
+  constexpr int PPW = PF ? TR_PPW : 1;
+  const int h = (blockIdx.x >> 3) % nh, npg = (blockIdx.x / (8 * nh)) * 8 + (blockIdx.x & 7), lane = threadIdx.x;
+  const int np0 = npg * PPW, np1 = min(NP, np0 + PPW);   // tail: the grid is rounded up to a multiple of 8 pixel groups
   uint64_t seed = 0;
   if (p > 0.f) seed = *seed_dev;
   const int j = lane & 15;
-  for (int i0 = 0; i0 < Tq; i0 += 4) {
-    const int i = i0 + (lane >> 4);
-    const bool ok = i < Tq && j < Tk && !(causal && j > i);
-    const int ic = min(i, Tq - 1), jc = min(j, Tk - 1);
-    float a = 0.f;
-    for (int d = 0; d < n4; ++d)
-      a += dot4(reinterpret_cast<const float4*>(sq + ic * hp)[d], reinterpret_cast<const float4*>(sk + jc * hp)[d]);
-    a = ok ? a : -INFINITY;
-    const float m = row16_max(a);
-    const float e = ok ? __expf(a - m) : 0.f;
-    float pr = e / row16_sum(e);
-    if (p > 0.f) pr *= vptr_drop_scale(seed, site, (((uint64_t)np * nh + h) * Tq + ic) * Tk + jc, p);
-    if (i < Tq) ss[i * 20 + j] = ok ? pr : 0.f;
+  TRows tq, tk, tv;
+  if (PF && np0 < np1) {
+    const int n = np0 / HW, pix = np0 - n * HW;
+    trows_load(tq, q, n, Tq, HW, pix, C, h * hd, hd, hp, lane);
+    trows_load(tk, k, n, Tk, HW, pix, C, h * hd, hd, hp, lane);
+    trows_load(tv, v, n, Tk, HW, pix, C, h * hd, hd, hp, lane);
   }
-  __syncthreads();
-  for (int e = lane; e < Tq * n4; e += 64) {
-    const int i = e / n4, d4 = e - i * n4;
-    if (d4 * 4 >= hd) continue;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = 0; c < Tk; ++c) axpy4(acc, ss[i * 20 + c], reinterpret_cast<const float4*>(sv + c * hp)[d4]);
-    store4(o, rq[i] + h * hd, d4 * 4, hd, acc);
+  for (int np = np0; np < np1; ++np) {
+    const int n = np / HW, pix = np - n * HW;
+    __syncthreads();
+    if (lane < Tq) rq[lane] = ((int64_t)(n * Tq + lane) * HW + pix) * C;
+    if (lane < Tk) rk[lane] = ((int64_t)(n * Tk + lane) * HW + pix) * C;
+    if (PF) {
+      trows_store(tq, sq, Tq, hp, lane);
+      trows_store(tk, sk, Tk, hp, lane);
+      trows_store(tv, sv, Tk, hp, lane);
+      if (np + 1 < np1) {  // wave-uniform: the next pixel's rows fly while this one is computed
+        const int n2 = (np + 1) / HW, pix2 = np + 1 - n2 * HW;
+        trows_load(tq, q, n2, Tq, HW, pix2, C, h * hd, hd, hp, lane);
+        trows_load(tk, k, n2, Tk, HW, pix2, C, h * hd, hd, hp, lane);
+        trows_load(tv, v, n2, Tk, HW, pix2, C, h * hd, hd, hp, lane);
+      }
+    } else {
+      __syncthreads();
+      stage_rows(q, sq, rq, Tq, h * hd, hd, hp, lane, 64);
+      stage_rows(k, sk, rk, Tk, h * hd, hd, hp, lane, 64);
+      stage_rows(v, sv, rk, Tk, h * hd, hd, hp, lane, 64);
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < Tq; i0 += 4) {
+      const int i = i0 + (lane >> 4);
+      const bool ok = i < Tq && j < Tk && !(causal && j > i);
+      const int ic = min(i, Tq - 1), jc = min(j, Tk - 1);
+      float a = 0.f;
+      for (int d = 0; d < n4; ++d)
+        a += dot4(reinterpret_cast<const float4*>(sq + ic * hp)[d], reinterpret_cast<const float4*>(sk + jc * hp)[d]);
+      a = ok ? a : -INFINITY;
+      const float m = row16_max(a);
+      const float e = ok ? __expf(a - m) : 0.f;
+      float pr = e / row16_sum(e);
+      if (p > 0.f) pr *= vptr_drop_scale(seed, site, (((uint64_t)np * nh + h) * Tq + ic) * Tk + jc, p);
+      if (i < Tq) ss[i * 20 + j] = ok ? pr : 0.f;
+    }
+    __syncthreads();
+    for (int e = lane; e < Tq * n4; e += 64) {
+      const int i = e / n4, d4 = e - i * n4;
+      if (d4 * 4 >= hd) continue;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int c = 0; c < Tk; ++c) axpy4(acc, ss[i * 20 + c], reinterpret_cast<const float4*>(sv + c * hp)[d4]);
+      store4(o, rq[i] + h * hd, d4 * 4, hd, acc);
+    }
   }
 }
 
+template <bool PF>
 __global__ __launch_bounds__(64) void tattn16_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, const float* __restrict__ dout,
                                                          float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
@@ -517,20 +618,45 @@ __global__ __launch_bounds__(64) void tattn16_bwd_kernel(const float* __restrict
   float* sp = sv + Tk * hp;       // [16][20]  dropped probabilities
   float* sds = sp + 16 * 20;      // [16][20]  dS
   __shared__ int64_t rq[16], rk[16];
-  const int h = (blockIdx.x >> 3) % nh, np = (blockIdx.x / (8 * nh)) * 8 + (blockIdx.x & 7), lane = threadIdx.x;
-  if (np >= NP) return;
-  const int n = np / HW, pix = np - n * HW;
-  if (lane < Tq) rq[lane] = ((int64_t)(n * Tq + lane) * HW + pix) * C;
-  if (lane < Tk) rk[lane] = ((int64_t)(n * Tk + lane) * HW + pix) * C;
-  __syncthreads();
-  stage_rows(q, sq, rq, Tq, h * hd, hd, hp, lane, 64);
-  stage_rows(dout, sdo, rq, Tq, h * hd, hd, hp, lane, 64);
-  stage_rows(k, sk, rk, Tk, h * hd, hd, hp, lane, 64);
-  stage_rows(v, sv, rk, Tk, h * hd, hd, hp, lane, 64);
-  __syncthreads();
+  constexpr int PPW = PF ? TR_PPW : 1;
+  const int h = (blockIdx.x >> 3) % nh, npg = (blockIdx.x / (8 * nh)) * 8 + (blockIdx.x & 7), lane = threadIdx.x;
+  const int np0 = npg * PPW, np1 = min(NP, np0 + PPW);
   uint64_t seed = 0;
   if (p > 0.f) seed = *seed_dev;
   const int j = lane & 15;
+  TRows tq, tdo, tk, tv;
+  if (PF && np0 < np1) {
+    const int n = np0 / HW, pix = np0 - n * HW;
+    trows_load(tq, q, n, Tq, HW, pix, C, h * hd, hd, hp, lane);
+    trows_load(tdo, dout, n, Tq, HW, pix, C, h * hd, hd, hp, lane);
+    trows_load(tk, k, n, Tk, HW, pix, C, h * hd, hd, hp, lane);
+    trows_load(tv, v, n, Tk, HW, pix, C, h * hd, hd, hp, lane);
+  }
+  for (int np = np0; np < np1; ++np) {
+  const int n = np / HW, pix = np - n * HW;
+  __syncthreads();
+  if (lane < Tq) rq[lane] = ((int64_t)(n * Tq + lane) * HW + pix) * C;
+  if (lane < Tk) rk[lane] = ((int64_t)(n * Tk + lane) * HW + pix) * C;
+  if (PF) {
+    trows_store(tq, sq, Tq, hp, lane);
+    trows_store(tdo, sdo, Tq, hp, lane);
+    trows_store(tk, sk, Tk, hp, lane);
+    trows_store(tv, sv, Tk, hp, lane);
+    if (np + 1 < np1) {  // wave-uniform: the next pixel's rows fly while this one is computed
+      const int n2 = (np + 1) / HW, pix2 = np + 1 - n2 * HW;
+      trows_load(tq, q, n2, Tq, HW, pix2, C, h * hd, hd, hp, lane);
+      trows_load(tdo, dout, n2, Tq, HW, pix2, C, h * hd, hd, hp, lane);
+      trows_load(tk, k, n2, Tk, HW, pix2, C, h * hd, hd, hp, lane);
+      trows_load(tv, v, n2, Tk, HW, pix2, C, h * hd, hd, hp, lane);
+    }
+  } else {
+    __syncthreads();
+    stage_rows(q, sq, rq, Tq, h * hd, hd, hp, lane, 64);
+    stage_rows(dout, sdo, rq, Tq, h * hd, hd, hp, lane, 64);
+    stage_rows(k, sk, rk, Tk, h * hd, hd, hp, lane, 64);
+    stage_rows(v, sv, rk, Tk, h * hd, hd, hp, lane, 64);
+  }
+  __syncthreads();
   for (int i0 = 0; i0 < Tq; i0 += 4) {
     const int i = i0 + (lane >> 4);
     const bool ok = i < Tq && j < Tk && !(causal && j > i);
@@ -571,6 +697,7 @@ __global__ __launch_bounds__(64) void tattn16_bwd_kernel(const float* __restrict
     store4(dk, rk[c] + h * hd, d4 * 4, hd, ak);
     store4(dv, rk[c] + h * hd, d4 * 4, hd, av);
   }
+  }
 }
 
 extern "C" int vptr_tattn_fwd(const float* q, const float* k, const float* v, float* o, int Nb, int Tq, int Tk, int HW, int C,
@@ -584,8 +711,13 @@ extern "C" int vptr_tattn_fwd(const float* q, const float* k, const float* v, fl
   const int hd = C / nh;
   if (Tq <= 16 && Tk <= 16 && hd % 2 == 0 && C % 2 == 0) {
     const size_t lds16 = sizeof(float) * ((Tq + 2 * Tk) * att_pitch(hd) + 16 * 20);
-    tattn16_fwd_kernel<<<dim3(cdiv(Nb * HW, 8) * 8 * nh), 64, lds16, (hipStream_t)stream>>>(q, k, v, o, Tq, Tk, HW, C, nh, causal,
-                                                                                           dropout_p, seed_dev, site, Nb * HW);
+    const int items = (Tq > Tk ? Tq : Tk) * (att_pitch(hd) / 2);
+    if (items <= 64 * TR_NIT && Nb * HW >= 64 * TR_PPW)
+      tattn16_fwd_kernel<true><<<dim3(cdiv(cdiv(Nb * HW, TR_PPW), 8) * 8 * nh), 64, lds16, (hipStream_t)stream>>>(
+          q, k, v, o, Tq, Tk, HW, C, nh, causal, dropout_p, seed_dev, site, Nb * HW);
+    else
+      tattn16_fwd_kernel<false><<<dim3(cdiv(Nb * HW, 8) * 8 * nh), 64, lds16, (hipStream_t)stream>>>(q, k, v, o, Tq, Tk, HW, C, nh, causal,
+                                                                                                    dropout_p, seed_dev, site, Nb * HW);
     VPTR_LAUNCH_CHECK();
     return 0;
   }
@@ -693,8 +825,13 @@ extern "C" int vptr_tattn_bwd(const float* q, const float* k, const float* v, co
   const int hd = C / nh;
   if (Tq <= 16 && Tk <= 16 && hd % 2 == 0 && C % 2 == 0) {
     const size_t lds16 = sizeof(float) * (2 * (Tq + Tk) * att_pitch(hd) + 2 * 16 * 20);
-    tattn16_bwd_kernel<<<dim3(cdiv(Nb * HW, 8) * 8 * nh), 64, lds16, (hipStream_t)stream>>>(q, k, v, dout, dq, dk, dv, Tq, Tk, HW, C, nh,
-                                                                                           causal, dropout_p, seed_dev, site, Nb * HW, dq_scale);
+    const int items = (Tq > Tk ? Tq : Tk) * (att_pitch(hd) / 2);
+    if (items <= 64 * TR_NIT && Nb * HW >= 64 * TR_PPW)
+      tattn16_bwd_kernel<true><<<dim3(cdiv(cdiv(Nb * HW, TR_PPW), 8) * 8 * nh), 64, lds16, (hipStream_t)stream>>>(
+          q, k, v, dout, dq, dk, dv, Tq, Tk, HW, C, nh, causal, dropout_p, seed_dev, site, Nb * HW, dq_scale);
+    else
+      tattn16_bwd_kernel<false><<<dim3(cdiv(Nb * HW, 8) * 8 * nh), 64, lds16, (hipStream_t)stream>>>(
+          q, k, v, dout, dq, dk, dv, Tq, Tk, HW, C, nh, causal, dropout_p, seed_dev, site, Nb * HW, dq_scale);
     VPTR_LAUNCH_CHECK();
     return 0;
   }
