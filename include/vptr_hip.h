@@ -125,9 +125,11 @@ int vptr_gemm_grouped(const vptr_gemm_desc* proto, const vptr_gemm_desc* descs_d
 int vptr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* y2, const float* tab,
                        int tab_div, int tab_mod, float* mean, float* rstd, int rows, int C, float eps,
                        vptr_stream_t stream);
-/* dx = LN'(dy + dy2); dgamma/dbeta are ACCUMULATED (+=) with atomics; dy2 may be null. */
+/* dx = LN'(dy + dy2) + dx_add; dgamma/dbeta are ACCUMULATED (+=) with atomics; dy2 and dx_add may be null.
+ * dx_add [rows, C] is the gradient that reaches x through the residual connection around the pre-norm sub-layer
+ * (x + f(LN(x)), VidHRFormer_modules.py:68-93): added here, it needs no accumulation pass of its own. */
 int vptr_layernorm_bwd(const float* dy, const float* dy2, const float* x, const float* gamma, const float* mean,
-                       const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int C,
+                       const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int C, const float* dx_add,
                        vptr_stream_t stream);
 
 /* out[(row / div) % mod, :] += src[row, :]   (gradient of a row-broadcast table; out must be zeroed by the caller) */

@@ -222,6 +222,25 @@ def test_layernorm_fwd_bwd(ops, dev):
     d0 = x.to(dev).requires_grad_(True)
     o = ops.layernorm(d0, ds[1].detach(), ds[2].detach())
     assert rel(o, y) < TOLV
+    # pass-through output: the residual gradient is added inside the backward kernel (dx_add); C = 48 (fused kernel) and 1028 (two-kernel path)
+    for Cc in (48, 1028):
+        xc, gc, bc = rn((rows, Cc), 46), rn((Cc,), 47).abs() + 0.5, rn((Cc,), 48)
+        g1, g2, g3 = rn((rows, Cc), 49), rn((rows, Cc), 50), rn((rows, Cc), 51)
+        tabc = rn((T, Cc), 52)
+        xr_ = xc.double().clone().requires_grad_(True)
+        yr = F.layer_norm(xr_, (Cc,), gc.double(), bc.double(), 1e-5)
+        ((yr * g1.double()).sum() + ((yr + tabc.double()[t_idx]) * g2.double()).sum() + (xr_ * g3.double()).sum()).backward()
+        xd = xc.to(dev).requires_grad_(True)
+        o, o2, xp = ops.layernorm(xd, gc.to(dev), bc.to(dev), tab=tabc.to(dev), tab_div=HW, tab_mod=T, passthrough=True)
+        assert torch.equal(xp, xd)
+        ((o * g1.to(dev)).sum() + (o2 * g2.to(dev)).sum() + (xp * g3.to(dev)).sum()).backward()
+        assert rel(xd.grad, xr_.grad) < 5e-5
+        xd2 = xc.to(dev).requires_grad_(True)      # only the pass-through and the plain output consumed
+        o, xp = ops.layernorm(xd2, gc.to(dev), bc.to(dev), passthrough=True)
+        ((o * g1.to(dev)).sum() + (xp * g3.to(dev)).sum()).backward()
+        xr2 = xc.double().clone().requires_grad_(True)
+        ((F.layer_norm(xr2, (Cc,), gc.double(), bc.double(), 1e-5) * g1.double()).sum() + (xr2 * g3.double()).sum()).backward()
+        assert rel(xd2.grad, xr2.grad) < 5e-5
 
 
 def test_rowtab_colsum(ops, dev):

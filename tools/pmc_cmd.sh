@@ -16,7 +16,19 @@ for f in sorted(glob.glob("gpurun_out/pmc_%s/*counter_collection.csv" % os.envir
         if sub not in r["Kernel_Name"]: continue
         k = r["Kernel_Name"].split("(")[0][-40:]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
-for k, d in agg.items():
-    print(k)
-    for c, v in sorted(d.items()): print("    %-28s %14.0f per launch" % (c, v / cnt[(k, c)]))
+if os.environ.get("COMPACT"):
+    print("%-40s %9s %7s %7s %7s %7s %7s" % ("kernel", "wave-cyc", "active", "valu", "lds", "wait", "w-inst"))
+    rows = []
+    for k, d in agg.items():
+        g = lambda c: d.get(c, 0.0) / max(cnt[(k, c)], 1)
+        wc = g("SQ_WAVE_CYCLES")
+        if wc <= 0: continue
+        rows.append((wc * cnt[(k, "SQ_WAVE_CYCLES")], k, wc, g("SQ_ACTIVE_INST_ANY") / wc, g("SQ_ACTIVE_INST_VALU") / wc, g("SQ_ACTIVE_INST_LDS") / wc,
+                     g("SQ_WAIT_ANY") / wc, g("SQ_WAIT_INST_ANY") / wc))
+    for r in sorted(rows, reverse=True)[:40]:
+        print("%-40s %9.0f %7.2f %7.2f %7.2f %7.2f %7.2f" % r[1:])
+else:
+    for k, d in agg.items():
+        print(k)
+        for c, v in sorted(d.items()): print("    %-28s %14.0f per launch" % (c, v / cnt[(k, c)]))
 PY

@@ -46,7 +46,7 @@ SIGNATURES = {
     "vptr_gemm_tile_cols": [I],
     "vptr_gemm_grouped": [ctypes.POINTER(GemmDesc), P, P, I, I, P],
     "vptr_layernorm_fwd": [P, P, P, P, P, P, I, I, P, P, I, I, F, P],
-    "vptr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, I, P],
+    "vptr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, I, P, P],
     "vptr_rowmod_sum": [P, P, I, I, I, I, P],
     "vptr_colsum": [P, P, I, I, P],
     "vptr_window_copy": [P, P, I, I, I, I, I, I, I, I, P],

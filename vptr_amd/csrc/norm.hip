@@ -72,7 +72,8 @@ extern "C" int vptr_layernorm_fwd(const float* x, const float* gamma, const floa
 __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ dy2,
                                                         const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                        float* __restrict__ dx, int rows, int C) {
+                                                        float* __restrict__ dx, int rows, int C,
+                                                        const float* __restrict__ dx_add) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict_
     float g = dy[off + i];
     if (dy2) g += dy2[off + i];
     const float xh = (x[off + i] - mu) * rs;
-    dx[off + i] = rs * (g * gamma[i] - s1 - xh * s2);
+    dx[off + i] = rs * (g * gamma[i] - s1 - xh * s2) + (dx_add ? dx_add[off + i] : 0.f);
   }
 }
 
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
                                                            const float* __restrict__ x_, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            float* __restrict__ dx_, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int rows, int C, int rpb) {
+                                                           float* __restrict__ dbeta, int rows, int C, int rpb,
+                                                           const float* __restrict__ dx_add_) {
   __shared__ float4 red[4][2][NC4 * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int C4 = C >> 2;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
     const float4* x = reinterpret_cast<const float4*>(x_) + (int64_t)row * C4;
     float4* dx = reinterpret_cast<float4*>(dx_) + (int64_t)row * C4;
     const float mu = mean[row], rs = rstd[row];
-    float4 g[NC4], xh[NC4];
+    float4 g[NC4], xh[NC4], ra[NC4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int k = 0; k < NC4; ++k) {
@@ -151,6 +153,8 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
       const float m = i < C4 ? 1.f : 0.f;
       const int ic = min(i, C4 - 1);
       float4 gv = dy[ic];
+      ra[k] = z;
+      if (dx_add_) ra[k] = reinterpret_cast<const float4*>(dx_add_)[(int64_t)row * C4 + ic];
       if (dy2_) {
         const float4 g2 = reinterpret_cast<const float4*>(dy2_)[(int64_t)row * C4 + ic];
         gv.x += g2.x; gv.y += g2.y; gv.z += g2.z; gv.w += g2.w;
@@ -168,8 +172,8 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
     for (int k = 0; k < NC4; ++k) {
       const int i = lane + 64 * k;
       if (i < C4)
-        dx[i] = make_float4(rs * (g[k].x * gam[k].x - s1 - xh[k].x * s2), rs * (g[k].y * gam[k].y - s1 - xh[k].y * s2),
-                            rs * (g[k].z * gam[k].z - s1 - xh[k].z * s2), rs * (g[k].w * gam[k].w - s1 - xh[k].w * s2));
+        dx[i] = make_float4(rs * (g[k].x * gam[k].x - s1 - xh[k].x * s2) + ra[k].x, rs * (g[k].y * gam[k].y - s1 - xh[k].y * s2) + ra[k].y,
+                            rs * (g[k].z * gam[k].z - s1 - xh[k].z * s2) + ra[k].z, rs * (g[k].w * gam[k].w - s1 - xh[k].w * s2) + ra[k].w);
       ag[k].x += g[k].x * xh[k].x; ag[k].y += g[k].y * xh[k].y; ag[k].z += g[k].z * xh[k].z; ag[k].w += g[k].w * xh[k].w;
       ab[k].x += g[k].x; ab[k].y += g[k].y; ab[k].z += g[k].z; ab[k].w += g[k].w;
     }
@@ -190,19 +194,19 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
 
 extern "C" int vptr_layernorm_bwd(const float* dy, const float* dy2, const float* x, const float* gamma, const float* mean,
                                   const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int C,
-                                  vptr_stream_t stream) {
+                                  const float* dx_add, vptr_stream_t stream) {
   VPTR_CHECK(rows > 0 && C > 0, "layernorm_bwd: empty input");
   hipStream_t st = (hipStream_t)stream;
   if (dx && dgamma && dbeta && C % 4 == 0 && C <= 1024) {
     const int rpb = rows >= 4096 ? 32 : 4;  // fewer, longer workgroups: the per-column atomics at the end contend across workgroups
     const int nb = cdiv(rows, rpb);
-    if (C <= 256) ln_bwd_fused_kernel<1><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb);
-    else if (C <= 768) ln_bwd_fused_kernel<3><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb);
-    else ln_bwd_fused_kernel<4><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb);
+    if (C <= 256) ln_bwd_fused_kernel<1><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb, dx_add);
+    else if (C <= 768) ln_bwd_fused_kernel<3><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb, dx_add);
+    else ln_bwd_fused_kernel<4><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb, dx_add);
     VPTR_LAUNCH_CHECK();
     return 0;
   }
-  if (dx) ln_bwd_dx_kernel<<<cdiv(rows, 4), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, rows, C);
+  if (dx) ln_bwd_dx_kernel<<<cdiv(rows, 4), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, rows, C, dx_add);
   if (dgamma && dbeta) {
     const int rpb = 64;
     dim3 grid(cdiv(C, 256), cdiv(rows, rpb));

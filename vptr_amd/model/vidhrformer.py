@@ -291,17 +291,20 @@ class VidHRFormerBlockEnc(nn.Module):
         s = self._site
         dp = _droppath_scale(self.drop_path_p, self.training, g.N, x.device)
         per_n = g.T * HW
-        u = ops.layernorm(x, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps)
-        x = self.SLMHSA.forward_tokens(u, u, x, g, lw_pos, s + 0, rowscale=dp, rs_div=per_n, rs_mod=g.N)
+        # every pre-norm LayerNorm also returns its input as a pass-through output xr, used as the sub-layer's residual: the
+        # residual gradient then comes back through the LayerNorm node and is added inside its backward kernel
+        u, xr = ops.layernorm(x, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps, passthrough=True)
+        x = self.SLMHSA.forward_tokens(u, u, xr, g, lw_pos, s + 0, rowscale=dp, rs_div=per_n, rs_mod=g.N)
         dp = _droppath_scale(self.drop_path_p, self.training, g.N, x.device)
-        u = ops.layernorm(x, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps)
-        x = self.SpatialFFN.forward_tokens(u, x, g, s + 1, rowscale=dp, rs_div=per_n, rs_mod=g.N)
-        u, uq = ops.layernorm(x, self.norm3.weight, self.norm3.bias, tab=tpos, tab_div=HW, tab_mod=g.T, eps=self.norm3.eps)
-        x = _mha_tokens(self.temporal_MHSA, uq, uq, u, x, g.N, g.T, g.T, HW, self.far, p, s + 3, out_dropout=p, out_site=s + 4,
+        u, xr = ops.layernorm(x, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps, passthrough=True)
+        x = self.SpatialFFN.forward_tokens(u, xr, g, s + 1, rowscale=dp, rs_div=per_n, rs_mod=g.N)
+        u, uq, xr = ops.layernorm(x, self.norm3.weight, self.norm3.bias, tab=tpos, tab_div=HW, tab_mod=g.T, eps=self.norm3.eps,
+                                  passthrough=True)
+        x = _mha_tokens(self.temporal_MHSA, uq, uq, u, xr, g.N, g.T, g.T, HW, self.far, p, s + 3, out_dropout=p, out_site=s + 4,
                         merge_v_grad=not tpos.requires_grad)
-        u = ops.layernorm(x, self.norm4.weight, self.norm4.bias, eps=self.norm4.eps)
+        u, xr = ops.layernorm(x, self.norm4.weight, self.norm4.bias, eps=self.norm4.eps, passthrough=True)
         h = ops.linear(u, self.linear1.weight, self.linear1.bias, act=ops.ACT_GELU, dropout_p=p, site=s + 5)
-        return ops.linear(h, self.linear2.weight, self.linear2.bias, residual=x, dropout_p=p, site=s + 6)
+        return ops.linear(h, self.linear2.weight, self.linear2.bias, residual=xr, dropout_p=p, site=s + 6)
 
 
 class VidHRFormerEncoder(nn.Module):
@@ -364,32 +367,36 @@ class VidHRFormerBlockDecNAR(nn.Module):
         s = self._site
         per_n = T2 * HW
         dp = _droppath_scale(self.drop_path_p, self.training, g.N, tgt.device)
-        t, tq = ops.layernorm(tgt, self.norm1.weight, self.norm1.bias, tab=qpos_tab, tab_div=1, tab_mod=per_n, eps=self.norm1.eps)
-        x = self.SLMHSA.forward_tokens(tq, t, tgt, g, lw_pos, s + 0, rowscale=dp, rs_div=per_n, rs_mod=g.N)
+        # (pass-through outputs xr: see VidHRFormerBlockEnc.forward_tokens)
+        t, tq, xr = ops.layernorm(tgt, self.norm1.weight, self.norm1.bias, tab=qpos_tab, tab_div=1, tab_mod=per_n, eps=self.norm1.eps,
+                                  passthrough=True)
+        x = self.SLMHSA.forward_tokens(tq, t, xr, g, lw_pos, s + 0, rowscale=dp, rs_div=per_n, rs_mod=g.N)
         dp = _droppath_scale(self.drop_path_p, self.training, g.N, tgt.device)
-        u = ops.layernorm(x, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps)
-        x = self.SpatialFFN.forward_tokens(u, x, g, s + 1, rowscale=dp, rs_div=per_n, rs_mod=g.N)
-        u, uq = ops.layernorm(x, self.norm3.weight, self.norm3.bias, tab=tpos_f, tab_div=HW, tab_mod=T2, eps=self.norm3.eps)
-        x = _mha_tokens(self.temporal_MHSA, uq, uq, u, x, g.N, T2, T2, HW, False, p, s + 3, out_dropout=p, out_site=s + 4,
+        u, xr = ops.layernorm(x, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps, passthrough=True)
+        x = self.SpatialFFN.forward_tokens(u, xr, g, s + 1, rowscale=dp, rs_div=per_n, rs_mod=g.N)
+        u, uq, xr = ops.layernorm(x, self.norm3.weight, self.norm3.bias, tab=tpos_f, tab_div=HW, tab_mod=T2, eps=self.norm3.eps,
+                                  passthrough=True)
+        x = _mha_tokens(self.temporal_MHSA, uq, uq, u, xr, g.N, T2, T2, HW, False, p, s + 3, out_dropout=p, out_site=s + 4,
                         merge_v_grad=not tpos_f.requires_grad)
-        u = ops.layernorm(x, self.norm4.weight, self.norm4.bias, eps=self.norm4.eps)
+        u, xr = ops.layernorm(x, self.norm4.weight, self.norm4.bias, eps=self.norm4.eps, passthrough=True)
         h = ops.linear(u, self.linear1.weight, self.linear1.bias, act=ops.ACT_GELU, dropout_p=p, site=s + 5)
-        x = ops.linear(h, self.linear2.weight, self.linear2.bias, residual=x, dropout_p=p, site=s + 6)
+        x = ops.linear(h, self.linear2.weight, self.linear2.bias, residual=xr, dropout_p=p, site=s + 6)
         # encoder-decoder attention; the reference applies drop_path1 to a (T2, N*HW, C) tensor, i.e. along TIME
         # (VidHRFormer_modules.py:204) -- reproduced: scale indexed by t = (row // HW) % T2
         if self.TSLMA_flag:
             # temporal-spatial window cross-attention (VidHRFormer_modules.py:195-199); here drop_path1 sees (N,T2,H,W,C): per sample
             dp = _droppath_scale(self.drop_path_p, self.training, g.N, tgt.device)
-            _, uq = ops.layernorm(x, self.norm5.weight, self.norm5.bias, tab=qpos_tab, tab_div=1, tab_mod=per_n, eps=self.norm5.eps)
-            x = self.TSLMA.forward_tokens(mem, uq, x, g, T1, Tlw_pos, s + 7, rowscale=dp, rs_div=per_n, rs_mod=g.N)
+            _, uq, xr = ops.layernorm(x, self.norm5.weight, self.norm5.bias, tab=qpos_tab, tab_div=1, tab_mod=per_n, eps=self.norm5.eps,
+                                      passthrough=True)
+            x = self.TSLMA.forward_tokens(mem, uq, xr, g, T1, Tlw_pos, s + 7, rowscale=dp, rs_div=per_n, rs_mod=g.N)
         else:
             dpt = _droppath_scale(self.drop_path_p, self.training, T2, tgt.device)
-            _, uq = ops.layernorm(x, self.norm5.weight, self.norm5.bias, tab=qpos_tpos_tab, tab_div=1, tab_mod=per_n,
-                                  eps=self.norm5.eps)
-            x = _mha_tokens(self.EncDecAttn, uq, mem_k, mem, x, g.N, T2, T1, HW, False, p, s + 7, rowscale=dpt, rs_div=HW, rs_mod=T2)
+            _, uq, xr = ops.layernorm(x, self.norm5.weight, self.norm5.bias, tab=qpos_tpos_tab, tab_div=1, tab_mod=per_n,
+                                      eps=self.norm5.eps, passthrough=True)
+            x = _mha_tokens(self.EncDecAttn, uq, mem_k, mem, xr, g.N, T2, T1, HW, False, p, s + 7, rowscale=dpt, rs_div=HW, rs_mod=T2)
         dp = _droppath_scale(self.drop_path_p, self.training, g.N, tgt.device)
-        u = ops.layernorm(x, self.norm6.weight, self.norm6.bias, eps=self.norm6.eps)
-        return self.SpatialFFN1.forward_tokens(u, x, g, s + 8, rowscale=dp, rs_div=per_n, rs_mod=g.N)
+        u, xr = ops.layernorm(x, self.norm6.weight, self.norm6.bias, eps=self.norm6.eps, passthrough=True)
+        return self.SpatialFFN1.forward_tokens(u, xr, g, s + 8, rowscale=dp, rs_div=per_n, rs_mod=g.N)
 
 
 class VidHRformerDecoderNAR(nn.Module):

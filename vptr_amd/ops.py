@@ -434,8 +434,12 @@ def linear(x, W, b=None, residual=None, alpha=1.0, act=ACT_NONE, rowscale=None, 
 # LayerNorm(C) (+ fused positional add)
 # ------------------------------------------------------------------------------------------------------------------
 class _LayerNormFn(torch.autograd.Function):
+    """y = LN(x) [, y2 = y + tab[...]] [, xr = x].  The pass-through output xr is x itself: a sub-layer that uses it as its
+    residual sends the residual gradient back through THIS node, where it is added inside the LayerNorm-backward kernel
+    (dx_add) instead of by an autograd accumulation pass."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, tab, tab_div, tab_mod, eps):
+    def forward(ctx, x, gamma, beta, tab, tab_div, tab_mod, eps, passthrough):
         _lib.require_cuda(x)
         ctx.set_materialize_grads(False)  # an unused output (e.g. y when only y + tab is consumed) arrives as None, not zeros
         x = _c(x)
@@ -450,19 +454,26 @@ class _LayerNormFn(torch.autograd.Function):
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.beta_ref = beta.detach()
         ctx.tab = (tab is not None, tab_div, tab_mod, tuple(tab.shape) if tab is not None else None)
-        if tab is None:
-            return y
-        return y, y2
+        ctx.passthrough = passthrough
+        outs = (y,) if tab is None else (y, y2)
+        if passthrough:
+            outs = outs + (x,)   # an input returned as-is: autograd makes it an identity output of this node
+        return outs[0] if len(outs) == 1 else outs
 
     @staticmethod
-    def backward(ctx, dy, dy2=None):
+    def backward(ctx, *grads):
         x, gamma, mean, rstd = ctx.saved_tensors
         has_tab, tab_div, tab_mod, tab_shape = ctx.tab
         rows, C = x.shape
+        grads = list(grads)
+        dres = grads.pop() if ctx.passthrough else None
+        dy = grads[0]
+        dy2 = grads[1] if has_tab else None
         dy2 = _c(dy2) if dy2 is not None else None
+        dres = _c(dres) if dres is not None else None
         if dy is None:  # only the position-added output was consumed
             if dy2 is None:
-                return (None,) * 7
+                return (dres,) + (None,) * 7
             k1, k2 = dy2, None
         else:
             k1, k2 = _c(dy), dy2
@@ -472,7 +483,7 @@ class _LayerNormFn(torch.autograd.Function):
         dgamma = sg if in_slab else torch.zeros_like(gamma)
         dbeta = sb if in_slab else torch.zeros_like(gamma)
         check(lib.vptr_layernorm_bwd(ptr(k1), ptr(k2), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma),
-                                     ptr(dbeta), rows, C, stream()), "vptr_layernorm_bwd")
+                                     ptr(dbeta), rows, C, ptr(dres), stream()), "vptr_layernorm_bwd")
         if in_slab:
             dgamma = dbeta = None
         dtab = None
@@ -480,12 +491,13 @@ class _LayerNormFn(torch.autograd.Function):
             dtab = torch.zeros((tab_mod, C), device=x.device, dtype=torch.float32)
             check(lib.vptr_rowmod_sum(ptr(dy2), ptr(dtab), rows, C, tab_div, tab_mod, stream()), "vptr_rowmod_sum")
             dtab = dtab.reshape(tab_shape)
-        return dx, dgamma, dbeta, dtab, None, None, None
+        return dx, dgamma, dbeta, dtab, None, None, None, None
 
 
-def layernorm(x, gamma, beta, tab=None, tab_div=1, tab_mod=1, eps=1e-5):
-    """y = LN(x) [, y2 = y + tab[(row // tab_div) % tab_mod]]; x [rows, C]; tab [tab_mod, C]."""
-    return _LayerNormFn.apply(x, gamma, beta, tab, int(tab_div), int(tab_mod), float(eps))
+def layernorm(x, gamma, beta, tab=None, tab_div=1, tab_mod=1, eps=1e-5, passthrough=False):
+    """y = LN(x) [, y2 = y + tab[(row // tab_div) % tab_mod]] [, xr]; x [rows, C]; tab [tab_mod, C].
+    passthrough=True appends xr (= x, for use as the residual of the sub-layer this LayerNorm feeds; see _LayerNormFn)."""
+    return _LayerNormFn.apply(x, gamma, beta, tab, int(tab_div), int(tab_mod), float(eps), bool(passthrough))
 
 
 class _AddRowTabFn(torch.autograd.Function):
