@@ -736,7 +736,10 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc 
   }
 
   const bool use_atomic = p.atomic || (!batched && nblk > tiles);
-  if (epi_rows && epi_vec_ok(p)) gemm_epilogue_rows_halves<NFN>(p, mb, acc, reinterpret_cast<float*>(sraw), m0, n0, wm, wn, lr, lq, tid, split == 0, use_atomic);
+  // (176-wide tiles only: with 64 / 128-wide tiles -- the auto-encoder's convs, M up to 655 360 -- the LDS round trip and its
+  // barriers cost more than the short rows gain: stage-1 step 32.8 -> 35.3 ms; and no atomic accumulation: float atomics
+  // stay scalar, so the round trip buys nothing)
+  if (NFN == 11 && epi_rows && !use_atomic && epi_vec_ok(p)) gemm_epilogue_rows_halves<NFN>(p, mb, acc, reinterpret_cast<float*>(sraw), m0, n0, wm, wn, lr, lq, tid, split == 0, use_atomic);
   else gemm_epilogue_serial<NFN>(p, mb, acc, m0, n0, wm, wn, lr, lq, split == 0, use_atomic);
   TS(5)
   TS_FLUSH
@@ -860,7 +863,7 @@ __device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, const Membe
       TS(2)
     }
   }
-  if (epi_rows && epi_vec_ok(p)) gemm_epilogue_rows<NFN>(p, mb, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, lr, lq, tid, first_split, use_atomic);
+  if (epi_rows && !use_atomic && epi_vec_ok(p)) gemm_epilogue_rows<NFN>(p, mb, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, lr, lq, tid, first_split, use_atomic);
   else gemm_epilogue<NFN, 1>(p, mb, acc, m0, n0, wm, wn, lr, lq, first_split, use_atomic);
   if constexpr (AMODE == VPTR_A_KSTRIDED) {
     if (p.a_rowsum && n0 == 0) {  // workgroup-uniform: column tile 0 owns the row sums of its A panel
