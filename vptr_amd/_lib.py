@@ -117,7 +117,8 @@ def ptr(t):
 
 
 def stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw handle of the current stream (torch.cuda.current_stream() builds a Stream object: ~9 us per launch, ~1.1 k launches/step)
+    return c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def require_cuda(*tensors):

@@ -30,11 +30,15 @@ class _DropPathPlan:
 
     def __init__(self):
         self.plan, self.rec, self.idx, self.scales = None, [], 0, None
+        self._keep = None  # (plan, device) -> device tensor of keep probabilities: built once, not per forward (a host->device copy)
 
     def begin(self, device):
         self.rec, self.idx, self.scales = [], 0, None
         if self.plan:
-            keep = torch.tensor([1.0 - p for p, _ in self.plan], device=device, dtype=torch.float32)[:, None]
+            if self._keep is None or self._keep[0] != self.plan or self._keep[1] != device:
+                self._keep = (list(self.plan), device,
+                              torch.tensor([1.0 - p for p, _ in self.plan], device=device, dtype=torch.float32)[:, None])
+            keep = self._keep[2]
             u = torch.rand((len(self.plan), max(c for _, c in self.plan)), device=device, dtype=torch.float32)
             self.scales = torch.floor(u + keep) / keep
 

@@ -187,7 +187,8 @@ class NARTrainer:
 
     def _disc_update(self, fake, real):
         """cal_lossD + optimizer_D.step(), then freeze the discriminator for the generator pass"""
-        self.disc.train()
+        if not self.disc.training:
+            self.disc.train()
         for p in self.disc.parameters():
             p.requires_grad_(True)
         self.opt_D.zero_grad()
@@ -257,7 +258,8 @@ class NARTrainer:
                 past_feats, future_feats = feats[:, :past.shape[1]], feats[:, past.shape[1]:]
             else:
                 past_feats, future_feats = self.enc(past), self.enc(future)
-        self.T.train()
+        if not self.T.training:   # nn.Module.train() walks ~500 sub-modules: ~5 ms of host time per step
+            self.T.train()
         self.opt.zero_grad()
         if self.dec_weight_grads:
             self.dec.zero_grad(set_to_none=True)  # train_NAR.py:61
@@ -341,7 +343,8 @@ class FARTrainer(NARTrainer):
     def _step_impl(self, past, future):
         with torch.no_grad():
             gt_feats = self.enc(torch.cat([past, future[:, :-1]], dim=1))    # train_FAR.py:53-55
-        self.T.train()
+        if not self.T.training:   # nn.Module.train() walks ~500 sub-modules: ~5 ms of host time per step
+            self.T.train()
         self.opt.zero_grad()
         if self.dec_weight_grads:
             self.dec.zero_grad(set_to_none=True)
@@ -388,12 +391,15 @@ class AETrainer:
 
     def step(self, past, future):
         x = torch.cat([past, future], dim=1)
-        self.enc.train()
-        self.dec.train()
+        if not self.enc.training:
+            self.enc.train()
+        if not self.dec.training:
+            self.dec.train()
         self.opt_G.zero_grad()
         rec = self.dec(self.enc(x))
         # ---- discriminator (cal_lossD, :20-29)
-        self.disc.train()
+        if not self.disc.training:
+            self.disc.train()
         for p in self.disc.parameters():
             p.requires_grad_(True)
         self.opt_D.zero_grad()
