@@ -135,6 +135,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_planes(const __bf16* __restrict__ 
 }
 
 // Variant 3: two stages (80 KB), 104 VGPRs -> TWO workgroups per CU (4 waves per SIMD) covering each other's barrier / DMA phases
+template <int ELIM>  // 0 full, 1 no DMA after the first step, 2 no MFMA, 3 fragments read once
 __global__ __launch_bounds__(NT, 4) void gemm_planes_2cu(const __bf16* __restrict__ Ah, const __bf16* __restrict__ Al,
                                                      const __bf16* __restrict__ Bh, const __bf16* __restrict__ Bl,
                                                      float* __restrict__ D, int M, int N, int K) {
@@ -189,28 +190,46 @@ __global__ __launch_bounds__(NT, 4) void gemm_planes_2cu(const __bf16* __restric
 #pragma unroll
   for (int ni = 0; ni < 6; ++ni) offB[ni] = lds_off((wn * 6 + ni) * 16 + lr, lq);
 
+  bf16x8 kah[2], kal[2], kbh[6], kbl[6];
   issue(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0): step kt has landed
     __syncthreads();
-    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < nk && (ELIM != 1 || kt < 1)) issue(kt + 1, (kt + 1) & 1);
     const __bf16* st = reinterpret_cast<const __bf16*>(smem + (kt & 1) * STAGE_B);
     const __bf16 *sAh = st, *sAl = st + A_B / 2, *sBh = st + A_B, *sBl = st + A_B + B_B / 2;
+    if (ELIM == 3 && kt > 0) {  // fragments stay from step 0: MFMA + DMA + barrier only
+#pragma unroll
+      for (int ni = 0; ni < 6; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kal[mi], kbh[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kah[mi], kbl[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kah[mi], kbh[ni], acc[mi][ni], 0, 0, 0);
+        }
+      continue;
+    }
     bf16x8 ah[2], al[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       ah[mi] = *reinterpret_cast<const bf16x8*>(&sAh[offA[mi]]);
       al[mi] = *reinterpret_cast<const bf16x8*>(&sAl[offA[mi]]);
+      if (ELIM == 3) { kah[mi] = ah[mi]; kal[mi] = al[mi]; }
     }
 #pragma unroll
     for (int ni = 0; ni < 6; ++ni) {
       const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&sBh[offB[ni]]);
       const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&sBl[offB[ni]]);
+      if (ELIM == 3) { kbh[ni] = bh; kbl[ni] = bl; }
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+        if (ELIM == 2) {  // no MFMA: fold the fragments into the accumulators with one cheap VALU op each
+          acc[mi][ni][0] += (float)al[mi][0] + (float)bh[0] + (float)ah[mi][1] + (float)bl[1];
+        } else {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+        }
       }
     }
   }
@@ -399,6 +418,11 @@ int main(int argc, char** argv) {
   if (run("builtin", gemm_planes<false>, 3, Ah, Al, Bh, Bl, D, M, N, K, hA, hB)) return 1;
   if (run("asm", gemm_planes<true>, 3, Ah, Al, Bh, Bl, D, M, N, K, hA, hB)) return 1;
   if (run("asm+fp", gemm_planes_fp, 3, Ah, Al, Bh, Bl, D, M, N, K, hA, hB)) return 1;
-  if (run("2 wg/CU", gemm_planes_2cu, 2, Ah, Al, Bh, Bl, D, M, N, K, hA, hB)) return 1;
+  if (run("2 wg/CU", gemm_planes_2cu<0>, 2, Ah, Al, Bh, Bl, D, M, N, K, hA, hB)) return 1;
+  if (getenv("ELIM")) {  // elimination runs (results are wrong by construction)
+    if (run("  no DMA", gemm_planes_2cu<1>, 2, Ah, Al, Bh, Bl, D, M, N, K, hA, hB)) return 1;
+    if (run("  no MFMA", gemm_planes_2cu<2>, 2, Ah, Al, Bh, Bl, D, M, N, K, hA, hB)) return 1;
+    if (run("  no reads", gemm_planes_2cu<3>, 2, Ah, Al, Bh, Bl, D, M, N, K, hA, hB)) return 1;
+  }
   return 0;
 }
