@@ -195,18 +195,30 @@ __global__ __launch_bounds__(NT, 4) void gemm_planes_2cu(const __bf16* __restric
   for (int kt = 0; kt < nk; ++kt) {
     __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0): step kt has landed
     __syncthreads();
-    if (kt + 1 < nk && (ELIM != 1 || kt < 1)) issue(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < nk && ((ELIM != 1 && ELIM != 4 && ELIM != 5) || kt < 1)) issue(kt + 1, (kt + 1) & 1);
     const __bf16* st = reinterpret_cast<const __bf16*>(smem + (kt & 1) * STAGE_B);
     const __bf16 *sAh = st, *sAl = st + A_B / 2, *sBh = st + A_B, *sBl = st + A_B + B_B / 2;
-    if (ELIM == 3 && kt > 0) {  // fragments stay from step 0: MFMA + DMA + barrier only
+    if ((ELIM == 3 || ELIM == 4 || ELIM == 5) && kt > 0) {  // fragments stay from step 0: MFMA + DMA + barrier only
 #pragma unroll
       for (int ni = 0; ni < 6; ++ni)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kal[mi], kbh[ni], acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kah[mi], kbl[ni], acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kah[mi], kbh[ni], acc[mi][ni], 0, 0, 0);
+          if (ELIM != 5) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kah[mi], kbl[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kah[mi], kbh[ni], acc[mi][ni], 0, 0, 0);
+          }
         }
+      if (ELIM == 5) {  // pass-major order: 12 independent MFMAs between two that touch the same accumulator
+#pragma unroll
+        for (int ni = 0; ni < 6; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kah[mi], kbl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < 6; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kah[mi], kbh[ni], acc[mi][ni], 0, 0, 0);
+      }
       continue;
     }
     bf16x8 ah[2], al[2];
@@ -214,13 +226,13 @@ __global__ __launch_bounds__(NT, 4) void gemm_planes_2cu(const __bf16* __restric
     for (int mi = 0; mi < 2; ++mi) {
       ah[mi] = *reinterpret_cast<const bf16x8*>(&sAh[offA[mi]]);
       al[mi] = *reinterpret_cast<const bf16x8*>(&sAl[offA[mi]]);
-      if (ELIM == 3) { kah[mi] = ah[mi]; kal[mi] = al[mi]; }
+      if (ELIM >= 3) { kah[mi] = ah[mi]; kal[mi] = al[mi]; }
     }
 #pragma unroll
     for (int ni = 0; ni < 6; ++ni) {
       const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&sBh[offB[ni]]);
       const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&sBl[offB[ni]]);
-      if (ELIM == 3) { kbh[ni] = bh; kbl[ni] = bl; }
+      if (ELIM >= 3) { kbh[ni] = bh; kbl[ni] = bl; }
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         if (ELIM == 2) {  // no MFMA: fold the fragments into the accumulators with one cheap VALU op each
@@ -362,6 +374,114 @@ __global__ __launch_bounds__(NT, 2) void gemm_planes_fp(const __bf16* __restrict
   }
 }
 
+// Variant 4: hi and lo interleaved per row and 32-k block -- X_il[row][k / 32][hi: 32 bf16 | lo: 32 bf16] -- so that every DMA
+// lane group fetches one FULL 128-byte line per row and K-step.  LDS image: rows of 128 bytes, 16-byte chunk c (0-3 hi, 4-7 lo)
+// of row r at physical chunk c ^ ((r >> 1) & 7): the 16 rows of a fragment read hit 16 different 16-byte bank groups.
+__global__ void split_il_kernel(const float* __restrict__ x, __bf16* __restrict__ out, int64_t rows, int K) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * K) return;
+  const int64_t r = i / K;
+  const int k = (int)(i - r * K), kb = k >> 5, kk = k & 31;
+  const float v = x[i];
+  const __bf16 h = (__bf16)v;
+  __bf16* o = out + (r * (K >> 5) + kb) * 64;
+  o[kk] = h;
+  o[32 + kk] = (__bf16)(v - (float)h);
+}
+constexpr int ILA_B = BM * 128, ILB_B = BROWS * 128, ILSTAGE_B = ILA_B + ILB_B;  // 16 KB + 24 KB
+template <int ELIM>
+__global__ __launch_bounds__(NT, 4) void gemm_planes_il(const __bf16* __restrict__ A, const __bf16* __restrict__ /*unused*/, const __bf16* __restrict__ Bm,
+                                                        const __bf16* __restrict__ /*unused*/, float* __restrict__ D, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lq = lane >> 4;
+  const int tiles_n = (N + BN - 1) / BN;
+  const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+  const int logical = xcd * xq + min(xcd, xr) + (blockIdx.x >> 3);
+  const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
+  const int nk = K / BK;
+  const int64_t pitch = (int64_t)(K >> 5) * 64;   // bf16 elements per row
+  const __bf16* src[UPW];
+  int dst[UPW];
+#pragma unroll
+  for (int i = 0; i < UPW; ++i) {
+    const int u = wave + 8 * i;                    // 40 units of 8 rows x 128 B: 16 of A, 24 of B
+    const bool isA = u < 16;
+    const int r0 = (isA ? u : u - 16) * 8;
+    const int prow = r0 + (lane >> 3), pch = lane & 7;
+    const int c = pch ^ ((prow >> 1) & 7);
+    const int grow = isA ? min(m0 + prow, M - 1) : min(n0 + prow, N - 1);
+    src[i] = (isA ? A : Bm) + (int64_t)grow * pitch + c * 8;
+    dst[i] = (isA ? 0 : ILA_B) + r0 * 128;
+  }
+  auto issue = [&](const int kt, const int stage) {
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) {
+      const __bf16* g = src[i] + (int64_t)kt * 64;
+      const uint32_t laddr = (uint32_t)(stage * ILSTAGE_B + dst[i]);
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(laddr)), "v"(g) : "memory");
+    }
+  };
+  f32x4 acc[2][6];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int offAh[2], offAl[2], offBh[6], offBl[6];   // byte offsets inside a stage
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int r = wm * 32 + mi * 16 + lr, f = (r >> 1) & 7;
+    offAh[mi] = r * 128 + ((lq ^ f) << 4);
+    offAl[mi] = r * 128 + (((4 + lq) ^ f) << 4);
+  }
+#pragma unroll
+  for (int ni = 0; ni < 6; ++ni) {
+    const int r = (wn * 6 + ni) * 16 + lr, f = (r >> 1) & 7;
+    offBh[ni] = ILA_B + r * 128 + ((lq ^ f) << 4);
+    offBl[ni] = ILA_B + r * 128 + (((4 + lq) ^ f) << 4);
+  }
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    if (kt + 1 < nk && (ELIM != 1 || kt < 1)) issue(kt + 1, (kt + 1) & 1);
+    const unsigned char* st = smem + (kt & 1) * ILSTAGE_B;
+    bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      ah[mi] = *reinterpret_cast<const bf16x8*>(st + offAh[mi]);
+      al[mi] = *reinterpret_cast<const bf16x8*>(st + offAl[mi]);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) {
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(st + offBh[ni]);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(st + offBl[ni]);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        if (ELIM == 2) {
+          acc[mi][ni][0] += (float)al[mi][0] + (float)bh[0] + (float)ah[mi][1] + (float)bl[1];
+        } else {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int ni = 0; ni < 6; ++ni) {
+    const int nf = wn * 6 + ni, col = n0 + nf * 16 + lr;
+    if (nf >= 11 || col >= N) continue;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 32 + mi * 16 + lq * 4 + r;
+        if (row < M) D[(int64_t)row * N + col] = acc[mi][ni][r];
+      }
+  }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 typedef void (*kern_t)(const __bf16*, const __bf16*, const __bf16*, const __bf16*, float*, int, int, int);
@@ -419,10 +539,24 @@ int main(int argc, char** argv) {
   if (run("asm", gemm_planes<true>, 3, Ah, Al, Bh, Bl, D, M, N, K, hA, hB)) return 1;
   if (run("asm+fp", gemm_planes_fp, 3, Ah, Al, Bh, Bl, D, M, N, K, hA, hB)) return 1;
   if (run("2 wg/CU", gemm_planes_2cu<0>, 2, Ah, Al, Bh, Bl, D, M, N, K, hA, hB)) return 1;
+  {
+    __bf16 *Ail, *Bil;
+    CK(hipMalloc(&Ail, 4 * hA.size())); CK(hipMalloc(&Bil, 4 * hB.size()));
+    split_il_kernel<<<(unsigned)((hA.size() + 255) / 256), 256>>>(dA, Ail, M, K);
+    split_il_kernel<<<(unsigned)((hB.size() + 255) / 256), 256>>>(dB, Bil, N, K);
+    CK(hipDeviceSynchronize());
+    if (run("il 2wg", gemm_planes_il<0>, 2, Ail, Ail, Bil, Bil, D, M, N, K, hA, hB)) return 1;
+    if (getenv("ELIM")) {
+      if (run("  il no DMA", gemm_planes_il<1>, 2, Ail, Ail, Bil, Bil, D, M, N, K, hA, hB)) return 1;
+      if (run("  il no MFMA", gemm_planes_il<2>, 2, Ail, Ail, Bil, Bil, D, M, N, K, hA, hB)) return 1;
+    }
+  }
   if (getenv("ELIM")) {  // elimination runs (results are wrong by construction)
     if (run("  no DMA", gemm_planes_2cu<1>, 2, Ah, Al, Bh, Bl, D, M, N, K, hA, hB)) return 1;
     if (run("  no MFMA", gemm_planes_2cu<2>, 2, Ah, Al, Bh, Bl, D, M, N, K, hA, hB)) return 1;
     if (run("  no reads", gemm_planes_2cu<3>, 2, Ah, Al, Bh, Bl, D, M, N, K, hA, hB)) return 1;
+    if (run("  MFMA only", gemm_planes_2cu<4>, 2, Ah, Al, Bh, Bl, D, M, N, K, hA, hB)) return 1;
+    if (run("  MFMA only, pass-major", gemm_planes_2cu<5>, 2, Ah, Al, Bh, Bl, D, M, N, K, hA, hB)) return 1;
   }
   return 0;
 }
