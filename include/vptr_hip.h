@@ -45,8 +45,10 @@ const char* vptr_last_error(void);
  *   v *= rowscale[(m / rs_div) % rs_mod]; dropout(p, site); v += residual[m, n]; if (act_after) v = relu(v);
  *   atomic: D[m,n] += v (split-K / gradient accumulation)  else  D[m,n] = v
  * ---------------------------------------------------------------------------------------------- */
-enum { VPTR_A_KCONTIG = 0, VPTR_A_KSTRIDED = 1, VPTR_A_CONV = 2 };
-enum { VPTR_B_KCONTIG = 0, VPTR_B_KSTRIDED = 1 };
+enum { VPTR_A_KCONTIG = 0, VPTR_A_KSTRIDED = 1, VPTR_A_CONV = 2,
+       VPTR_A_CONV_PLANES = 3 /* as VPTR_A_CONV, but A holds the NHWC input as bf16 hi / lo planes (vptr_split_planes) */ };
+enum { VPTR_B_KCONTIG = 0, VPTR_B_KSTRIDED = 1,
+       VPTR_B_PLANES = 2 /* B[n][tap][c / 32][hi 32 | lo 32] bf16: plane form of the k-contiguous conv weight */ };
 enum { VPTR_ACT_NONE = 0, VPTR_ACT_GELU = 1, VPTR_ACT_RELU = 2, VPTR_ACT_LRELU = 3 /* LeakyReLU(0.2), VPTR_modules.py:70 */ };
 enum { VPTR_PAD_ZERO = 0, VPTR_PAD_REFLECT = 1, VPTR_PAD_REPLICATE = 2 };
 
@@ -101,6 +103,13 @@ typedef struct vptr_gemm_desc {
 } vptr_gemm_desc;
 
 int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream);
+
+/* "Convert once" operand format of the a_mode = VPTR_A_CONV_PLANES path (first user: the frozen VPTREnc of the NAR / FAR
+ * steps, ResNetAutoEncoder.py:127-151 under train_NAR.py:54-56): x [rows, C] fp32 -> planes [(rows + 1), ceil(C/32), 64] bf16,
+ * block (row, cb) = hi(x[row, 32 cb .. +31]) then lo(...), channels beyond C and the extra last row zero; x = hi + lo to
+ * 2^-17 relative.  The GEMM stages such operands with global_load_lds (no conversion, no LDS stores in its main loop).
+ * planes must be 128-byte aligned. */
+int vptr_split_planes(const float* x, void* planes, int64_t rows, int C, vptr_stream_t stream);
 
 /* Column width of the output tile vptr_gemm / vptr_gemm_grouped use for an N-column problem (64, 128 or 176);
  * the row height is always 128.  Host-side helper for building vptr_gemm_grouped's tile table. */

@@ -192,6 +192,30 @@ def test_conv_gather(ops, dev, pad_mode, stride):
     assert rel(y.reshape(B, OH, OW, Cout).permute(0, 3, 1, 2), ref) < TOL3
 
 
+@pytest.mark.parametrize("pad_mode,stride,Cin,Cout", [("reflect", 1, 48, 528), ("zero", 1, 40, 100), ("zero", 2, 64, 176), ("replicate", 1, 528, 528)])
+def test_conv_planes_matches_register_staged(ops, dev, pad_mode, stride, Cin, Cout):
+    """a_mode = VPTR_A_CONV_PLANES (bf16 hi / lo plane operands staged by global_load_lds) == the fp32-staged implicit GEMM"""
+    Bf, H, W = 5, 8, 8
+    OH, OW = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    x = rn((Bf * H * W, Cin), 400).to(dev)
+    wt = rn((Cout, Cin, 3, 3), 401, (9 * Cin) ** -0.5).to(dev)
+    cs, bs = (rn((Cout,), 402).abs() + 0.5).to(dev), rn((Cout,), 403).to(dev)
+    res = rn((Bf * OH * OW, Cout), 404).to(dev)
+    ref = ops.conv_nhwc(x, ops.conv_weight_as_gemm_b(wt, False), Bf, H, W, Cin, OH, OW, 3, 3, stride, 1, pad_mode, False, Cout,
+                        colscale=cs, bias=bs, act=ops.ACT_RELU)
+    ref2 = ops.conv_nhwc(x, ops.conv_weight_as_gemm_b(wt, False), Bf, H, W, Cin, OH, OW, 3, 3, stride, 1, pad_mode, False, Cout,
+                         colscale=cs, bias=bs, residual=res, act_after=True)
+    with ops.frozen_weights(True):
+        xp, wp = ops.split_planes(x), ops.conv_weight_as_planes(wt)
+        assert xp.shape == (Bf * H * W + 1, (Cin + 31) // 32, 64) and float(xp[-1].abs().max()) == 0.0
+        rec = xp[:-1, :, :32].float() + xp[:-1, :, 32:].float()                      # hi + lo reproduces x to 2^-17
+        assert rel(rec.reshape(Bf * H * W, -1)[:, :Cin], x) < 1e-5
+        y = ops.conv_nhwc_planes(xp, wp, Bf, H, W, Cin, OH, OW, 3, 3, stride, 1, pad_mode, Cout, colscale=cs, bias=bs, act=ops.ACT_RELU)
+        y2 = ops.conv_nhwc_planes(xp, wp, Bf, H, W, Cin, OH, OW, 3, 3, stride, 1, pad_mode, Cout, colscale=cs, bias=bs, residual=res,
+                                  act_after=True)
+    assert rel(y, ref) < TOL3 and rel(y2, ref2) < TOL3
+
+
 def test_conv_transposed_gather(ops, dev):
     B, Cin, Cout, H, W = 2, 24, 20, 6, 5
     x, w = rn((B, Cin, H, W), 32), rn((Cin, Cout, 3, 3), 33, 0.1)

@@ -44,6 +44,7 @@ P, I, F, L, U = c_void_p, c_int, c_float, c_int64, c_uint32
 SIGNATURES = {
     "vptr_gemm": [ctypes.POINTER(GemmDesc), P],
     "vptr_gemm_tile_cols": [I],
+    "vptr_split_planes": [P, P, L, I, P],
     "vptr_gemm_grouped": [ctypes.POINTER(GemmDesc), P, P, I, I, P],
     "vptr_layernorm_fwd": [P, P, P, P, P, P, I, I, P, P, I, I, F, P],
     "vptr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, I, P, P],

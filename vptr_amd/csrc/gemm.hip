@@ -1019,12 +1019,201 @@ static int nfn_for(const int N) {
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// ---- convert-once path (first slice: the frozen encoder's 3x3 convolutions) ---------------------------------------------
+// Operands arrive as interleaved bf16 hi / lo planes, X[row][c / 32][hi: 32 | lo: 32] (one 128-byte line per row and 32
+// channels; channels padded to a multiple of 32 with zeros, and -- for activations -- one extra all-zero row at the end that
+// zero-padded taps point at).  They are staged with global_load_lds_dwordx4: every lane fetches the 16-byte chunk that
+// belongs at its linear LDS position (rows of 128 bytes, chunk c of row r at c ^ ((r >> 1) & 7): conflict-free fragment
+// reads), so the main loop has no VALU split and no ds_write.  Two 40 KB stages and ~110 VGPRs: two workgroups per CU.
+// tools/gemm_planes_probe.hip is the stand-alone study of this loop (1.4-1.45x the register-staged kernels).
+constexpr int PL_STAGE = (GBM + 192) * 128;          // A 16 KB + B 24 KB (192 B rows: 176 used)
+constexpr int PL_UPW = PL_STAGE / 1024 / 8;          // 1 KB DMA pieces per wave and stage: 5 (2 of A, 3 of B)
+
+__global__ void split_planes_kernel(const float* __restrict__ x, __bf16* __restrict__ out, int64_t rows, int C, int CB) {
+  // thread = (row, 32-channel block, group of 4 channels); row == rows is the all-zero row
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (rows + 1) * CB * 8) return;
+  const int j = (int)(i & 7);
+  const int64_t rb = i >> 3;
+  const int64_t r = rb / CB;
+  const int cb = (int)(rb - r * CB), c = cb * 32 + j * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (r < rows) {
+    if (c + 3 < C) {
+      const float4 t = *reinterpret_cast<const float4*>(x + r * C + c);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+      for (int e = 0; e < 4; ++e) if (c + e < C) v[e] = x[r * C + c + e];
+    }
+  }
+  uint32_t hi[2], lo[2];
+  split2(v[0], v[1], hi[0], lo[0]);
+  split2(v[2], v[3], hi[1], lo[1]);
+  __bf16* o = out + rb * 64 + j * 4;
+  *reinterpret_cast<uint2*>(o) = make_uint2(hi[0], hi[1]);
+  *reinterpret_cast<uint2*>(o + 32) = make_uint2(lo[0], lo[1]);
+}
+
+__global__ __launch_bounds__(GNT, 4) void vptr_conv_planes_kernel(const vptr_gemm_desc p) {
+  constexpr int NFN = 11, BN = 176;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char pl_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lq = lane >> 4;
+  const int logical = xcd_logical_block();
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int m0 = (logical / tiles_n) * GBM, n0 = (logical % tiles_n) * BN;
+  const int CB = (p.conv_Cin + 31) >> 5;
+  const int nk = p.conv_KH * p.conv_KW * CB;
+  const __bf16* Ail = reinterpret_cast<const __bf16*>(p.A);
+  const __bf16* Bil = reinterpret_cast<const __bf16*>(p.B);
+  const int64_t zero_pix = (int64_t)(p.M / (p.conv_OH * p.conv_OW)) * p.conv_IH * p.conv_IW;  // the appended all-zero row
+
+  // A pieces (2 per wave): 8 output pixels x 128 B each; the source pixel depends on the tap
+  int a_f[2], a_oy[2], a_ox[2], a_c[2], a_dst[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int u = wave + 8 * i, prow = u * 8 + (lane >> 3);
+    a_c[i] = (lane & 7) ^ ((prow >> 1) & 7);
+    const int gm = min(m0 + prow, p.M - 1), per = p.conv_OH * p.conv_OW;
+    a_f[i] = gm / per;
+    const int rem = gm - a_f[i] * per;
+    a_oy[i] = rem / p.conv_OW;
+    a_ox[i] = rem - a_oy[i] * p.conv_OW;
+    a_dst[i] = u * 1024;
+  }
+  // B pieces (3 per wave): 8 weight rows x 128 B
+  const __bf16* b_src[3];
+  int b_dst[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int u = wave + 8 * i, prow = u * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((prow >> 1) & 7);
+    b_src[i] = Bil + (int64_t)min(n0 + prow, p.N - 1) * nk * 64 + c * 8;
+    b_dst[i] = GBM * 128 + u * 1024;
+  }
+  const __bf16* a_src[2];   // source line of the current tap, block 0
+  auto set_tap = [&](const int tap) {
+    const int ky = tap / p.conv_KW, kx = tap - ky * p.conv_KW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int iy = StageConv::map_coord(a_oy[i], ky, p.conv_IH, p), ix = StageConv::map_coord(a_ox[i], kx, p.conv_IW, p);
+      const int64_t pix = (iy >= 0 && ix >= 0) ? ((int64_t)(a_f[i] * p.conv_IH + iy) * p.conv_IW + ix) : zero_pix;
+      a_src[i] = Ail + pix * CB * 64 + a_c[i] * 8;
+    }
+  };
+  auto issue = [&](const int kt, const int cb, const int stage) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const __bf16* g = a_src[i] + cb * 64;
+      const uint32_t laddr = (uint32_t)(stage * PL_STAGE + a_dst[i]);
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(laddr)), "v"(g) : "memory");
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const __bf16* g = b_src[i] + (int64_t)kt * 64;
+      const uint32_t laddr = (uint32_t)(stage * PL_STAGE + b_dst[i]);
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(laddr)), "v"(g) : "memory");
+    }
+  };
+
+  f32x4 acc[2][6];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int offAh[2], offAl[2], offBh[6], offBl[6];   // byte offsets of the fragments inside a stage
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int r = wm * 32 + mi * 16 + lr, f = (r >> 1) & 7;
+    offAh[mi] = r * 128 + ((lq ^ f) << 4);
+    offAl[mi] = r * 128 + (((4 + lq) ^ f) << 4);
+  }
+#pragma unroll
+  for (int ni = 0; ni < 6; ++ni) {
+    const int r = (wn * 6 + ni) * 16 + lr, f = (r >> 1) & 7;
+    offBh[ni] = GBM * 128 + r * 128 + ((lq ^ f) << 4);
+    offBl[ni] = GBM * 128 + r * 128 + (((4 + lq) ^ f) << 4);
+  }
+
+  int tap = 0, cb = 0;   // position of the NEXT step to issue
+  set_tap(0);
+  issue(0, 0, 0);
+  cb = 1;
+  if (cb == CB) { cb = 0; tap = 1; if (tap < p.conv_KH * p.conv_KW) set_tap(tap); }
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): step kt has landed (the only DMA in flight)
+    __syncthreads();                      // ... for every wave, and everyone is done reading the other stage
+    if (kt + 1 < nk) {
+      issue(kt + 1, cb, (kt + 1) & 1);
+      if (++cb == CB) { cb = 0; ++tap; if (tap < p.conv_KH * p.conv_KW) set_tap(tap); }
+    }
+    const unsigned char* st = pl_smem + (kt & 1) * PL_STAGE;
+    bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      ah[mi] = *reinterpret_cast<const bf16x8*>(st + offAh[mi]);
+      al[mi] = *reinterpret_cast<const bf16x8*>(st + offAl[mi]);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) {
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(st + offBh[ni]);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(st + offBl[ni]);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+      }
+    }
+  }
+  const Member mb = {nullptr, nullptr, p.D, p.bias, p.alpha};
+  gemm_epilogue_serial<NFN>(p, mb, acc, m0, n0, wm, wn, lr, lq, true, p.atomic != 0);
+}
+
+extern "C" int vptr_split_planes(const float* x, void* planes, int64_t rows, int C, vptr_stream_t stream) {
+  VPTR_CHECK(x && planes && rows > 0 && C > 0 && C % 4 == 0, "split_planes: bad arguments (C must be a multiple of 4)");
+  const int CB = (C + 31) / 32;
+  const int64_t n = (rows + 1) * CB * 8;
+  split_planes_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, reinterpret_cast<__bf16*>(planes), rows, C, CB);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+static int launch_conv_planes(const vptr_gemm_desc& d, hipStream_t st) {
+  VPTR_CHECK(d.b_mode == VPTR_B_PLANES && !d.conv_transposed && d.split_k <= 1 && d.precision == 3 && !d.Dpre,
+             "vptr_gemm(conv planes): needs plane weights, a forward convolution, split_k = 1, precision 3, no Dpre");
+  VPTR_CHECK((reinterpret_cast<uintptr_t>(d.A) & 127) == 0 && (reinterpret_cast<uintptr_t>(d.B) & 127) == 0,
+             "vptr_gemm(conv planes): plane buffers must be 128-byte aligned");
+  VPTR_CHECK(d.M % (d.conv_OH * d.conv_OW) == 0, "vptr_gemm(conv planes): M must be frames * OH * OW");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_conv_planes_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * PL_STAGE) != hipSuccess) {
+      vptr_set_error("vptr_gemm(conv planes): cannot reserve %d bytes of LDS", 2 * PL_STAGE);
+      return -1;
+    }
+    attr_set = true;
+  }
+  const int tiles = ((d.M + GBM - 1) / GBM) * ((d.N + 175) / 176);
+  vptr_conv_planes_kernel<<<tiles, GNT, 2 * PL_STAGE, st>>>(d);
+  return 0;
+}
+
 extern "C" int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream) {
   VPTR_CHECK(desc != nullptr, "vptr_gemm: null descriptor");
   vptr_gemm_desc d = *desc;
   VPTR_CHECK(d.M > 0 && d.N > 0 && d.K > 0, "vptr_gemm: empty problem M=%d N=%d K=%d", d.M, d.N, d.K);
   VPTR_CHECK(d.A && d.B && d.D, "vptr_gemm: null operand");
   VPTR_CHECK(d.precision == 1 || d.precision == 3, "vptr_gemm: precision must be 1 or 3 (got %d)", d.precision);
+  if (d.a_mode == VPTR_A_CONV_PLANES) {
+    if (d.alpha == 0.f) d.alpha = 1.f;
+    VPTR_CHECK(d.K == d.conv_KH * d.conv_KW * d.conv_Cin && d.conv_stride >= 1 && d.conv_OH > 0 && d.conv_OW > 0, "vptr_gemm(conv planes): bad geometry");
+    if (d.dropout_p > 0.f) VPTR_CHECK(d.seed_dev != nullptr && d.dropout_p < 1.f, "vptr_gemm: dropout needs seed_dev and p < 1");
+    const int rc = launch_conv_planes(d, reinterpret_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
   VPTR_CHECK(al16(d.A) && al16(d.B), "vptr_gemm: A and B must be 16-byte aligned");
   if (d.a_mode != VPTR_A_KSTRIDED || d.b_mode != VPTR_B_KSTRIDED)
     VPTR_CHECK(d.K % 4 == 0, "vptr_gemm: K must be a multiple of 4 for k-contiguous operands (got %d)", d.K);

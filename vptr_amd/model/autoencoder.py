@@ -12,6 +12,8 @@ stage-1 script is a 'next' row and raises NotImplementedE
 """
 import functools
 
+import os
+
 import torch
 import torch.nn as nn
 from torch.nn import init
@@ -168,11 +170,20 @@ class ResnetEncoder(nn.Module):
             h, w, cin = oh, ow, cout
             idx += 3
         pad_mode = self.padding_type
+        # frozen encoder (stage 2): activations and weights of the 18 ResnetBlock convolutions as bf16 hi / lo planes, staged
+        # by global_load_lds ("convert once"); anywhere else the register-staged fp32 path
+        planes = ops.config.weights_frozen and cin % 4 == 0 and os.environ.get("VPTR_ENC_PLANES", "1") != "0"
         for bi in range(9):
             blk = m[idx + bi]
             convs, bns = blk._layers()
             s1, b1 = _bn_eval(bns[0])
             s2, b2 = _bn_eval(bns[1])
+            if planes:
+                t = ops.conv_nhwc_planes(ops.split_planes(y), ops.conv_weight_as_planes(convs[0].weight), B, h, w, cin, h, w, 3, 3, 1, 1,
+                                         pad_mode, cin, colscale=s1, bias=b1, act=ops.ACT_RELU)
+                y = ops.conv_nhwc_planes(ops.split_planes(t), ops.conv_weight_as_planes(convs[1].weight), B, h, w, cin, h, w, 3, 3, 1, 1,
+                                         pad_mode, cin, colscale=s2, bias=b2, residual=y, act_after=(bi == 8))
+                continue
             t = ops.conv_nhwc(y, ops.conv_weight_as_gemm_b(convs[0].weight, False), B, h, w, cin, h, w, 3, 3, 1, 1, pad_mode,
                               False, cin, colscale=s1, bias=b1, act=ops.ACT_RELU)
             y = ops.conv_nhwc(t, ops.conv_weight_as_gemm_b(convs[1].weight, False), B, h, w, cin, h, w, 3, 3, 1, 1, pad_mode,

@@ -1010,6 +1010,49 @@ def conv_nhwc(x, Bmat, frames, IH, IW, Cin, OH, OW, KH, KW, stride, pad, pad_mod
     return y
 
 
+# ---- "convert once" operands (bf16 hi / lo planes) for the frozen encoder's convolutions ------------------------------------
+def split_planes(x):
+    """x [rows, C] fp32 -> planes [(rows + 1), ceil(C / 32), 64] bf16 (hi 32 | lo 32 per block; last row and pad channels zero):
+    the operand format of conv_nhwc_planes (include/vptr_hip.h, vptr_split_planes)."""
+    x = _c(x)
+    rows, C = x.shape
+    out = torch.empty((rows + 1, (C + 31) // 32, 64), device=x.device, dtype=torch.bfloat16)
+    check(lib.vptr_split_planes(ptr(x), ptr(out), rows, C, stream()), "vptr_split_planes")
+    return out
+
+
+def conv_weight_as_planes(weight):
+    """Conv2d weight [Cout, Cin, KH, KW] -> plane form B[n][tap][ceil(Cin / 32)][hi 32 | lo 32] bf16.  Only inside a
+    frozen_weights scope (the copy is cached on the parameter, keyed by version and address)."""
+    if not config.weights_frozen:
+        raise RuntimeError("conv_weight_as_planes: plane weights are only kept for frozen modules")
+    key = (weight._version, weight.data_ptr())
+    hit = getattr(weight, "_vptr_planes", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.no_grad():
+        Cout, Cin, KH, KW = weight.shape
+        CB = (Cin + 31) // 32
+        w = weight.permute(0, 2, 3, 1).reshape(Cout, KH * KW, Cin).float()
+        w = torch.nn.functional.pad(w, (0, CB * 32 - Cin)).reshape(Cout, KH * KW, CB, 32)
+        hi = w.to(torch.bfloat16)
+        lo = (w - hi.float()).to(torch.bfloat16)
+        B = torch.stack([hi, lo], dim=3).contiguous()       # [Cout, taps, CB, 2, 32]
+    setattr(weight, "_vptr_planes", (key, B))
+    return B
+
+
+def conv_nhwc_planes(x_planes, Bplanes, frames, IH, IW, Cin, OH, OW, KH, KW, stride, pad, pad_mode, Cout, colscale=None, bias=None,
+                     act=ACT_NONE, residual=None, act_after=False):
+    """conv_nhwc with both operands in plane form (x_planes from split_planes, Bplanes from conv_weight_as_planes): the GEMM
+    stages them with global_load_lds -- no fp32 -> bf16 split and no LDS stores in its main loop; fp32 output."""
+    M = frames * OH * OW
+    y = torch.empty((M, Cout), device=x_planes.device, dtype=torch.float32)
+    gemm_raw(x_planes, Bplanes, y, M, Cout, KH * KW * Cin, 3, 2, lda=0, ldb=0, colscale=colscale, bias=bias, act=act, residual=residual,
+             act_after=act_after, conv=(IH, IW, Cin, OH, OW, KH, KW, stride, pad, PAD_MODES[pad_mode], 0), precision=3)
+    return y
+
+
 # ---- trainable convolutions (stage-1 auto-encoder / PatchGAN training, train_AutoEncoder.py:44-86) -------------------------
 class _Conv2dNHWCFn(torch.autograd.Function):
     """nn.Conv2d / nn.ConvTranspose2d on NHWC token grids with full autograd, every piece an MFMA GEMM:
