@@ -46,7 +46,8 @@ const char* vptr_last_error(void);
  *   atomic: D[m,n] += v (split-K / gradient accumulation)  else  D[m,n] = v
  * ---------------------------------------------------------------------------------------------- */
 enum { VPTR_A_KCONTIG = 0, VPTR_A_KSTRIDED = 1, VPTR_A_CONV = 2,
-       VPTR_A_CONV_PLANES = 3 /* as VPTR_A_CONV, but A holds the NHWC input as bf16 hi / lo planes (vptr_split_planes) */ };
+       VPTR_A_CONV_PLANES = 3 /* as VPTR_A_CONV, but A holds the NHWC input as bf16 hi / lo planes (vptr_split_planes) */,
+       VPTR_A_PLANES = 4      /* k-contiguous A[M][K/32][hi 32 | lo 32] bf16 planes, K % 32 == 0; batch members allowed */ };
 enum { VPTR_B_KCONTIG = 0, VPTR_B_KSTRIDED = 1,
        VPTR_B_PLANES = 2 /* B[n][tap][c / 32][hi 32 | lo 32] bf16: plane form of the k-contiguous conv weight */ };
 enum { VPTR_ACT_NONE = 0, VPTR_ACT_GELU = 1, VPTR_ACT_RELU = 2, VPTR_ACT_LRELU = 3 /* LeakyReLU(0.2), VPTR_modules.py:70 */ };

@@ -1054,19 +1054,23 @@ __global__ void split_planes_kernel(const float* __restrict__ x, __bf16* __restr
   *reinterpret_cast<uint2*>(o + 32) = make_uint2(lo[0], lo[1]);
 }
 
+// CONV = false: plain k-contiguous operands A[M][K/32][64], B[N][K/32][64] (K % 32 == 0), up to three batch members.
+template <bool CONV>
 __global__ __launch_bounds__(GNT, 4) void vptr_conv_planes_kernel(const vptr_gemm_desc p) {
   constexpr int NFN = 11, BN = 176;
   extern __shared__ __attribute__((aligned(1024))) unsigned char pl_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lq = lane >> 4;
-  const int logical = xcd_logical_block();
   const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles = tiles_n * ((p.M + GBM - 1) / GBM);
+  const int grp = xcd_logical_block() / tiles, logical = xcd_logical_block() - grp * tiles;
+  const Member mb = member_of(p, (!CONV && p.batch > 1) ? grp : 0);
   const int m0 = (logical / tiles_n) * GBM, n0 = (logical % tiles_n) * BN;
-  const int CB = (p.conv_Cin + 31) >> 5;
-  const int nk = p.conv_KH * p.conv_KW * CB;
-  const __bf16* Ail = reinterpret_cast<const __bf16*>(p.A);
-  const __bf16* Bil = reinterpret_cast<const __bf16*>(p.B);
-  const int64_t zero_pix = (int64_t)(p.M / (p.conv_OH * p.conv_OW)) * p.conv_IH * p.conv_IW;  // the appended all-zero row
+  const int CB = CONV ? (p.conv_Cin + 31) >> 5 : p.K >> 5;
+  const int nk = CONV ? p.conv_KH * p.conv_KW * CB : CB;
+  const __bf16* Ail = reinterpret_cast<const __bf16*>(mb.A);
+  const __bf16* Bil = reinterpret_cast<const __bf16*>(mb.B);
+  const int64_t zero_pix = CONV ? (int64_t)(p.M / (p.conv_OH * p.conv_OW)) * p.conv_IH * p.conv_IW : 0;  // the appended all-zero row
 
   // A pieces (2 per wave): 8 output pixels x 128 B each; the source pixel depends on the tap
   int a_f[2], a_oy[2], a_ox[2], a_c[2], a_dst[2];
@@ -1074,12 +1078,15 @@ __global__ __launch_bounds__(GNT, 4) void vptr_conv_planes_kernel(const vptr_gem
   for (int i = 0; i < 2; ++i) {
     const int u = wave + 8 * i, prow = u * 8 + (lane >> 3);
     a_c[i] = (lane & 7) ^ ((prow >> 1) & 7);
-    const int gm = min(m0 + prow, p.M - 1), per = p.conv_OH * p.conv_OW;
-    a_f[i] = gm / per;
-    const int rem = gm - a_f[i] * per;
-    a_oy[i] = rem / p.conv_OW;
-    a_ox[i] = rem - a_oy[i] * p.conv_OW;
     a_dst[i] = u * 1024;
+    a_f[i] = a_oy[i] = a_ox[i] = 0;
+    if constexpr (CONV) {
+      const int gm = min(m0 + prow, p.M - 1), per = p.conv_OH * p.conv_OW;
+      a_f[i] = gm / per;
+      const int rem = gm - a_f[i] * per;
+      a_oy[i] = rem / p.conv_OW;
+      a_ox[i] = rem - a_oy[i] * p.conv_OW;
+    }
   }
   // B pieces (3 per wave): 8 weight rows x 128 B
   const __bf16* b_src[3];
@@ -1093,6 +1100,11 @@ __global__ __launch_bounds__(GNT, 4) void vptr_conv_planes_kernel(const vptr_gem
   }
   const __bf16* a_src[2];   // source line of the current tap, block 0
   auto set_tap = [&](const int tap) {
+    if constexpr (!CONV) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a_src[i] = Ail + (int64_t)min(m0 + (wave + 8 * i) * 8 + (lane >> 3), p.M - 1) * CB * 64 + a_c[i] * 8;
+      return;
+    }
     const int ky = tap / p.conv_KW, kx = tap - ky * p.conv_KW;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1139,13 +1151,14 @@ __global__ __launch_bounds__(GNT, 4) void vptr_conv_planes_kernel(const vptr_gem
   set_tap(0);
   issue(0, 0, 0);
   cb = 1;
-  if (cb == CB) { cb = 0; tap = 1; if (tap < p.conv_KH * p.conv_KW) set_tap(tap); }
+  const int ntap = CONV ? p.conv_KH * p.conv_KW : 1;
+  if (cb == CB) { cb = 0; tap = 1; if (tap < ntap) set_tap(tap); }
   for (int kt = 0; kt < nk; ++kt) {
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): step kt has landed (the only DMA in flight)
     __syncthreads();                      // ... for every wave, and everyone is done reading the other stage
     if (kt + 1 < nk) {
       issue(kt + 1, cb, (kt + 1) & 1);
-      if (++cb == CB) { cb = 0; ++tap; if (tap < p.conv_KH * p.conv_KW) set_tap(tap); }
+      if (++cb == CB) { cb = 0; ++tap; if (tap < ntap) set_tap(tap); }
     }
     const unsigned char* st = pl_smem + (kt & 1) * PL_STAGE;
     bf16x8 ah[2], al[2];
@@ -1166,8 +1179,12 @@ __global__ __launch_bounds__(GNT, 4) void vptr_conv_planes_kernel(const vptr_gem
       }
     }
   }
-  const Member mb = {nullptr, nullptr, p.D, p.bias, p.alpha};
-  gemm_epilogue_serial<NFN>(p, mb, acc, m0, n0, wm, wn, lr, lq, true, p.atomic != 0);
+  if (!p.atomic && epi_vec_ok(p)) {
+    __syncthreads();  // the last stage is still being read by slower waves
+    gemm_epilogue_rows_halves<NFN>(p, mb, acc, reinterpret_cast<float*>(pl_smem), m0, n0, wm, wn, lr, lq, tid, true, false);
+  } else {
+    gemm_epilogue_serial<NFN>(p, mb, acc, m0, n0, wm, wn, lr, lq, true, p.atomic != 0);
+  }
 }
 
 extern "C" int vptr_split_planes(const float* x, void* planes, int64_t rows, int C, vptr_stream_t stream) {
@@ -1180,22 +1197,30 @@ extern "C" int vptr_split_planes(const float* x, void* planes, int64_t rows, int
 }
 
 static int launch_conv_planes(const vptr_gemm_desc& d, hipStream_t st) {
-  VPTR_CHECK(d.b_mode == VPTR_B_PLANES && !d.conv_transposed && d.split_k <= 1 && d.precision == 3 && !d.Dpre,
-             "vptr_gemm(conv planes): needs plane weights, a forward convolution, split_k = 1, precision 3, no Dpre");
-  VPTR_CHECK((reinterpret_cast<uintptr_t>(d.A) & 127) == 0 && (reinterpret_cast<uintptr_t>(d.B) & 127) == 0,
-             "vptr_gemm(conv planes): plane buffers must be 128-byte aligned");
-  VPTR_CHECK(d.M % (d.conv_OH * d.conv_OW) == 0, "vptr_gemm(conv planes): M must be frames * OH * OW");
+  const bool conv = d.a_mode == VPTR_A_CONV_PLANES;
+  VPTR_CHECK(d.b_mode == VPTR_B_PLANES && d.split_k <= 1 && d.precision == 3 && d.ksegs <= 1,
+             "vptr_gemm(planes): needs plane weights, split_k = 1, precision 3, no K segments");
+  if (conv) VPTR_CHECK(!d.conv_transposed && !d.Dpre && d.batch <= 1 && d.M % (d.conv_OH * d.conv_OW) == 0,
+                       "vptr_gemm(conv planes): forward convolution only, M = frames * OH * OW, no Dpre / batch");
+  else VPTR_CHECK(d.K % 32 == 0, "vptr_gemm(planes): K must be a multiple of 32 (got %d)", d.K);
+  uintptr_t bits = reinterpret_cast<uintptr_t>(d.A) | reinterpret_cast<uintptr_t>(d.B);
+  if (d.batch > 1) bits |= reinterpret_cast<uintptr_t>(d.A_x1) | reinterpret_cast<uintptr_t>(d.B_x1) |
+                           (d.batch > 2 ? reinterpret_cast<uintptr_t>(d.A_x2) | reinterpret_cast<uintptr_t>(d.B_x2) : 0);
+  VPTR_CHECK((bits & 127) == 0, "vptr_gemm(planes): plane buffers must be 128-byte aligned");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_conv_planes_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_conv_planes_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * PL_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_conv_planes_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             2 * PL_STAGE) != hipSuccess) {
-      vptr_set_error("vptr_gemm(conv planes): cannot reserve %d bytes of LDS", 2 * PL_STAGE);
+      vptr_set_error("vptr_gemm(planes): cannot reserve %d bytes of LDS", 2 * PL_STAGE);
       return -1;
     }
     attr_set = true;
   }
-  const int tiles = ((d.M + GBM - 1) / GBM) * ((d.N + 175) / 176);
-  vptr_conv_planes_kernel<<<tiles, GNT, 2 * PL_STAGE, st>>>(d);
+  const int tiles = ((d.M + GBM - 1) / GBM) * ((d.N + 175) / 176) * (conv ? 1 : d.batch);
+  if (conv) vptr_conv_planes_kernel<true><<<tiles, GNT, 2 * PL_STAGE, st>>>(d);
+  else vptr_conv_planes_kernel<false><<<tiles, GNT, 2 * PL_STAGE, st>>>(d);
   return 0;
 }
 
@@ -1205,9 +1230,18 @@ extern "C" int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream) {
   VPTR_CHECK(d.M > 0 && d.N > 0 && d.K > 0, "vptr_gemm: empty problem M=%d N=%d K=%d", d.M, d.N, d.K);
   VPTR_CHECK(d.A && d.B && d.D, "vptr_gemm: null operand");
   VPTR_CHECK(d.precision == 1 || d.precision == 3, "vptr_gemm: precision must be 1 or 3 (got %d)", d.precision);
-  if (d.a_mode == VPTR_A_CONV_PLANES) {
+  if (d.a_mode == VPTR_A_CONV_PLANES || d.a_mode == VPTR_A_PLANES) {
     if (d.alpha == 0.f) d.alpha = 1.f;
-    VPTR_CHECK(d.K == d.conv_KH * d.conv_KW * d.conv_Cin && d.conv_stride >= 1 && d.conv_OH > 0 && d.conv_OW > 0, "vptr_gemm(conv planes): bad geometry");
+    if (d.batch < 1) d.batch = 1;
+    if (d.batch > 1) {
+      VPTR_CHECK(d.batch <= 3 && d.A_x1 && d.B_x1 && d.D_x1 && (d.batch < 3 || (d.A_x2 && d.B_x2 && d.D_x2)) && !d.Dpre && !d.residual && !d.atomic,
+                 "vptr_gemm(planes): bad batch members");
+      if (d.alpha_x1 == 0.f) d.alpha_x1 = 1.f;
+      if (d.alpha_x2 == 0.f) d.alpha_x2 = 1.f;
+    }
+    if (d.rowscale) VPTR_CHECK(d.rs_div >= 1 && d.rs_mod >= 1, "vptr_gemm: rowscale needs rs_div, rs_mod >= 1");
+    if (d.a_mode == VPTR_A_CONV_PLANES)
+      VPTR_CHECK(d.K == d.conv_KH * d.conv_KW * d.conv_Cin && d.conv_stride >= 1 && d.conv_OH > 0 && d.conv_OW > 0, "vptr_gemm(conv planes): bad geometry");
     if (d.dropout_p > 0.f) VPTR_CHECK(d.seed_dev != nullptr && d.dropout_p < 1.f, "vptr_gemm: dropout needs seed_dev and p < 1");
     const int rc = launch_conv_planes(d, reinterpret_cast<hipStream_t>(stream));
     if (rc) return rc;
