@@ -1056,7 +1056,7 @@ __global__ void split_planes_kernel(const float* __restrict__ x, __bf16* __restr
 
 // CONV = false: plain k-contiguous operands A[M][K/32][64], B[N][K/32][64] (K % 32 == 0), up to three batch members.
 template <bool CONV>
-__global__ __launch_bounds__(GNT, 4) void vptr_conv_planes_kernel(const vptr_gemm_desc p) {
+__global__ __launch_bounds__(GNT, 4) void vptr_conv_planes_kernel(const vptr_gemm_desc p, const int epi_rows) {
   constexpr int NFN = 11, BN = 176;
   extern __shared__ __attribute__((aligned(1024))) unsigned char pl_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(GNT, 4) void vptr_conv_planes_kernel(const vptr_gem
       }
     }
   }
-  if (!p.atomic && epi_vec_ok(p)) {
+  if (epi_rows && !p.atomic && epi_vec_ok(p)) {
     __syncthreads();  // the last stage is still being read by slower waves
     gemm_epilogue_rows_halves<NFN>(p, mb, acc, reinterpret_cast<float*>(pl_smem), m0, n0, wm, wn, lr, lq, tid, true, false);
   } else {
@@ -1219,8 +1219,8 @@ static int launch_conv_planes(const vptr_gemm_desc& d, hipStream_t st) {
     attr_set = true;
   }
   const int tiles = ((d.M + GBM - 1) / GBM) * ((d.N + 175) / 176) * (conv ? 1 : d.batch);
-  if (conv) vptr_conv_planes_kernel<true><<<tiles, GNT, 2 * PL_STAGE, st>>>(d);
-  else vptr_conv_planes_kernel<false><<<tiles, GNT, 2 * PL_STAGE, st>>>(d);
+  if (conv) vptr_conv_planes_kernel<true><<<tiles, GNT, 2 * PL_STAGE, st>>>(d, epi_rows_flag() & 2);
+  else vptr_conv_planes_kernel<false><<<tiles, GNT, 2 * PL_STAGE, st>>>(d, epi_rows_flag() & 2);
   return 0;
 }
 
