@@ -101,6 +101,10 @@ typedef struct vptr_gemm_desc {
   float *D_x1, *D_x2;
   const float *bias_x1, *bias_x2;
   float alpha_x1, alpha_x2;
+  /* plane-operand kernels only (a_mode = VPTR_A_CONV_PLANES / VPTR_A_PLANES): additionally (or, with D = NULL, instead) write
+     the result as bf16 hi / lo planes [M (+1)][ceil(N/32)][64] -- the operand format of the NEXT plane GEMM, so no
+     vptr_split_planes pass is needed in between.  Pad channels / the extra row are never written (keep the buffer zeroed). */
+  void* D_planes;
 } vptr_gemm_desc;
 
 int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream);

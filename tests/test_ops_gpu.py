@@ -234,6 +234,16 @@ def test_conv_planes_matches_register_staged(ops, dev, pad_mode, stride, Cin, Co
         y2 = ops.conv_nhwc_planes(xp, wp, Bf, H, W, Cin, OH, OW, 3, 3, stride, 1, pad_mode, Cout, colscale=cs, bias=bs, residual=res,
                                   act_after=True)
     assert rel(y, ref) < TOL3 and rel(y2, ref2) < TOL3
+    if Cout % 4 == 0:  # plane-form output written by the epilogue == a split pass over the fp32 output
+        with ops.frozen_weights(True):
+            po = torch.zeros((Bf * OH * OW + 1, (Cout + 31) // 32, 64), device=dev, dtype=torch.bfloat16)
+            y3 = ops.conv_nhwc_planes(xp, wp, Bf, H, W, Cin, OH, OW, 3, 3, stride, 1, pad_mode, Cout, colscale=cs, bias=bs, residual=res,
+                                      act_after=True, planes_out=po)
+            assert torch.equal(y3, y2) and torch.equal(po, ops.split_planes(y2))
+            po2 = torch.zeros_like(po)
+            none = ops.conv_nhwc_planes(xp, wp, Bf, H, W, Cin, OH, OW, 3, 3, stride, 1, pad_mode, Cout, colscale=cs, bias=bs, residual=res,
+                                        act_after=True, planes_out=po2, fp32_out=False)
+            assert none is None and torch.equal(po2, po)
 
 
 def test_conv_transposed_gather(ops, dev):

@@ -36,6 +36,7 @@ class GemmDesc(ctypes.Structure):
         ("batch", c_int), ("ksegs", c_int),
         ("A_x1", c_void_p), ("A_x2", c_void_p), ("B_x1", c_void_p), ("B_x2", c_void_p), ("D_x1", c_void_p), ("D_x2", c_void_p),
         ("bias_x1", c_void_p), ("bias_x2", c_void_p), ("alpha_x1", c_float), ("alpha_x2", c_float),
+        ("D_planes", c_void_p),
     ]
 
 

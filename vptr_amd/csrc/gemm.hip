@@ -559,12 +559,22 @@ __device__ __forceinline__ void gemm_epilogue_rows_halves(const vptr_gemm_desc& 
           if (p.act_after) t = t > 0.f ? t : 0.f;
           v[e] = t;
         }
-        float* dst = mb.D + (int64_t)row * p.ldd + col;
-        if (use_atomic) {
+        if (p.D_planes) {  // the consumer's operand format straight from the producer: hi | lo of this row's 32-channel block
+          uint32_t hi[2], lo[2];
+          split2(v[0], v[1], hi[0], lo[0]);
+          split2(v[2], v[3], hi[1], lo[1]);
+          __bf16* o = reinterpret_cast<__bf16*>(p.D_planes) + ((int64_t)row * ((p.N + 31) >> 5) + (col >> 5)) * 64 + (col & 31);
+          *reinterpret_cast<uint2*>(o) = make_uint2(hi[0], hi[1]);
+          *reinterpret_cast<uint2*>(o + 32) = make_uint2(lo[0], lo[1]);
+        }
+        if (mb.D) {
+          float* dst = mb.D + (int64_t)row * p.ldd + col;
+          if (use_atomic) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e, v[e]);
-        } else {
-          *reinterpret_cast<f32x4*>(dst) = v;
+            for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e, v[e]);
+          } else {
+            *reinterpret_cast<f32x4*>(dst) = v;
+          }
         }
       }
     }
@@ -1179,7 +1189,7 @@ __global__ __launch_bounds__(GNT, 4) void vptr_conv_planes_kernel(const vptr_gem
       }
     }
   }
-  if (epi_rows && !p.atomic && epi_vec_ok(p)) {
+  if ((epi_rows || p.D_planes) && !p.atomic && epi_vec_ok(p)) {
     __syncthreads();  // the last stage is still being read by slower waves
     gemm_epilogue_rows_halves<NFN>(p, mb, acc, reinterpret_cast<float*>(pl_smem), m0, n0, wm, wn, lr, lq, tid, true, false);
   } else {
@@ -1228,7 +1238,8 @@ extern "C" int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream) {
   VPTR_CHECK(desc != nullptr, "vptr_gemm: null descriptor");
   vptr_gemm_desc d = *desc;
   VPTR_CHECK(d.M > 0 && d.N > 0 && d.K > 0, "vptr_gemm: empty problem M=%d N=%d K=%d", d.M, d.N, d.K);
-  VPTR_CHECK(d.A && d.B && d.D, "vptr_gemm: null operand");
+  VPTR_CHECK(d.A && d.B && (d.D || d.D_planes), "vptr_gemm: null operand");
+  if (d.D_planes) VPTR_CHECK(d.a_mode == VPTR_A_CONV_PLANES || d.a_mode == VPTR_A_PLANES, "vptr_gemm: D_planes is an output of the plane-operand kernels only");
   VPTR_CHECK(d.precision == 1 || d.precision == 3, "vptr_gemm: precision must be 1 or 3 (got %d)", d.precision);
   if (d.a_mode == VPTR_A_CONV_PLANES || d.a_mode == VPTR_A_PLANES) {
     if (d.alpha == 0.f) d.alpha = 1.f;
@@ -1240,6 +1251,16 @@ extern "C" int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream) {
       if (d.alpha_x2 == 0.f) d.alpha_x2 = 1.f;
     }
     if (d.rowscale) VPTR_CHECK(d.rs_div >= 1 && d.rs_mod >= 1, "vptr_gemm: rowscale needs rs_div, rs_mod >= 1");
+    if (d.D_planes) {
+      vptr_gemm_desc t = d;
+      if (!t.D) t.D = reinterpret_cast<float*>(d.D_planes);   // alignment test only
+      VPTR_CHECK(!d.atomic && d.batch == 1 && (d.N & 3) == 0 && (d.ldd & 3) == 0 && (d.ldr & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(d.D_planes) | reinterpret_cast<uintptr_t>(t.D) | reinterpret_cast<uintptr_t>(d.residual) |
+                       reinterpret_cast<uintptr_t>(d.bias) | reinterpret_cast<uintptr_t>(d.colscale) | reinterpret_cast<uintptr_t>(d.Dpre)) & 15) == 0,
+                 "vptr_gemm(planes): D_planes needs the row-major epilogue (N, ldd, ldr multiples of 4, 16-byte aligned pointers, no atomics / batch)");
+    } else {
+      VPTR_CHECK(d.D != nullptr, "vptr_gemm(planes): null output");
+    }
     if (d.a_mode == VPTR_A_CONV_PLANES)
       VPTR_CHECK(d.K == d.conv_KH * d.conv_KW * d.conv_Cin && d.conv_stride >= 1 && d.conv_OH > 0 && d.conv_OW > 0, "vptr_gemm(conv planes): bad geometry");
     if (d.dropout_p > 0.f) VPTR_CHECK(d.seed_dev != nullptr && d.dropout_p < 1.f, "vptr_gemm: dropout needs seed_dev and p < 1");

@@ -179,10 +179,20 @@ class ResnetEncoder(nn.Module):
             s1, b1 = _bn_eval(bns[0])
             s2, b2 = _bn_eval(bns[1])
             if planes:
-                t = ops.conv_nhwc_planes(ops.split_planes(y), ops.conv_weight_as_planes(convs[0].weight), B, h, w, cin, h, w, 3, 3, 1, 1,
-                                         pad_mode, cin, colscale=s1, bias=b1, act=ops.ACT_RELU)
-                y = ops.conv_nhwc_planes(ops.split_planes(t), ops.conv_weight_as_planes(convs[1].weight), B, h, w, cin, h, w, 3, 3, 1, 1,
-                                         pad_mode, cin, colscale=s2, bias=b2, residual=y, act_after=(bi == 8))
+                # two persistent, zero-initialised plane buffers: the convs write their result in plane form themselves
+                # (pad channels and the all-zero row are never touched), only the very first input needs a split pass
+                if bi == 0:
+                    key = (B * h * w, cin, y.device)
+                    if getattr(self, "_plane_bufs", (None,))[0] != key:
+                        shape = (B * h * w + 1, (cin + 31) // 32, 64)
+                        self._plane_bufs = (key, torch.zeros(shape, device=y.device, dtype=torch.bfloat16),
+                                            torch.zeros(shape, device=y.device, dtype=torch.bfloat16))
+                    pa, pb = self._plane_bufs[1], self._plane_bufs[2]
+                    ops.split_planes(y, out=pa)
+                ops.conv_nhwc_planes(pa, ops.conv_weight_as_planes(convs[0].weight), B, h, w, cin, h, w, 3, 3, 1, 1, pad_mode, cin,
+                                     colscale=s1, bias=b1, act=ops.ACT_RELU, planes_out=pb, fp32_out=False)
+                y = ops.conv_nhwc_planes(pb, ops.conv_weight_as_planes(convs[1].weight), B, h, w, cin, h, w, 3, 3, 1, 1, pad_mode, cin,
+                                         colscale=s2, bias=b2, residual=y, act_after=(bi == 8), planes_out=(pa if bi < 8 else None))
                 continue
             t = ops.conv_nhwc(y, ops.conv_weight_as_gemm_b(convs[0].weight, False), B, h, w, cin, h, w, 3, 3, 1, 1, pad_mode,
                               False, cin, colscale=s1, bias=b1, act=ops.ACT_RELU)

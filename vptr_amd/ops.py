@@ -84,7 +84,8 @@ def _c(t):
 # ------------------------------------------------------------------------------------------------------------------
 def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None, colscale=None, alpha=1.0, act=ACT_NONE,
              Dpre=None, rowscale=None, rs_div=1, rs_mod=1, dropout_p=0.0, site=0, residual=None, act_after=False,
-             atomic=False, split_k=1, conv=None, precision=None, seed=None, a_rowsum=None, batch_extra=None, kseg_extra=None):
+             atomic=False, split_k=1, conv=None, precision=None, seed=None, a_rowsum=None, batch_extra=None, kseg_extra=None,
+             planes_out=None):
     """One vptr_gemm launch.  batch_extra = [(A, B, D, bias, alpha), ...] adds up to two same-shaped independent problems to
     the grid; kseg_extra = [(A, B), ...] adds up to two K-segments accumulated into the same D (include/vptr_hip.h)."""
     d = GemmDesc()
@@ -99,10 +100,11 @@ def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None
         for i, (A2, B2) in enumerate(kseg_extra, 1):
             setattr(d, "A_x%d" % i, A2.data_ptr()), setattr(d, "B_x%d" % i, B2.data_ptr())
     d.a_rowsum = ptr(a_rowsum)
+    d.D_planes = ptr(planes_out)
     d.A, d.B, d.D, d.Dpre = ptr(A), ptr(B), ptr(D), ptr(Dpre)
     d.lda = lda if lda is not None else (A.stride(0) if a_mode != 2 else 0)
     d.ldb = ldb if ldb is not None else B.stride(0)
-    d.ldd = D.stride(0)
+    d.ldd = D.stride(0) if D is not None else N
     d.M, d.N, d.K = M, N, K
     d.a_mode, d.b_mode = a_mode, b_mode
     d.precision = precision if precision is not None else config.gemm_precision
@@ -1011,12 +1013,13 @@ def conv_nhwc(x, Bmat, frames, IH, IW, Cin, OH, OW, KH, KW, stride, pad, pad_mod
 
 
 # ---- "convert once" operands (bf16 hi / lo planes) for the frozen encoder's convolutions ------------------------------------
-def split_planes(x):
+def split_planes(x, out=None):
     """x [rows, C] fp32 -> planes [(rows + 1), ceil(C / 32), 64] bf16 (hi 32 | lo 32 per block; last row and pad channels zero):
     the operand format of conv_nhwc_planes (include/vptr_hip.h, vptr_split_planes)."""
     x = _c(x)
     rows, C = x.shape
-    out = torch.empty((rows + 1, (C + 31) // 32, 64), device=x.device, dtype=torch.bfloat16)
+    if out is None:
+        out = torch.empty((rows + 1, (C + 31) // 32, 64), device=x.device, dtype=torch.bfloat16)
     check(lib.vptr_split_planes(ptr(x), ptr(out), rows, C, stream()), "vptr_split_planes")
     return out
 
@@ -1043,13 +1046,17 @@ def conv_weight_as_planes(weight):
 
 
 def conv_nhwc_planes(x_planes, Bplanes, frames, IH, IW, Cin, OH, OW, KH, KW, stride, pad, pad_mode, Cout, colscale=None, bias=None,
-                     act=ACT_NONE, residual=None, act_after=False):
+                     act=ACT_NONE, residual=None, act_after=False, planes_out=None, fp32_out=True):
     """conv_nhwc with both operands in plane form (x_planes from split_planes, Bplanes from conv_weight_as_planes): the GEMM
-    stages them with global_load_lds -- no fp32 -> bf16 split and no LDS stores in its main loop; fp32 output."""
+    stages them with global_load_lds -- no fp32 -> bf16 split and no LDS stores in its main loop.  planes_out (a ZEROED
+    [(M + 1), ceil(Cout / 32), 64] bf16 buffer, reusable) also receives the result in plane form for the next plane conv;
+    fp32_out=False then skips the fp32 copy.  Returns the fp32 output (or None)."""
     M = frames * OH * OW
-    y = torch.empty((M, Cout), device=x_planes.device, dtype=torch.float32)
+    y = torch.empty((M, Cout), device=x_planes.device, dtype=torch.float32) if fp32_out else None
+    if y is None and planes_out is None:
+        raise RuntimeError("conv_nhwc_planes: no output requested")
     gemm_raw(x_planes, Bplanes, y, M, Cout, KH * KW * Cin, 3, 2, lda=0, ldb=0, colscale=colscale, bias=bias, act=act, residual=residual,
-             act_after=act_after, conv=(IH, IW, Cin, OH, OW, KH, KW, stride, pad, PAD_MODES[pad_mode], 0), precision=3)
+             act_after=act_after, conv=(IH, IW, Cin, OH, OW, KH, KW, stride, pad, PAD_MODES[pad_mode], 0), precision=3, planes_out=planes_out)
     return y
 
 
