@@ -740,6 +740,52 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
     r1 = r2;
   }
 }
+
+// Two adjacent x columns per thread (W even): 4 column loads per row for 2 outputs instead of 6 -- the single-column version
+// is bound by the CU's vector-memory issue rate (48 us against a 35 us HBM time at the step's shape).
+struct DwRow2 { float4 c0, c1, c2, c3; };   // columns xw0-1, xw0, xw0+1, xw0+2 (out-of-range ones zeroed)
+__device__ __forceinline__ DwRow2 dw_load_row2(const float4* __restrict__ x, int64_t frame_row0, int row, int H, int xw0, int W, int F4,
+                                               int c4) {
+  const float rok = (row >= 0 && row < H) ? 1.f : 0.f;
+  const int64_t base = (frame_row0 + min(max(row, 0), H - 1)) * W;
+  DwRow2 o;
+  o.c0 = scale4(x[(base + max(xw0 - 1, 0)) * F4 + c4], xw0 > 0 ? rok : 0.f);
+  o.c1 = scale4(x[(base + xw0) * F4 + c4], rok);
+  o.c2 = scale4(x[(base + xw0 + 1) * F4 + c4], rok);
+  o.c3 = scale4(x[(base + min(xw0 + 2, W - 1)) * F4 + c4], xw0 + 2 < W ? rok : 0.f);
+  return o;
+}
+__global__ __launch_bounds__(256) void dwconv_fwd2_kernel(const float* __restrict__ x_, const float* __restrict__ w9,
+                                                          const float* __restrict__ b, float* __restrict__ y_, int frames, int H,
+                                                          int W, int F4, int flip) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int W2 = W >> 1;
+  if (idx >= (int64_t)frames * W2 * F4) return;
+  const int c4 = (int)(idx % F4);
+  const int xw0 = (int)((idx / F4) % W2) * 2;
+  const int64_t f = idx / ((int64_t)F4 * W2);
+  const float4* __restrict__ x = reinterpret_cast<const float4*>(x_);
+  float4* __restrict__ y = reinterpret_cast<float4*>(y_);
+  float4 w[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) w[t] = reinterpret_cast<const float4*>(w9)[(int64_t)(flip ? 8 - t : t) * F4 + c4];
+  const float4 bias = b ? reinterpret_cast<const float4*>(b)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  DwRow2 r0 = dw_load_row2(x, f * H, -1, H, xw0, W, F4, c4), r1 = dw_load_row2(x, f * H, 0, H, xw0, W, F4, c4);
+  for (int yh = 0; yh < H; ++yh) {
+    const DwRow2 r2 = dw_load_row2(x, f * H, yh + 1, H, xw0, W, F4, c4);
+    float4 a = bias, a2 = bias;
+    fma4(a, w[0], r0.c0); fma4(a, w[1], r0.c1); fma4(a, w[2], r0.c2);
+    fma4(a, w[3], r1.c0); fma4(a, w[4], r1.c1); fma4(a, w[5], r1.c2);
+    fma4(a, w[6], r2.c0); fma4(a, w[7], r2.c1); fma4(a, w[8], r2.c2);
+    fma4(a2, w[0], r0.c1); fma4(a2, w[1], r0.c2); fma4(a2, w[2], r0.c3);
+    fma4(a2, w[3], r1.c1); fma4(a2, w[4], r1.c2); fma4(a2, w[5], r1.c3);
+    fma4(a2, w[6], r2.c1); fma4(a2, w[7], r2.c2); fma4(a2, w[8], r2.c3);
+    y[((f * H + yh) * W + xw0) * F4 + c4] = a;
+    y[((f * H + yh) * W + xw0 + 1) * F4 + c4] = a2;
+    r0 = r1;
+    r1 = r2;
+  }
+}
 // dw9[tap, c] += sum_{f,y,x} dy[f,y,x,c] * x[f,y+ky-1,x+kx-1,c];  db[c] += sum dy.
 // Block = 32 channel quads x 8 x-lanes over a chunk of frames; every thread walks its columns with the same rolling window
 // (1 + 3 float4 loads per pixel), the 8 x-lanes are summed through LDS and each block issues 40 atomics per channel quad.
@@ -796,7 +842,10 @@ extern "C" int vptr_dwconv3x3_fwd(const float* x, const float* w9, const float* 
                                   vptr_stream_t stream) {
   VPTR_CHECK(frames > 0 && H > 0 && W > 0 && F > 0 && F % 4 == 0, "dwconv3x3_fwd: bad arguments");
   const int64_t total = (int64_t)frames * W * (F / 4);
-  dwconv_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, w9, b, y, frames, H, W, F / 4, 0);
+  if (W % 2 == 0 && total >= (1 << 16))
+    dwconv_fwd2_kernel<<<(unsigned)((total / 2 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, w9, b, y, frames, H, W, F / 4, 0);
+  else
+    dwconv_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, w9, b, y, frames, H, W, F / 4, 0);
   VPTR_LAUNCH_CHECK();
   return 0;
 }
@@ -806,7 +855,12 @@ extern "C" int vptr_dwconv3x3_bwd(const float* dy, const float* x, const float* 
   VPTR_CHECK(frames > 0 && H > 0 && W > 0 && F > 0 && F % 4 == 0, "dwconv3x3_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)frames * W * (F / 4);
-  if (dx) dwconv_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(dy, w9, nullptr, dx, frames, H, W, F / 4, 1);
+  if (dx) {
+    if (W % 2 == 0 && total >= (1 << 16))
+      dwconv_fwd2_kernel<<<(unsigned)((total / 2 + 255) / 256), 256, 0, st>>>(dy, w9, nullptr, dx, frames, H, W, F / 4, 1);
+    else
+      dwconv_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(dy, w9, nullptr, dx, frames, H, W, F / 4, 1);
+  }
   if (dw9 && db) {
     const int fpb = frames >= 64 ? 8 : 1;
     dwconv_bwd_w_kernel<<<dim3(cdiv(F / 4, DWB_C4), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
