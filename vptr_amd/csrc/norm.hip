@@ -791,6 +791,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd2_kernel(const float* __restric
 // (1 + 3 float4 loads per pixel), the 8 x-lanes are summed through LDS and each block issues 40 atomics per channel quad.
 #define DWB_C4 32
 #define DWB_XL 8
+template <bool PAIR>  // PAIR (W even): lane = (x pair, frame parity), 4 x + 2 dy loads per two pixels instead of 6 + 2
 __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restrict__ dy_, const float* __restrict__ x_,
                                                            float* __restrict__ dw9, float* __restrict__ db, int frames, int H,
                                                            int W, int F4, int fpb) {
@@ -805,6 +806,25 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restri
   float4 acc[9], ab = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (PAIR) {
+    for (int64_t f = f0 + (xl >> 2); f < f1; f += 2)
+      for (int xw0 = (xl & 3) * 2; xw0 < W; xw0 += 8) {
+        DwRow2 r0 = dw_load_row2(x, f * H, -1, H, xw0, W, F4, c4c), r1 = dw_load_row2(x, f * H, 0, H, xw0, W, F4, c4c);
+        for (int yh = 0; yh < H; ++yh) {
+          const DwRow2 r2 = dw_load_row2(x, f * H, yh + 1, H, xw0, W, F4, c4c);
+          const float4 g = dy[((f * H + yh) * W + xw0) * F4 + c4c], g2 = dy[((f * H + yh) * W + xw0 + 1) * F4 + c4c];
+          ab.x += g.x + g2.x; ab.y += g.y + g2.y; ab.z += g.z + g2.z; ab.w += g.w + g2.w;
+          fma4(acc[0], g, r0.c0); fma4(acc[1], g, r0.c1); fma4(acc[2], g, r0.c2);
+          fma4(acc[3], g, r1.c0); fma4(acc[4], g, r1.c1); fma4(acc[5], g, r1.c2);
+          fma4(acc[6], g, r2.c0); fma4(acc[7], g, r2.c1); fma4(acc[8], g, r2.c2);
+          fma4(acc[0], g2, r0.c1); fma4(acc[1], g2, r0.c2); fma4(acc[2], g2, r0.c3);
+          fma4(acc[3], g2, r1.c1); fma4(acc[4], g2, r1.c2); fma4(acc[5], g2, r1.c3);
+          fma4(acc[6], g2, r2.c1); fma4(acc[7], g2, r2.c2); fma4(acc[8], g2, r2.c3);
+          r0 = r1;
+          r1 = r2;
+        }
+      }
+  } else
   for (int64_t f = f0; f < f1; ++f)
     for (int xw = xl; xw < W; xw += DWB_XL) {
       DwRow r0 = dw_load_row(x, f * H, -1, H, xw, W, F4, c4c), r1 = dw_load_row(x, f * H, 0, H, xw, W, F4, c4c);
@@ -863,7 +883,10 @@ extern "C" int vptr_dwconv3x3_bwd(const float* dy, const float* x, const float* 
   }
   if (dw9 && db) {
     const int fpb = frames >= 64 ? 8 : 1;
-    dwconv_bwd_w_kernel<<<dim3(cdiv(F / 4, DWB_C4), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
+    if (W % 2 == 0)
+      dwconv_bwd_w_kernel<true><<<dim3(cdiv(F / 4, DWB_C4), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
+    else
+      dwconv_bwd_w_kernel<false><<<dim3(cdiv(F / 4, DWB_C4), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
   }
   VPTR_LAUNCH_CHECK();
   return 0;
