@@ -256,8 +256,9 @@ def test_conv_transposed_gather(ops, dev):
 
 
 # ----------------------------------------------------------------------------------------------------------- layernorm
-def test_layernorm_fwd_bwd(ops, dev):
-    rows, C, HW, T = 2 * 3 * 16, 48, 16, 3
+@pytest.mark.parametrize("nb,C,HW,T", [(2, 48, 16, 3), (32, 528, 48, 3), (40, 100, 40, 3)])   # small, model-sized and C % 16 != 0 rows
+def test_layernorm_fwd_bwd(ops, dev, nb, C, HW, T):
+    rows = nb * T * HW
     x, g, b, tab = rn((rows, C), 40), rn((C,), 41).abs() + 0.5, rn((C,), 42), rn((T, C), 43)
     go, go2 = rn((rows, C), 44), rn((rows, C), 45)
     xs = [t.double().clone().requires_grad_(True) for t in (x, g, b, tab)]
