@@ -206,6 +206,100 @@ def ae_case(ref, name, img_ch, feat, HW, N, T, padding_type, out_layer, seed):
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
 
 
+def ae_digest_case(ref, name, img_ch, feat, HW, N, T, padding_type, out_layer, seed):
+    """FULL-SIZE auto-encoder (feat 528) at a given image size / channel count / padding: eval forward, decoder backward.
+    Saves per-tensor norms + sampled elements (inputs are regenerated from the seeds by the test)."""
+    enc = ref.VPTREnc(img_ch, feat_dim=feat, n_downsampling=3, padding_type=padding_type)
+    dec = ref.VPTRDec(img_ch, feat_dim=feat, n_downsampling=3, out_layer=out_layer, padding_type=padding_type)
+    fill.apply_fill(enc, seed)
+    fill.apply_fill(dec, seed + 10)
+    enc.eval(), dec.eval()
+    x = fill.rand_input((N, T, img_ch, HW, HW), seed + 1, -0.25, 0.25)
+    g = fill.rand_normal((N, T, img_ch, HW, HW), seed + 2)
+    with torch.no_grad():
+        f_r = enc(x)
+    fin = f_r.clone().requires_grad_(True)
+    y_r = dec(fin)
+    (y_r * g).sum().backward()
+    dgr = {k: p.grad.clone() for k, p in dec.named_parameters()}
+    Pe, Pd = dict(enc.state_dict()), {k: v.clone() for k, v in dec.state_dict().items()}
+    for k, _ in dec.named_parameters():
+        Pd[k].requires_grad_(True)
+    with torch.no_grad():
+        f_o = O.enc_forward(Pe, x, padding_type=padding_type)
+    fo_in = f_r.clone().requires_grad_(True)
+    y_o = O.dec_forward(Pd, fo_in, out_layer=out_layer)
+    (y_o * g).sum().backward()
+    e = [rel(f_o, f_r), rel(y_o, y_r), rel(fo_in.grad, fin.grad), max(rel(Pd[k].grad, dgr[k]) for k in dgr)]
+    print(f"[{name}] fp32 oracle-vs-ref: enc {e[0]:.2e} dec {e[1]:.2e} dfeat {e[2]:.2e} dparam {e[3]:.2e}")
+    assert max(e) < 5e-5, name
+    save = {"meta": json.dumps(dict(img_ch=img_ch, feat=feat, HW=HW, N=N, T=T, padding_type=padding_type, out_layer=out_layer,
+                                    seed=seed))}
+    for tag, t in (("feat", f_r), ("y", y_r.detach()), ("dfeat", fin.grad)):
+        n, smp = fill.digest(t)
+        save[tag + "_norm"], save[tag + "_samples"] = np.array(n), smp
+    gn = {}
+    for k, v in dgr.items():
+        n, smp = fill.digest(v, count=256)
+        gn[k] = n
+        save["gsamp:" + k] = smp
+    save["grad_norms"] = json.dumps(gn)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
+
+
+def _notebook_rollouts():
+    """The reference's own test-time rollout functions, executed from where they lie: the `def`s of Test_VPTR.ipynb cell 5
+    (FAR_RIL_test_single_iter, FAR_RIP_test_single_iter, NAR_test_single_iter, NAR_BAIR_2_to_28_test_single_iter).  Nothing of
+    the notebook is copied into this repository; the fixture holds inputs and the tensors these functions returned."""
+    nb = json.load(open(os.path.join("/root/reference", "Test_VPTR.ipynb")))
+    src = [''.join(c["source"]) for c in nb["cells"] if c["cell_type"] == "code" and "def FAR_RIP_test_single_iter" in ''.join(c["source"])]
+    assert len(src) == 1
+    ns = {"torch": torch}
+    exec(compile(src[0], "Test_VPTR.ipynb:cell5", "exec"), ns)
+    return ns
+
+
+def rollout_case(ref, name, seed):
+    """Test-time rollouts by the reference's notebook functions on the reference's modules (tiny sizes)."""
+    nbf = _notebook_rollouts()
+    feat, HW, N = 48, 64, 2
+    enc = ref.VPTREnc(1, feat_dim=feat, n_downsampling=3, padding_type="reflect").eval()
+    dec = ref.VPTRDec(1, feat_dim=feat, n_downsampling=3, out_layer="Sigmoid", padding_type="reflect").eval()
+    fill.apply_fill(enc, seed)
+    fill.apply_fill(dec, seed + 1)
+    cpu = torch.device("cpu")
+    save = {"meta": json.dumps(dict(feat=feat, HW=HW, N=N, seed=seed))}
+    # FAR: Tp = 3, num_future_frames = 3, five predictions -> the window slides for i >= 3
+    cfg_far = dict(Tp=3, Tf=3, H=8, W=8, C=feat, nhead=8, window_size=4, num_encoder_layers=2, rpe=True)
+    far = build_nar(ref, cfg_far, seed + 2, far=True).eval()
+    past = fill.rand_input((N, 3, 1, HW, HW), seed + 3)
+    fut = fill.rand_input((N, 5, 1, HW, HW), seed + 4)
+    with torch.no_grad():
+        rip, _ = nbf["FAR_RIP_test_single_iter"]((past, fut), enc, dec, far, 5, cpu)
+        ril, _ = nbf["FAR_RIL_test_single_iter"]((past, fut), enc, dec, far, 5, cpu)
+    save.update(cfg_far=json.dumps(cfg_far), far_past=past.numpy(), far_rip=rip.numpy(), far_ril=ril.numpy())
+    # NAR, feature-chained rounds: Tp = Tf = 2, four predictions
+    cfg_nar = dict(Tp=2, Tf=2, H=8, W=8, C=feat, nhead=8, window_size=4, num_encoder_layers=1, num_decoder_layers=1, rpe=True)
+    nar = build_nar(ref, cfg_nar, seed + 5).eval()
+    past = fill.rand_input((N, 2, 1, HW, HW), seed + 6)
+    fut = fill.rand_input((N, 4, 1, HW, HW), seed + 7)
+    with torch.no_grad():
+        chained, _ = nbf["NAR_test_single_iter"]((past, fut), enc, dec, nar, 4, cpu)
+    save.update(cfg_nar=json.dumps(cfg_nar), nar_past=past.numpy(), nar_chained=chained.numpy())
+    # NAR, the BAIR 2 -> 28 recipe (three re-encoded rounds, the last one trimmed by two frames): Tp = 2, Tf = 4 -> 10 frames
+    cfg_b = dict(Tp=2, Tf=4, H=8, W=8, C=feat, nhead=8, window_size=4, num_encoder_layers=1, num_decoder_layers=2, rpe=True)
+    narb = build_nar(ref, cfg_b, seed + 8).eval()
+    past = fill.rand_input((N, 2, 1, HW, HW), seed + 9)
+    fut = fill.rand_input((N, 10, 1, HW, HW), seed + 10)
+    with torch.no_grad():
+        bair, _ = nbf["NAR_BAIR_2_to_28_test_single_iter"]((past, fut), enc, dec, narb, 10, cpu)
+    assert bair.shape[1] == 10
+    save.update(cfg_bair=json.dumps(cfg_b), bair_past=past.numpy(), bair_frames=bair.numpy())
+    # train_FAR.py:103-125 (test_phase=True) is covered by tests against the oracle loops; here also through the reference modules
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
+    print(f"[{name}] rollouts: RIP {tuple(rip.shape)} RIL {tuple(ril.shape)} NAR {tuple(chained.shape)} BAIR {tuple(bair.shape)}")
+
+
 def losses_case(ref, name, seed):
     N, T, C, h, w = 2, 3, 24, 8, 8
     gt = fill.rand_normal((N, T, 1, 64, 64), seed)
@@ -520,6 +614,12 @@ def main():
         ("nar_kth128_digest", lambda n: transformer_case(ref, n, dict(k64, Tf=40, H=16, W=16, window_size=8), False, 1, 53, full=False,
                                                           check64=False)),
         ("far_bair_digest", lambda n: transformer_case(ref, n, far, True, 1, 52, full=False, check64=False)),
+        # BASELINE config 4 at its literal size: VPTRFormerFAR(2, 28, ...), T_in = 29 (train_FAR_mp.py:293-300)
+        ("far_bair29_digest", lambda n: transformer_case(ref, n, dict(far, Tf=28, Tin=29), True, 1, 54, full=False, check64=False)),
+        # full-size auto-encoders: BAIR (3 channels, zero padding, 64x64) and KTH 128x128 (1 channel, reflect)
+        ("ae_bair528_digest", lambda n: ae_digest_case(ref, n, 3, 528, 64, 1, 2, "zero", "Tanh", 23)),
+        ("ae_kth128_digest", lambda n: ae_digest_case(ref, n, 1, 528, 128, 1, 2, "reflect", "Tanh", 24)),
+        ("rollouts_tiny", lambda n: rollout_case(ref, n, 111)),
     ]
     only = sys.argv[1:]
     for name, fn in cases:

@@ -312,6 +312,49 @@ def test_flat_adamw_state_dict_is_torch_adamw_compatible():
         assert torch.equal(b["state"][i]["exp_avg_sq"], sd["state"][i]["exp_avg_sq"]) and float(b["state"][i]["step"]) == 3.0
 
 
+def test_flat_adamw_state_dict_channel_last_params():
+    """Parameters that FlatAdamW STORES channel-last (LayerNorm((C,H,W)) affines, depthwise 3x3 weights) must cross the
+    torch.optim.AdamW state format in their logical layout, both ways (round-1 bug: slab order leaked into the state)."""
+    from vptr_amd.train import FlatAdamW
+    torch.manual_seed(1)
+
+    def make():
+        return torch.nn.ModuleList([torch.nn.Conv2d(4, 4, 3, groups=4), torch.nn.LayerNorm((3, 2, 2)), torch.nn.Linear(6, 5)])
+    ref = make()
+    ref_opt = torch.optim.AdamW(ref.parameters(), lr=3e-4, weight_decay=0.01)
+    for _ in range(2):
+        for p in ref.parameters():
+            p.grad = torch.randn_like(p)
+        ref_opt.step()
+    sd = ref_opt.state_dict()
+    ours = make()
+    ours.load_state_dict(ref.state_dict())
+    cl = [id(ours[0].weight), id(ours[1].weight), id(ours[1].bias)]
+    fo = FlatAdamW(ours.parameters(), lr=1e-4, channel_last=cl)
+    for a_, b_ in zip(ours.parameters(), ref.parameters()):
+        assert torch.equal(a_.detach(), b_.detach())          # re-pointing into the slab keeps the logical values
+    assert not ours[0].weight.is_contiguous()                  # ... while the storage order really is channel-last
+    fo.load_state_dict(sd)
+    for i, p in enumerate(ours.parameters()):
+        off, n, layout = fo._layout[i]
+        m_logical = fo.m[off:off + n].view(layout[0]).permute(layout[1]) if layout else fo.m[off:off + n].view(p.shape)
+        assert torch.equal(m_logical, sd["state"][i]["exp_avg"]), "moment of parameter %d scrambled on load" % i
+        # the slab itself holds the moment in the SAME storage order as the parameter
+        if layout:
+            assert torch.equal(fo.m[off:off + n], sd["state"][i]["exp_avg"].permute(*[*range(1, p.dim()), 0]).reshape(-1))
+    out = fo.state_dict()
+    for i in sd["state"]:
+        assert out["state"][i]["exp_avg"].is_contiguous()
+        assert torch.equal(out["state"][i]["exp_avg"], sd["state"][i]["exp_avg"])
+        assert torch.equal(out["state"][i]["exp_avg_sq"], sd["state"][i]["exp_avg_sq"])
+    back = torch.optim.AdamW(make().parameters(), lr=1.0)
+    back.load_state_dict(out)     # shapes are the logical ones: torch accepts the state as its own
+    with pytest.raises(ValueError):
+        bad = {"param_groups": sd["param_groups"], "state": {k: dict(v) for k, v in sd["state"].items()}}
+        bad["state"][0]["exp_avg"] = bad["state"][0]["exp_avg"].reshape(-1)
+        fo.load_state_dict(bad)
+
+
 def test_oracle_far_train_step_golden():
     z = load("step_far_tiny")
     cfg, meta = jload(z, "cfg"), jload(z, "meta")

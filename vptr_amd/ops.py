@@ -41,9 +41,14 @@ def _dev_key(device):
 
 
 def _master_seed(device):
+    """Device-resident master seed of the dropout / DropPath masks.  Initialised from torch.initial_seed() (so torch.manual_seed /
+    the reference's set_seed steer it) mixed with the process rank and the device index: data-parallel replicas draw different
+    masks, as the reference's per-process RNG streams do."""
     key = _dev_key(device)
     if key not in _seed_state:
-        _seed_state[key] = torch.full((1,), 0x5DEECE66D, dtype=torch.int64, device=device)
+        rank = int(os.environ.get("RANK", "0"))
+        v = (torch.initial_seed() * 0x9E3779B97F4A7C15 + (rank + 1) * 0xBF58476D1CE4E5B9 + (key + 1) * 0x94D049BB133111EB) & 0x7FFFFFFFFFFFFFFF
+        _seed_state[key] = torch.full((1,), v, dtype=torch.int64, device=device)
     return _seed_state[key]
 
 

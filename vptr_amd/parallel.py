@@ -14,19 +14,30 @@ import torch
 import torch.distributed as dist
 
 
+def _broadcast_any(t, src, group):
+    """dist.broadcast for tensors that may be non-contiguous views (FlatAdamW exposes channel-last stored parameters as permuted
+    views of its slab; NCCL and gloo reject those): broadcast a contiguous temporary and copy it back."""
+    if t.is_contiguous():
+        dist.broadcast(t, src, group=group)
+    else:
+        tmp = t.contiguous()
+        dist.broadcast(tmp, src, group=group)
+        t.copy_(tmp)
+
+
 def broadcast_module(module, src=0, group=None):
     """Make every rank hold rank `src`'s parameters and buffers (DDP constructor semantics)."""
     with torch.no_grad():
         for t in module.state_dict().values():
             if t.is_floating_point() or t.dtype in (torch.int64, torch.int32):
-                dist.broadcast(t, src, group=group)
+                _broadcast_any(t, src, group)
 
 
 def broadcast_buffers(module, src=0, group=None):
     """DDP's per-forward buffer broadcast (BatchNorm running statistics of the NAR-encoder conv-FFNs)."""
     with torch.no_grad():
         for b in module.buffers():
-            dist.broadcast(b, src, group=group)
+            _broadcast_any(b, src, group)
 
 
 def allreduce_mean_(flat, group=None, bucket_elems=16 << 20):

@@ -48,6 +48,7 @@ class FlatAdamW:
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         off = 0
+        self._layout = []  # per parameter: (offset, numel, None | (channel-last storage shape, permutation back to the logical shape))
         with torch.no_grad():
             for p in self.params:
                 n = p.numel()
@@ -59,7 +60,9 @@ class FlatAdamW:
                     p.data = self.flat[off:off + n].view(shape_cl).permute(inv)
                     p.data.copy_(val)
                     p.grad = self.grad[off:off + n].view(shape_cl).permute(inv)
+                    self._layout.append((off, n, (shape_cl, inv)))
                 else:
+                    self._layout.append((off, n, None))
                     self.flat[off:off + n].copy_(p.detach().reshape(-1))
                     p.data = self.flat[off:off + n].view(p.shape)
                     p.grad = self.grad[off:off + n].view(p.shape)
@@ -71,14 +74,20 @@ class FlatAdamW:
         ops.register_flat_slab(self.flat, self.grad)  # backward kernels accumulate weight gradients in place
 
     # -- torch.optim.AdamW-compatible state (checkpoints of the reference carry `optimizer_T.state_dict()`) ------------------
+    def _logical(self, slab, i):
+        """view of parameter i's range of `slab` (m, v, ...) in the parameter's LOGICAL shape: channel-last stored parameters
+        come back through the same permuted view their .data uses, so state crosses the torch.optim format unscrambled"""
+        off, n, cl = self._layout[i]
+        if cl is None:
+            return slab[off:off + n].view(self.params[i].shape)
+        return slab[off:off + n].view(cl[0]).permute(cl[1])
+
     def state_dict(self):
-        state, off = {}, 0
+        state = {}
         step = self.step_dev.detach().clone().reshape(())
-        for i, p in enumerate(self.params):
-            n = p.numel()
-            state[i] = {"step": step.clone(), "exp_avg": self.m[off:off + n].view(p.shape).clone(),
-                        "exp_avg_sq": self.v[off:off + n].view(p.shape).clone()}
-            off += n
+        for i in range(len(self.params)):
+            state[i] = {"step": step.clone(), "exp_avg": self._logical(self.m, i).contiguous().clone(),
+                        "exp_avg_sq": self._logical(self.v, i).contiguous().clone()}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                  "params": list(range(len(self.params)))}
@@ -91,22 +100,23 @@ class FlatAdamW:
             raise ValueError("FlatAdamW.load_state_dict: %d parameters in the checkpoint, %d here" % (len(ids), len(self.params)))
         g0 = groups[0]
         self.lr, self.betas, self.eps, self.weight_decay = g0["lr"], tuple(g0["betas"]), g0["eps"], g0["weight_decay"]
-        off, step = 0, None
+        step = None
         with torch.no_grad():
-            for pid, p in zip(ids, self.params):
-                n = p.numel()
+            for i, (pid, p) in enumerate(zip(ids, self.params)):
                 st = sd["state"].get(pid)
                 if st is None:  # parameter never stepped
-                    self.m[off:off + n].zero_()
-                    self.v[off:off + n].zero_()
+                    self._logical(self.m, i).zero_()
+                    self._logical(self.v, i).zero_()
                 else:
-                    self.m[off:off + n].copy_(st["exp_avg"].reshape(-1))
-                    self.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                        raise ValueError("FlatAdamW.load_state_dict: parameter %d has shape %s, its state %s"
+                                         % (i, tuple(p.shape), tuple(st["exp_avg"].shape)))
+                    self._logical(self.m, i).copy_(st["exp_avg"])
+                    self._logical(self.v, i).copy_(st["exp_avg_sq"])
                     s_i = float(st["step"])
                     if step is not None and s_i != step:
                         raise ValueError("FlatAdamW.load_state_dict: per-parameter step counts differ (%g vs %g)" % (s_i, step))
                     step = s_i
-                off += n
             self.step_dev.fill_(0.0 if step is None else step)
 
     def zero_grad(self):
@@ -117,20 +127,22 @@ class FlatAdamW:
         self.grad.zero_()
 
     def grad_norm(self):
-        """global L2 norm of the current gradients (device tensor), as clip_grad_norm_ returns"""
-        return self.sumsq.sqrt()
+        """global L2 norm of the (scaled) gradients of the last step (device tensor), as clip_grad_norm_ returns"""
+        return self.sumsq.sqrt() * self._last_scale
+
+    _last_scale = 1.0
 
     def step(self, grad_scale=1.0):
+        """grad_scale multiplies every gradient before clipping (e.g. 1 / accumulation steps)"""
         n = self.flat.numel()
+        self._last_scale = float(grad_scale)
         self.sumsq.zero_()
         check(lib.vptr_sumsq(ptr(self.grad), n, ptr(self.sumsq), stream()), "vptr_sumsq")
-        if grad_scale != 1.0:
-            self.sumsq.mul_(grad_scale * grad_scale)
         self.step_dev.add_(1.0)
         check(lib.vptr_adamw(ptr(self.flat), ptr(self.grad), ptr(self.m), ptr(self.v), n, self.lr, self.betas[0], self.betas[1],
                              self.eps, self.weight_decay, ptr(self.step_dev),
                              ptr(self.sumsq) if self.max_grad_norm is not None else None,
-                             float(self.max_grad_norm or 0.0), 1.0, stream()), "vptr_adamw")
+                             float(self.max_grad_norm or 0.0), float(grad_scale), stream()), "vptr_adamw")
 
 
 def _channel_last_ids(transformer):
@@ -152,6 +164,9 @@ class NARTrainer:
     def __init__(self, enc, dec, transformer, batch_size, lr=1e-4, max_grad_norm=1.0, lam_pc=0.1, process_group=None,
                  bucket_mb=64, dec_weight_grads=True, disc=None, lam_gan=None, gan_mode="vanilla"):
         self.enc, self.dec, self.T = enc.eval(), dec.eval(), transformer
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.bucket_elems = bucket_mb * (1 << 20) // 4
         self._init_gan(disc, lam_gan, lr, gan_mode)
         # Stage 2 optimises the transformer only (train_NAR.py:205).  The reference nevertheless leaves the decoder's
         # parameters trainable (:190-191), so its backward computes decoder weight gradients nobody consumes; that work
@@ -196,6 +211,10 @@ class NARTrainer:
         l_real = self.gan(self.disc(real.flatten(0, 1)), True)
         loss_D = (l_fake + l_real) * 0.5 * self.lam_gan
         loss_D.backward()
+        if self.pg is not None and self.world > 1:   # the reference's DDP-wrapped discriminator averages its gradients too
+            ops.flush_wgrads()
+            from .parallel import allreduce_mean_
+            allreduce_mean_(self.opt_D.grad, self.pg, self.bucket_elems)
         self.opt_D.step()
         for p in self.disc.parameters():
             p.requires_grad_(False)
@@ -325,6 +344,9 @@ class FARTrainer(NARTrainer):
     def __init__(self, enc, dec, transformer, lr=1e-4, max_grad_norm=1.0, process_group=None, bucket_mb=64, dec_weight_grads=True,
                  disc=None, lam_gan=None, gan_mode="vanilla"):
         self.enc, self.dec, self.T = enc.eval(), dec.eval(), transformer
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.bucket_elems = bucket_mb * (1 << 20) // 4
         self._init_gan(disc, lam_gan, lr, gan_mode)
         for p in enc.parameters():
             p.requires_grad_(False)
