@@ -47,9 +47,12 @@ const char* vptr_last_error(void);
  * ---------------------------------------------------------------------------------------------- */
 enum { VPTR_A_KCONTIG = 0, VPTR_A_KSTRIDED = 1, VPTR_A_CONV = 2,
        VPTR_A_CONV_PLANES = 3 /* as VPTR_A_CONV, but A holds the NHWC input as bf16 hi / lo planes (vptr_split_planes) */,
-       VPTR_A_PLANES = 4      /* k-contiguous A[M][K/32][hi 32 | lo 32] bf16 planes, K % 32 == 0; batch members allowed */ };
+       VPTR_A_P16 = 5         /* k-contiguous A[M][K] in the P16 plane format (see vptr_to_p16); needs b_mode = VPTR_B_P16 */,
+       VPTR_A_P16T = 6        /* vptr_gemm_grouped only: token-major P16 G[K = tokens][M]; needs b_mode = VPTR_B_P16T */ };
 enum { VPTR_B_KCONTIG = 0, VPTR_B_KSTRIDED = 1,
-       VPTR_B_PLANES = 2 /* B[n][tap][c / 32][hi 32 | lo 32] bf16: plane form of the k-contiguous conv weight */ };
+       VPTR_B_PLANES = 2 /* B[n][tap][c / 32][hi 32 | lo 32] bf16: plane form of the k-contiguous conv weight */,
+       VPTR_B_P16 = 3    /* k-contiguous B[N][K] in the P16 plane format (weight planes, vptr_weight_planes) */,
+       VPTR_B_P16T = 4   /* vptr_gemm_grouped only: token-major P16 X[K = tokens][N] */ };
 enum { VPTR_ACT_NONE = 0, VPTR_ACT_GELU = 1, VPTR_ACT_RELU = 2, VPTR_ACT_LRELU = 3 /* LeakyReLU(0.2), VPTR_modules.py:70 */ };
 enum { VPTR_PAD_ZERO = 0, VPTR_PAD_REFLECT = 1, VPTR_PAD_REPLICATE = 2 };
 
@@ -105,6 +108,9 @@ typedef struct vptr_gemm_desc {
      the result as bf16 hi / lo planes [M (+1)][ceil(N/32)][64] -- the operand format of the NEXT plane GEMM, so no
      vptr_split_planes pass is needed in between.  Pad channels / the extra row are never written (keep the buffer zeroed). */
   void* D_planes;
+  /* a_mode = VPTR_A_P16 only: != 0 writes D (and D_x1 / D_x2) in the P16 plane format instead of fp32 (the operand format of the
+     GEMM that consumes it; Dpre stays fp32).  Needs N and ldd multiples of 16 and 64-byte aligned outputs. */
+  int d_p16;
 } vptr_gemm_desc;
 
 int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream);
@@ -116,6 +122,30 @@ int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream);
  * planes must be 128-byte aligned. */
 int vptr_split_planes(const float* x, void* planes, int64_t rows, int C, vptr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * P16: the "convert once" operand format of every nn.Linear forward / input-gradient / weight-gradient GEMM of the
+ * transformers (MultiHeadAttentionRPE.py:543-545,687-688; VidHRFormer_modules.py:79-89,185-192,204-205,430,436 and their
+ * autograd).  A P16 tensor has the shape, pitch and byte size of the fp32 [rows, C] tensor it stands for (C % 16 == 0); each
+ * 16-channel granule (64 bytes) holds 16 bf16 `hi` then 16 bf16 `lo` with x = hi + lo to 2^-17 relative.  Producers write it
+ * directly (the `p16` flags of vptr_layernorm_fwd, the attention cores, vptr_norm_act_fwd/bwd, vptr_act_bwd and
+ * vptr_gemm_desc.d_p16); the GEMMs stage it with global_load_lds (no conversion and no LDS stores in their main loops).
+ * vptr_to_p16 is the stand-alone conversion pass for tensors no producer kernel emits in this format. */
+int vptr_to_p16(const float* x, void* out, int64_t rows, int C, vptr_stream_t stream);
+
+/* Weight planes for a table of nn.Linear / 1x1-conv weights in ONE launch (after every optimizer step):
+ *   W [N, ldw] fp32 (K columns used)  ->  Wp [N, K] P16 (B operand of the forward GEMM, b_mode = VPTR_B_P16)
+ *                                         WT [K, N] P16 (B operand of the input-gradient GEMM dX = dY . W)
+ * N % 16 == 0, K % 16 == 0.  tile_start_dev[g] = first 32 x 32 tile of entry g (ceil(N/32) * ceil(K/32) tiles each). */
+typedef struct vptr_wplane_entry {
+  const float* W;
+  void* Wp;
+  void* WT;
+  int64_t ldw;
+  int N, K;
+} vptr_wplane_entry;
+int vptr_weight_planes(const vptr_wplane_entry* table_dev, const int* tile_start_dev, int count, int total_tiles,
+                       vptr_stream_t stream);
+
 /* Column width of the output tile vptr_gemm / vptr_gemm_grouped use for an N-column problem (64, 128 or 176);
  * the row height is always 128.  Host-side helper for building vptr_gemm_grouped's tile table. */
 int vptr_gemm_tile_cols(int N);
@@ -124,6 +154,9 @@ int vptr_gemm_tile_cols(int N);
  * Used for the weight gradients of a whole backward pass (dW = dY^T . X of every nn.Linear, train_NAR.py:101): the
  * per-layer calls are recorded and flushed together, because each one alone (12-60 output tiles, K = all tokens)
  * cannot fill 256 CUs without ~30 K-splits that each pay a prologue and an atomic epilogue.
+ * With a_mode = VPTR_A_P16T / b_mode = VPTR_B_P16T both operands are token-major P16 tensors (A = dY [tokens, M] with lda,
+ * B = X [tokens, N] with ldb, K = tokens): the convert-once weight-gradient kernel (fragments by ds_read_b64_tr_b16, tile
+ * 128 x 176 for every N); a_rowsum then comes out of an MFMA product with a vector of ones.
  *   proto          host copy of any member: a_mode / b_mode (must be k-strided x k-strided), precision and the tile
  *                  class of N (vptr_gemm_tile_cols) are taken from it and must be common to the group
  *   descs_dev      DEVICE array [count] of descriptors (split_k ignored; atomic = 1 accumulates into D)
@@ -158,10 +191,12 @@ int vptr_add_rowtab(const float* x, const float* tab, float* y, int rows, int C,
  * (MultiHeadAttentionRPE.py:586-590,623,629-650,677-682 + window partition VidHRFormer_modules.py:497-525,
  *  done by index arithmetic).  q (pre-scaled), k, v, o: [B*H*W, C] token-major, B = N*T frames.
  *  bias_table [(2ws-1)^2, nh] or null; rel_index int64 [ws*ws, ws*ws].
+ *  p16 (all attention cores): != 0 writes the outputs that only feed GEMMs -- o in the forward calls, dq / dk / dv in the
+ *  backward calls -- in the P16 plane format (C % 16 == 0) instead of fp32; inputs are always fp32.
  * ---------------------------------------------------------------------------------------------- */
 int vptr_winattn_fwd(const float* q, const float* k, const float* v, const float* bias_table, const int64_t* rel_index,
                      float* o, int B, int H, int W, int C, int nh, int ws, float dropout_p, const uint64_t* seed_dev,
-                     uint32_t site, vptr_stream_t stream);
+                     uint32_t site, int p16, vptr_stream_t stream);
 /* dq,dk,dv are written; dbias_table is ACCUMULATED (may be null).  dq is multiplied by dq_scale on the way out: with
  * q = alpha * (x Wq^T + bq) (the head_dim^-0.5 of MultiHeadAttentionRPE.py:586 / nn.MultiheadAttention), dq_scale = alpha
  * makes dq the gradient of the UNSCALED projection, so dQ, dK, dV can feed one K-segmented input-gradient GEMM
@@ -169,7 +204,7 @@ int vptr_winattn_fwd(const float* q, const float* k, const float* v, const float
 int vptr_winattn_bwd(const float* q, const float* k, const float* v, const float* bias_table, const int64_t* rel_index,
                      const float* dout, float* dq, float* dk, float* dv, float* dbias_table, int B, int H, int W, int C,
                      int nh, int ws, float dropout_p, const uint64_t* seed_dev, uint32_t site, float dq_scale,
-                     vptr_stream_t stream);
+                     int p16, vptr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Temporal attention core (nn.MultiheadAttention slow path, VidHRFormer_modules.py:74-84,183-187,199-206):
@@ -177,20 +212,20 @@ int vptr_winattn_bwd(const float* q, const float* k, const float* v, const float
  * causal != 0 masks j > i (FAR, :76-82).
  * ---------------------------------------------------------------------------------------------- */
 int vptr_tattn_fwd(const float* q, const float* k, const float* v, float* o, int Nb, int Tq, int Tk, int HW, int C, int nh,
-                   int causal, float dropout_p, const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream);
+                   int causal, float dropout_p, const uint64_t* seed_dev, uint32_t site, int p16, vptr_stream_t stream);
 int vptr_tattn_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk, float* dv,
                    int Nb, int Tq, int Tk, int HW, int C, int nh, int causal, float dropout_p, const uint64_t* seed_dev,
-                   uint32_t site, float dq_scale /* as in vptr_winattn_bwd */, vptr_stream_t stream);
+                   uint32_t site, float dq_scale /* as in vptr_winattn_bwd */, int p16, vptr_stream_t stream);
 
 /* Temporal-spatial window attention (TemporalSpatialLocalMultiheadAttention, VidHRFormer_modules.py:219-284 with the
  * permutes of :444-484 folded into index arithmetic): q [(n,tq,h,w), C] (pre-scaled), k, v [(n,tk,h,w), C]; for every
  * ws x ws window and head the Tq*ws*ws queries attend to the Tk*ws*ws memory tokens of the same window.
  * H, W multiples of ws (PadBlock padding is applied by the caller with vptr_window_copy). */
 int vptr_tsattn_fwd(const float* q, const float* k, const float* v, float* o, int Nb, int Tq, int Tk, int H, int W, int ws, int C,
-                    int nh, float dropout_p, const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream);
+                    int nh, float dropout_p, const uint64_t* seed_dev, uint32_t site, int p16, vptr_stream_t stream);
 int vptr_tsattn_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk, float* dv, int Nb,
                     int Tq, int Tk, int H, int W, int ws, int C, int nh, float dropout_p, const uint64_t* seed_dev,
-                    uint32_t site, vptr_stream_t stream);
+                    uint32_t site, int p16, vptr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Conv-FFN pieces (MlpDWBN, VidHRFormer_modules.py:424-442) on channel-last [rows = frames*HW, F].
@@ -236,7 +271,8 @@ int vptr_nchw_to_tokens_masked(const float* dout, const float* out, float* dtok,
 /* backward of the GEMM epilogue: dx[m,n] = dy[m,n] * dropmask(site) * rowscale[(m / rs_div) % rs_mod] * act'(h[m,n]) * alpha
  * (act 1: exact GELU on the saved pre-activation h; act 2: ReLU mask h > 0; act 0: h unused). rowscale may be null. */
 int vptr_act_bwd(const float* dy, const float* h, float* dx, int rows, int C, int act, float alpha, const float* rowscale,
-                 int rs_div, int rs_mod, float dropout_p, const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream);
+                 int rs_div, int rs_mod, float dropout_p, const uint64_t* seed_dev, uint32_t site,
+                 int out_p16 /* != 0: dx is written in the P16 plane format (C % 16 == 0): it only feeds GEMMs */, vptr_stream_t stream);
 /* y = x * mask(site)/keep -- standalone dropout (fwd and bwd are the same call) */
 int vptr_dropout(const float* x, float* y, int64_t n, float dropout_p, const uint64_t* seed_dev, uint32_t site,
                  vptr_stream_t stream);

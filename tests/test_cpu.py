@@ -434,3 +434,51 @@ def test_oracle_nar_gan_step_golden():
         r = st.step(past, fut)
         for k in ref:
             assert abs(r[k] - ref[k]) <= 2e-4 * abs(ref[k]) + 1e-7, (k, r[k], ref[k])
+
+
+def test_rollout_loops_match_reference_notebook_on_cpu():
+    """The rollout LOOPS of vptr_amd.inference (model-agnostic host logic) driven with oracle-backed callables vs the tensors the
+    reference's own notebook functions produced (tests/golden/rollouts_tiny.npz, see oracle/make_golden.py::rollout_case)."""
+    from oracle import vptr_oracle as O
+    from vptr_amd.inference import far_rollout, nar_bair_2_to_28, nar_rollout
+    import vptr_amd.model as pkg
+    z = load("rollouts_tiny")
+    meta = jload(z, "meta")
+
+    class Fn:
+        def __init__(self, f, **attrs):
+            self.f = f
+            self.__dict__.update(attrs)
+
+        def eval(self):
+            return self
+
+        def __call__(self, x):
+            return self.f(x)
+
+    def state(module, seed):
+        fill.apply_fill(module, seed)
+        return {k: v.detach().clone() for k, v in module.state_dict().items()}
+    Pe = state(pkg.VPTREnc(1, meta["feat"], 3, "reflect"), meta["seed"])
+    Pd = state(pkg.VPTRDec(1, meta["feat"], 3, "Sigmoid", "reflect"), meta["seed"] + 1)
+    enc = Fn(lambda x: O.enc_forward(Pe, x))
+    dec = Fn(lambda f: O.dec_forward(Pd, f, out_layer="Sigmoid"))
+    cfg = jload(z, "cfg_far")
+    Pf = state(build_transformer(pkg, cfg, True), meta["seed"] + 2)
+    far = Fn(lambda f: O.far_forward(Pf, f, cfg), num_future_frames=cfg["Tf"])
+    past = torch.from_numpy(z["far_past"])
+    for mode, key in (("RIP", "far_rip"), ("RIL", "far_ril")):
+        got = far_rollout(enc, dec, far, past, z[key].shape[1], mode=mode)
+        assert got.shape == tuple(z[key].shape) and rel(got, z[key]) < 2e-5, (mode, rel(got, z[key]))
+    cfgn = jload(z, "cfg_nar")
+    Pn = state(build_transformer(pkg, cfgn, False), meta["seed"] + 5)
+    nar = Fn(lambda f: O.nar_forward(Pn, f, cfgn), num_future_frames=cfgn["Tf"])
+    got = nar_rollout(enc, dec, nar, torch.from_numpy(z["nar_past"]), rounds=2, chain="feats")
+    assert rel(got, z["nar_chained"]) < 2e-5
+    cfgb = jload(z, "cfg_bair")
+    Pb = state(build_transformer(pkg, cfgb, False), meta["seed"] + 8)
+    narb = Fn(lambda f: O.nar_forward(Pb, f, cfgb), num_future_frames=cfgb["Tf"])
+    got = nar_bair_2_to_28(enc, dec, narb, torch.from_numpy(z["bair_past"]))
+    assert got.shape == tuple(z["bair_frames"].shape) and rel(got, z["bair_frames"]) < 2e-5
+    with pytest.raises(ValueError):
+        nar_rollout(enc, dec, narb, torch.from_numpy(z["bair_past"]), rounds=2, chain="feats")   # Tf != Tp cannot chain features

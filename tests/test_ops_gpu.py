@@ -129,26 +129,6 @@ def test_gemm_k_segments(ops, dev, M, N, K, nseg):
     assert rel(y, (ref - r.double().cpu()) * 2.0) < TOL3
 
 
-@pytest.mark.parametrize("M,N,K", [(1000, 528, 544), (5000, 2112, 64), (130, 100, 96)])
-def test_gemm_plane_operands(ops, dev, M, N, K):
-    """a_mode = VPTR_A_PLANES / b_mode = VPTR_B_PLANES: k-contiguous operands as bf16 hi / lo planes, plain and batched"""
-    xs = [rn((M, K), 420 + i).to(dev) for i in range(3)]
-    Ws = [rn((N, K), 430 + i, K ** -0.5).to(dev) for i in range(3)]
-    bs = [rn((N,), 440 + i).to(dev) for i in range(3)]
-    xp, Wp = [ops.split_planes(x) for x in xs], [ops.split_planes(W) for W in Ws]
-    r = rn((M, N), 450).to(dev)
-    y, pre = torch.empty((M, N), device=dev), torch.empty((M, N), device=dev)
-    ops.gemm_raw(xp[0], Wp[0], y, M, N, K, 4, 2, lda=0, ldb=0, bias=bs[0], alpha=0.5, act=ops.ACT_GELU, Dpre=pre, residual=r, precision=3)
-    ref_pre = (xs[0].double().cpu() @ Ws[0].double().cpu().t() + bs[0].double().cpu()) * 0.5
-    assert rel(pre, ref_pre) < TOL3 and rel(y, F.gelu(ref_pre) + r.double().cpu()) < TOL3
-    ys = [torch.empty((M, N), device=dev) for _ in range(3)]
-    ops.gemm_raw(xp[0], Wp[0], ys[0], M, N, K, 4, 2, lda=0, ldb=0, bias=bs[0], alpha=0.25, precision=3,
-                 batch_extra=[(xp[1], Wp[1], ys[1], bs[1], 1.0), (xp[2], Wp[2], ys[2], None, 2.0)])
-    for i, al in enumerate((0.25, 1.0, 2.0)):
-        ref = (xs[i].double().cpu() @ Ws[i].double().cpu().t() + (bs[i].double().cpu() if i < 2 else 0.0)) * al
-        assert rel(ys[i], ref) < TOL3
-
-
 def test_gemm_epilogue_variants(ops, dev):
     M, N, K = 200, 176, 64
     x, W = rn((M, K), 9), rn((N, K), 10, K ** -0.5)

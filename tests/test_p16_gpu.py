@@ -1,0 +1,133 @@
+"""GPU parity of the P16 ("convert once") path: the plane format itself, the weight-plane builder, the DMA-staged nt GEMM with
+its fused epilogues / batch members / K segments / K tail, the token-major grouped weight-gradient kernel (transposing LDS reads,
+bias gradient by a ones-fragment, token tail), and the autograd wrappers that route nn.Linear-shaped work through them.
+References are fp64 torch on the CPU; tolerance = the split-bf16 GEMM's 3e-5 rel-L2."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel
+from oracle import fill
+
+pytestmark = pytest.mark.gpu
+TOL3 = 3e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import vptr_amd.ops as ops
+    return ops
+
+
+def rn(shape, seed, scale=1.0):
+    return fill.rand_normal(shape, seed, scale)
+
+
+def test_p16_format_round_trip(ops, dev):
+    x = rn((300, 528), 1) * torch.logspace(-6, 3, 528)[None, :]
+    xp = ops.to_p16(x.to(dev))
+    assert xp.shape == x.shape and xp.dtype == torch.float32
+    back = ops.p16_decode(xp).cpu()
+    assert float(((back - x).abs() / x.abs().clamp_min(1e-30)).max()) < 2.0 ** -16
+    # layout: granule g of row r = 16 bf16 hi, then 16 bf16 lo, hi = bf16(x)
+    raw = xp.cpu().view(torch.bfloat16).reshape(300, 33, 2, 16)
+    assert torch.equal(raw[:, :, 0].reshape(300, 528), x.to(torch.bfloat16))
+
+
+def test_weight_planes(ops, dev):
+    Ws = [rn((528, 528), 2).to(dev), rn((2112, 528), 3).to(dev), rn((48, 192), 4).to(dev)]
+    st = ops.WeightPlanes(Ws)
+    for W in Ws:
+        wp, ldw, wt, ldt = st.lookup(W)
+        assert ldw == W.shape[1] and ldt == W.shape[0]
+        assert float((ops.p16_decode(wp) - W).abs().max()) <= 2.0 ** -16 * float(W.abs().max())
+        assert float((ops.p16_decode(wt.contiguous()) - W.t()).abs().max()) <= 2.0 ** -16 * float(W.abs().max())
+    # row slices of a packed in_proj weight: forward planes are rows, transposed planes are a column block
+    wp, ldw, wt, ldt = st.lookup(Ws[1][528:1056])
+    assert torch.equal(ops.p16_decode(wp), ops.p16_decode(st.lookup(Ws[1])[0])[528:1056])
+    assert wt.shape == (528, 528) and ldt == 2112
+    # stale planes are rebuilt when the weight changed through torch
+    Ws[0].mul_(2.0)
+    assert float((ops.p16_decode(st.lookup(Ws[0])[0]) - Ws[0]).abs().max()) <= 2.0 ** -15 * float(Ws[0].abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 528, 528), (1000, 1584, 528), (128, 352, 2112), (64, 48, 48), (257, 96, 80), (5000, 2112, 64),
+                                   (10, 16, 16)])
+def test_gemm_p16_nt_epilogue(ops, dev, M, N, K):
+    x, W, b, r = rn((M, K), 1), rn((N, K), 2, K ** -0.5), rn((N,), 3), rn((M, N), 4)
+    ref_pre = (x.double() @ W.double().t() + b.double()) * 0.5
+    ref = F.gelu(ref_pre) + r.double()
+    xp, Wp = ops.to_p16(x.to(dev)), ops.to_p16(W.to(dev))
+    y, pre = torch.empty((M, N), device=dev), torch.empty((M, N), device=dev)
+    ops.gemm_raw(xp, Wp, y, M, N, K, ops.A_P16, ops.B_P16, bias=b.to(dev), alpha=0.5, act=ops.ACT_GELU, Dpre=pre, residual=r.to(dev))
+    assert rel(y, ref) < TOL3 and rel(pre, ref_pre) < TOL3
+    # the same product written as P16 (the operand format of a following GEMM)
+    yp = torch.empty((M, N), device=dev)
+    ops.gemm_raw(xp, Wp, yp, M, N, K, ops.A_P16, ops.B_P16, bias=b.to(dev), alpha=0.5, act=ops.ACT_GELU, Dpre=pre, residual=r.to(dev), d_p16=True)
+    assert rel(ops.p16_decode(yp), ref) < TOL3
+    # row scale + ReLU-after-residual + plain
+    rs = rn((7,), 5).abs().to(dev)
+    ops.gemm_raw(xp, Wp, y, M, N, K, ops.A_P16, ops.B_P16, rowscale=rs, rs_div=3, rs_mod=7, residual=r.to(dev), act_after=True)
+    idx = (torch.arange(M) // 3) % 7
+    ref2 = torch.relu((x.double() @ W.double().t()) * rs.cpu().double()[idx][:, None] + r.double())
+    assert rel(y, ref2) < TOL3
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 528, 528), (5000, 528, 528), (130, 96, 80)])
+def test_gemm_p16_batch_and_segments(ops, dev, M, N, K):
+    xs = [ops.to_p16(rn((M, K), 200 + i).to(dev)) for i in range(3)]
+    Wf = [rn((N, K), 210 + i, K ** -0.5) for i in range(3)]
+    Ws = [ops.to_p16(w.to(dev)) for w in Wf]
+    bs = [rn((N,), 220 + i).to(dev) for i in range(3)]
+    al = [0.25, 1.0, 2.0]
+    ys = [torch.empty((M, N), device=dev) for _ in range(3)]
+    ops.gemm_raw(xs[0], Ws[0], ys[0], M, N, K, ops.A_P16, ops.B_P16, bias=bs[0], alpha=al[0],
+                 batch_extra=[(xs[1], Ws[1], ys[1], bs[1], al[1]), (xs[2], Ws[2], ys[2], None, al[2])])
+    for i in range(3):
+        ref = (ops.p16_decode(xs[i]).double().cpu() @ Wf[i].double().t() + (bs[i].double().cpu() if i < 2 else 0.0)) * al[i]
+        assert rel(ys[i], ref) < TOL3
+    # K segments: D = sum_s A_s . B_s^T with a residual; B_s here are the same [N, K] planes
+    r = rn((M, N), 260).to(dev)
+    y = torch.empty((M, N), device=dev)
+    ops.gemm_raw(xs[0], Ws[0], y, M, N, K, ops.A_P16, ops.B_P16, alpha=0.5, residual=r, kseg_extra=[(xs[1], Ws[1]), (xs[2], Ws[2])])
+    ref = sum(ops.p16_decode(a).double().cpu() @ w.double().t() for a, w in zip(xs, Wf)) * 0.5 + r.double().cpu()
+    assert rel(y, ref) < TOL3
+
+
+def test_wgrad_p16_grouped(ops, dev):
+    """token-major P16 operands, several problems per launch, accumulation into pre-filled slabs, bias gradients, output scale,
+    a token count that is not a multiple of 32 (masked tail) and row / column tiles that overhang the matrix"""
+    probs = [(1024, 528, 528, 1.0), (640, 176, 2112, 1.0), (72, 48, 48, 0.5), (1000, 2112, 528, 1.0), (40, 16, 192, 2.0), (333, 528, 48, 1.0)]
+    keep, refs = [], []
+    for i, (T, N, K, alpha) in enumerate(probs):
+        g, x = rn((T, N), 10 + i), rn((T, K), 20 + i)
+        dW0, db0 = rn((N, K), 30 + i), rn((N,), 40 + i)
+        gd, xd, dW, db = ops.to_p16(g.to(dev)), ops.to_p16(x.to(dev)), dW0.to(dev), db0.to(dev)
+        keep.append((gd, xd, dW, db))
+        refs.append((dW0.double() + alpha * (g.double().t() @ x.double()), db0.double() + alpha * g.double().sum(0)))
+        ops.defer_wgrad(gd, xd, dW, N, K, T, db=db if i != 1 else None, alpha=alpha, p16=True)
+    ops.flush_wgrads()
+    for i, ((gd, xd, dW, db), (rW, rb)) in enumerate(zip(keep, refs)):
+        assert rel(dW, rW) < TOL3, i
+        if i != 1:
+            assert rel(db, rb) < TOL3, i
+
+
+def test_linear_autograd_p16(ops, dev):
+    """ops.linear through the P16 kernels (inputs converted on the fly, weights through the plane cache) vs torch autograd,
+    including a chain in which the first layer's output and the second layer's incoming gradient never exist as fp32"""
+    M, K, F_, N = 640, 528, 2112, 528
+    x = rn((M, K), 1).to(dev).requires_grad_(True)
+    W1, b1 = rn((F_, K), 2, K ** -0.5).to(dev).requires_grad_(True), rn((F_,), 3).to(dev).requires_grad_(True)
+    W2, b2 = rn((N, F_), 4, F_ ** -0.5).to(dev).requires_grad_(True), rn((N,), 5).to(dev).requires_grad_(True)
+    r = rn((M, N), 6).to(dev).requires_grad_(True)
+    g = rn((M, N), 7).to(dev)
+    h = ops.linear(x, W1, b1, act=ops.ACT_GELU, out_p16=True)
+    y = ops.linear(h, W2, b2, residual=r, x_p16=True)
+    (y * g).sum().backward()
+    xr, W1r, b1r, W2r, b2r, rr = [t.detach().double().cpu().requires_grad_(True) for t in (x, W1, b1, W2, b2, r)]
+    yr = F.gelu(xr @ W1r.t() + b1r) @ W2r.t() + b2r + rr
+    (yr * g.double().cpu()).sum().backward()
+    assert rel(y, yr) < TOL3
+    for got, ref in ((x, xr), (W1, W1r), (b1, b1r), (W2, W2r), (b2, b2r), (r, rr)):
+        assert rel(got.grad, ref.grad) < 2 * TOL3

@@ -37,7 +37,13 @@ class GemmDesc(ctypes.Structure):
         ("A_x1", c_void_p), ("A_x2", c_void_p), ("B_x1", c_void_p), ("B_x2", c_void_p), ("D_x1", c_void_p), ("D_x2", c_void_p),
         ("bias_x1", c_void_p), ("bias_x2", c_void_p), ("alpha_x1", c_float), ("alpha_x2", c_float),
         ("D_planes", c_void_p),
+        ("d_p16", c_int),
     ]
+
+
+class WPlaneEntry(ctypes.Structure):
+    """Mirror of `vptr_wplane_entry` (include/vptr_hip.h)."""
+    _fields_ = [("W", c_void_p), ("Wp", c_void_p), ("WT", c_void_p), ("ldw", c_int64), ("N", c_int), ("K", c_int)]
 
 
 P, I, F, L, U = c_void_p, c_int, c_float, c_int64, c_uint32
@@ -46,6 +52,8 @@ SIGNATURES = {
     "vptr_gemm": [ctypes.POINTER(GemmDesc), P],
     "vptr_gemm_tile_cols": [I],
     "vptr_split_planes": [P, P, L, I, P],
+    "vptr_to_p16": [P, P, L, I, P],
+    "vptr_weight_planes": [P, P, I, I, P],
     "vptr_gemm_grouped": [ctypes.POINTER(GemmDesc), P, P, I, I, P],
     "vptr_layernorm_fwd": [P, P, P, P, P, P, I, I, P, P, I, I, F, P],
     "vptr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, I, P, P],
@@ -53,12 +61,12 @@ SIGNATURES = {
     "vptr_colsum": [P, P, I, I, P],
     "vptr_window_copy": [P, P, I, I, I, I, I, I, I, I, P],
     "vptr_add_rowtab": [P, P, P, I, I, I, I, P],
-    "vptr_winattn_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, P],
-    "vptr_winattn_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, F, P],
-    "vptr_tattn_fwd": [P, P, P, P, I, I, I, I, I, I, I, F, P, U, P],
-    "vptr_tattn_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, P, U, F, P],
-    "vptr_tsattn_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, F, P, U, P],
-    "vptr_tsattn_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P, U, P],
+    "vptr_winattn_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, I, P],
+    "vptr_winattn_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, F, I, P],
+    "vptr_tattn_fwd": [P, P, P, P, I, I, I, I, I, I, I, F, P, U, I, P],
+    "vptr_tattn_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, P, U, F, I, P],
+    "vptr_tsattn_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, F, P, U, I, P],
+    "vptr_tsattn_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P, U, I, P],
     "vptr_colstats": [P, P, P, P, F, P, I, I, P],
     "vptr_groupstats": [P, P, P, P, F, I, I, P],
     "vptr_norm_act_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, P, U, P, I, I, P, P],
@@ -68,7 +76,7 @@ SIGNATURES = {
     "vptr_nchw_to_tokens": [P, P, I, I, I, P],
     "vptr_tokens_to_nchw": [P, P, I, I, I, I, P],
     "vptr_nchw_to_tokens_masked": [P, P, P, I, I, I, P],
-    "vptr_act_bwd": [P, P, P, I, I, I, F, P, I, I, F, P, U, P],
+    "vptr_act_bwd": [P, P, P, I, I, I, F, P, I, I, F, P, U, I, P],
     "vptr_dropout": [P, P, L, F, P, U, P],
     "vptr_rowscale": [P, P, P, I, I, I, I, P],
     "vptr_conv7_in_fwd": [P, P, P, P, P, I, I, I, I, I, P],
@@ -98,7 +106,7 @@ def _load():
         fn.restype = c_int
     lib.vptr_abi_version.restype = c_int
     lib.vptr_last_error.restype = ctypes.c_char_p
-    if lib.vptr_abi_version() != 2:
+    if lib.vptr_abi_version() != 3:
         raise ImportError("vptr_amd: ABI version mismatch in %s" % LIB_PATH)
     return lib
 

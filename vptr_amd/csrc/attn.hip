@@ -10,6 +10,12 @@
 // ------------------------------------------------------------------------------------------------------------
 // window attention forward: block per (window, head)
 // ------------------------------------------------------------------------------------------------------------
+// scalar output element of an fp32 (p16 = 0) or P16 (p16 != 0: the tensor only feeds GEMMs) tensor
+__device__ __forceinline__ void store1(float* __restrict__ dst, const int64_t e, const float v, const int p16) {
+  if (p16) vptr_p16_store1(reinterpret_cast<unsigned char*>(dst), e, v);
+  else dst[e] = v;
+}
+
 __device__ __forceinline__ int win_row(int win, int l, int H, int W, int ws, int nqh, int nqw) {
   const int b = win / (nqh * nqw), r = win - b * (nqh * nqw);
   const int qh = r / nqw, qw = r - qh * nqw;
@@ -21,7 +27,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const float* __restric
                                                           const float* __restrict__ v, const float* __restrict__ table,
                                                           const int64_t* __restrict__ rel_index, float* __restrict__ o, int H,
                                                           int W, int C, int nh, int ws, float p, const uint64_t* seed_dev,
-                                                          uint32_t site) {
+                                                          uint32_t site, int p16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int L = ws * ws, hd = C / nh, hp = hd + 1, Lp = L + 1;
   float* sq = smem;            // [L][hp]
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const float* __restric
     const int i = e / hd, d = e - i * hd;
     float a = 0.f;
     for (int j = 0; j < L; ++j) a += ss[i * Lp + j] * sv[j * hp + d];
-    o[(int64_t)srow[i] * C + h * hd + d] = a;
+    store1(o, (int64_t)srow[i] * C + h * hd + d, a, p16);
   }
 }
 
@@ -133,16 +139,23 @@ __device__ __forceinline__ void rows16_store(const Rows16& r, float* dst, int hp
   }
 }
 // out rows: dst[rowoff[r] + hoff + d] = acc (hd even; float2 stores)
-__device__ __forceinline__ void store4(float* __restrict__ dst, int64_t base, int d, int hd, const float4 v) {
+// p16: dst is a P16 tensor (the output only feeds GEMMs): base + d is even, so a channel pair never straddles a 16-channel granule
+__device__ __forceinline__ void store4(float* __restrict__ dst, int64_t base, int d, int hd, const float4 v, const int p16) {
+  if (p16) {
+    vptr_p16_store2(reinterpret_cast<unsigned char*>(dst), base + d, v.x, v.y);
+    if (d + 2 < hd) vptr_p16_store2(reinterpret_cast<unsigned char*>(dst), base + d + 2, v.z, v.w);
+    return;
+  }
   *reinterpret_cast<float2*>(dst + base + d) = make_float2(v.x, v.y);
   if (d + 2 < hd) *reinterpret_cast<float2*>(dst + base + d + 2) = make_float2(v.z, v.w);
 }
+
 
 __global__ __launch_bounds__(256) void winattn16_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                             const float* __restrict__ v, const float* __restrict__ table,
                                                             const int64_t* __restrict__ rel_index, float* __restrict__ o,
                                                             int nwin, int H, int W, int C, int nh, float p,
-                                                            const uint64_t* seed_dev, uint32_t site, int wpb) {
+                                                            const uint64_t* seed_dev, uint32_t site, int wpb, int p16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int hd = C / nh, hp = att_pitch(hd), n4 = hp >> 2;
   float* sq = smem;             // [16][hp]
@@ -189,7 +202,7 @@ __global__ __launch_bounds__(256) void winattn16_fwd_kernel(const float* __restr
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
       for (int c = 0; c < 16; ++c) axpy4(acc, sp[r * 20 + c], reinterpret_cast<const float4*>(sv + c * hp)[d4]);
-      store4(o, srow[r] + h * hd, d4 * 4, hd, acc);
+      store4(o, srow[r] + h * hd, d4 * 4, hd, acc, p16);
     }
   }
 }
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(256) void winattn16_bwd_kernel(const float* __restr
                                                             float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
                                                             float* __restrict__ dtable, int nwin, int H, int W, int C, int nh,
                                                             float p, const uint64_t* seed_dev, uint32_t site, int wpb,
-                                                            float dq_scale) {
+                                                            float dq_scale, int p16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int hd = C / nh, hp = att_pitch(hd), n4 = hp >> 2;
   float* sq = smem;             // [16][hp]
@@ -265,9 +278,9 @@ __global__ __launch_bounds__(256) void winattn16_bwd_kernel(const float* __restr
         axpy4(av, sp[c * 20 + r], reinterpret_cast<const float4*>(sdo + c * hp)[d4]);
       }
       const int64_t g = srow[r] + h * hd;
-      store4(dq, g, d4 * 4, hd, make_float4(aq.x * dq_scale, aq.y * dq_scale, aq.z * dq_scale, aq.w * dq_scale));
-      store4(dk, g, d4 * 4, hd, ak);
-      store4(dv, g, d4 * 4, hd, av);
+      store4(dq, g, d4 * 4, hd, make_float4(aq.x * dq_scale, aq.y * dq_scale, aq.z * dq_scale, aq.w * dq_scale), p16);
+      store4(dk, g, d4 * 4, hd, ak, p16);
+      store4(dv, g, d4 * 4, hd, av, p16);
     }
   }
   if (dtable) {  // 256 (i, j) elements -> 49 table entries: LDS atomics, then one global atomic per entry
@@ -283,7 +296,8 @@ __global__ __launch_bounds__(256) void winattn16_bwd_kernel(const float* __restr
 
 extern "C" int vptr_winattn_fwd(const float* q, const float* k, const float* v, const float* bias_table,
                                 const int64_t* rel_index, float* o, int B, int H, int W, int C, int nh, int ws,
-                                float dropout_p, const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream) {
+                                float dropout_p, const uint64_t* seed_dev, uint32_t site, int p16, vptr_stream_t stream) {
+  if (p16) VPTR_CHECK(C % 16 == 0, "winattn_fwd: P16 outputs need C %% 16 == 0 (got %d)", C);
   VPTR_CHECK(B > 0 && H > 0 && W > 0 && C > 0 && nh > 0 && ws > 0, "winattn_fwd: bad arguments");
   VPTR_CHECK(C % nh == 0, "winattn_fwd: embed_dim must be divisible by num_heads");
   VPTR_CHECK(H % ws == 0 && W % ws == 0, "winattn_fwd: H, W must be multiples of the window size (pad on the host)");
@@ -296,7 +310,7 @@ extern "C" int vptr_winattn_fwd(const float* q, const float* k, const float* v, 
     const int wpb = nwin >= 64 ? 2 : 1;   // two windows per workgroup: the second one's loads overlap the first one's math
     const size_t lds16 = sizeof(float) * (3 * 16 * att_pitch(hd) + 16 * 20);
     winattn16_fwd_kernel<<<dim3(cdiv(nwin, wpb), nh), 256, lds16, (hipStream_t)stream>>>(q, k, v, bias_table, rel_index, o, nwin, H, W, C,
-                                                                                         nh, dropout_p, seed_dev, site, wpb);
+                                                                                         nh, dropout_p, seed_dev, site, wpb, p16);
     VPTR_LAUNCH_CHECK();
     return 0;
   }
@@ -306,7 +320,7 @@ extern "C" int vptr_winattn_fwd(const float* q, const float* k, const float* v, 
     (void)hipFuncSetAttribute((const void*)winattn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   dim3 grid(B * (H / ws) * (W / ws), nh);
   winattn_fwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(q, k, v, bias_table, rel_index, o, H, W, C, nh, ws, dropout_p,
-                                                             seed_dev, site);
+                                                             seed_dev, site, p16);
   VPTR_LAUNCH_CHECK();
   return 0;
 }
@@ -320,7 +334,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const float* __restric
                                                           float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
                                                           float* __restrict__ dtable, int nwin, int H, int W, int C, int nh,
                                                           int ws, float p, const uint64_t* seed_dev, uint32_t site, int wpb,
-                                                          float dq_scale) {
+                                                          float dq_scale, int p16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int L = ws * ws, hd = C / nh, hp = hd + 1, Lp = L + 1;
   const int ntab = (2 * ws - 1) * (2 * ws - 1);
@@ -399,9 +413,9 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const float* __restric
         av += sp[j * Lp + i] * sdo[j * hp + d];
       }
       const int64_t g = (int64_t)srow[i] * C + h * hd + d;
-      dq[g] = aq * dq_scale;
-      dk[g] = ak;
-      dv[g] = av;
+      store1(dq, g, aq * dq_scale, p16);
+      store1(dk, g, ak, p16);
+      store1(dv, g, av, p16);
     }
   }
   __syncthreads();
@@ -412,7 +426,8 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const float* __restric
 extern "C" int vptr_winattn_bwd(const float* q, const float* k, const float* v, const float* bias_table,
                                 const int64_t* rel_index, const float* dout, float* dq, float* dk, float* dv,
                                 float* dbias_table, int B, int H, int W, int C, int nh, int ws, float dropout_p,
-                                const uint64_t* seed_dev, uint32_t site, float dq_scale, vptr_stream_t stream) {
+                                const uint64_t* seed_dev, uint32_t site, float dq_scale, int p16, vptr_stream_t stream) {
+  if (p16) VPTR_CHECK(C % 16 == 0, "winattn_bwd: P16 outputs need C %% 16 == 0 (got %d)", C);
   VPTR_CHECK(B > 0 && H > 0 && W > 0 && C > 0 && nh > 0 && ws > 0, "winattn_bwd: bad arguments");
   VPTR_CHECK(C % nh == 0 && H % ws == 0 && W % ws == 0 && ws * ws <= ATT_MAXL, "winattn_bwd: unsupported geometry");
   if (bias_table || dbias_table) VPTR_CHECK(rel_index != nullptr, "winattn_bwd: bias table needs rel_index");
@@ -426,7 +441,7 @@ extern "C" int vptr_winattn_bwd(const float* q, const float* k, const float* v, 
     const size_t lds16 = sizeof(float) * (4 * 16 * att_pitch(hd) + 2 * 16 * 20);
     winattn16_bwd_kernel<<<dim3(cdiv(nwin, wpb16), nh), 256, lds16, (hipStream_t)stream>>>(q, k, v, bias_table, rel_index, dout, dq, dk,
                                                                                           dv, dbias_table, nwin, H, W, C, nh,
-                                                                                          dropout_p, seed_dev, site, wpb16, dq_scale);
+                                                                                          dropout_p, seed_dev, site, wpb16, dq_scale, p16);
     VPTR_LAUNCH_CHECK();
     return 0;
   }
@@ -437,7 +452,7 @@ extern "C" int vptr_winattn_bwd(const float* q, const float* k, const float* v, 
     (void)hipFuncSetAttribute((const void*)winattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   winattn_bwd_kernel<<<dim3(cdiv(nwin, wpb), nh), 256, lds, (hipStream_t)stream>>>(q, k, v, bias_table, rel_index, dout, dq, dk, dv,
                                                                                  dbias_table, nwin, H, W, C, nh, ws, dropout_p,
-                                                                                 seed_dev, site, wpb, dq_scale);
+                                                                                 seed_dev, site, wpb, dq_scale, p16);
   VPTR_LAUNCH_CHECK();
   return 0;
 }
@@ -448,7 +463,7 @@ extern "C" int vptr_winattn_bwd(const float* q, const float* k, const float* v, 
 __global__ __launch_bounds__(64) void tattn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, float* __restrict__ o, int Tq, int Tk,
                                                        int HW, int C, int nh, int causal, float p, const uint64_t* seed_dev,
-                                                       uint32_t site) {
+                                                       uint32_t site, int p16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int hd = C / nh, hp = hd + 1, Tp = Tk + 1;
   float* sq = smem;             // [Tq][hp]
@@ -495,7 +510,7 @@ __global__ __launch_bounds__(64) void tattn_fwd_kernel(const float* __restrict__
     const int i = e / hd, d = e - i * hd;
     float a = 0.f;
     for (int j = 0; j < Tk; ++j) a += ss[i * Tp + j] * sv[j * hp + d];
-    o[((int64_t)(n * Tq + i) * HW + pix) * C + h * hd + d] = a;
+    store1(o, ((int64_t)(n * Tq + i) * HW + pix) * C + h * hd + d, a, p16);
   }
 }
 
@@ -534,7 +549,7 @@ template <bool PF>  // PF: TR_PPW pixels per wave, the next pixel's rows prefetc
 __global__ __launch_bounds__(64) void tattn16_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, float* __restrict__ o, int Tq, int Tk,
                                                          int HW, int C, int nh, int causal, float p, const uint64_t* seed_dev,
-                                                         uint32_t site, int NP) {
+                                                         uint32_t site, int NP, int p16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int hd = C / nh, hp = att_pitch(hd), n4 = hp >> 2;
   float* sq = smem;              // [Tq][hp]
@@ -598,7 +613,7 @@ __global__ __launch_bounds__(64) void tattn16_fwd_kernel(const float* __restrict
       if (d4 * 4 >= hd) continue;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int c = 0; c < Tk; ++c) axpy4(acc, ss[i * 20 + c], reinterpret_cast<const float4*>(sv + c * hp)[d4]);
-      store4(o, rq[i] + h * hd, d4 * 4, hd, acc);
+      store4(o, rq[i] + h * hd, d4 * 4, hd, acc, p16);
     }
   }
 }
@@ -608,7 +623,7 @@ __global__ __launch_bounds__(64) void tattn16_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ v, const float* __restrict__ dout,
                                                          float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
                                                          int Tq, int Tk, int HW, int C, int nh, int causal, float p,
-                                                         const uint64_t* seed_dev, uint32_t site, int NP, float dq_scale) {
+                                                         const uint64_t* seed_dev, uint32_t site, int NP, float dq_scale, int p16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int hd = C / nh, hp = att_pitch(hd), n4 = hp >> 2;
   float* sq = smem;               // [Tq][hp]
@@ -684,7 +699,7 @@ __global__ __launch_bounds__(64) void tattn16_bwd_kernel(const float* __restrict
     if (d4 * 4 >= hd) continue;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c = 0; c < Tk; ++c) axpy4(acc, sds[i * 20 + c], reinterpret_cast<const float4*>(sk + c * hp)[d4]);
-    store4(dq, rq[i] + h * hd, d4 * 4, hd, make_float4(acc.x * dq_scale, acc.y * dq_scale, acc.z * dq_scale, acc.w * dq_scale));
+    store4(dq, rq[i] + h * hd, d4 * 4, hd, make_float4(acc.x * dq_scale, acc.y * dq_scale, acc.z * dq_scale, acc.w * dq_scale), p16);
   }
   for (int e = lane; e < Tk * n4; e += 64) {
     const int c = e / n4, d4 = e - c * n4;
@@ -694,15 +709,16 @@ __global__ __launch_bounds__(64) void tattn16_bwd_kernel(const float* __restrict
       axpy4(ak, sds[i * 20 + c], reinterpret_cast<const float4*>(sq + i * hp)[d4]);
       axpy4(av, sp[i * 20 + c], reinterpret_cast<const float4*>(sdo + i * hp)[d4]);
     }
-    store4(dk, rk[c] + h * hd, d4 * 4, hd, ak);
-    store4(dv, rk[c] + h * hd, d4 * 4, hd, av);
+    store4(dk, rk[c] + h * hd, d4 * 4, hd, ak, p16);
+    store4(dv, rk[c] + h * hd, d4 * 4, hd, av, p16);
   }
   }
 }
 
 extern "C" int vptr_tattn_fwd(const float* q, const float* k, const float* v, float* o, int Nb, int Tq, int Tk, int HW, int C,
                               int nh, int causal, float dropout_p, const uint64_t* seed_dev, uint32_t site,
-                              vptr_stream_t stream) {
+                              int p16, vptr_stream_t stream) {
+  if (p16) VPTR_CHECK(C % 16 == 0, "tattn_fwd: P16 outputs need C %% 16 == 0 (got %d)", C);
   VPTR_CHECK(Nb > 0 && Tq > 0 && Tk > 0 && HW > 0 && C > 0 && nh > 0, "tattn_fwd: bad arguments");
   VPTR_CHECK(C % nh == 0, "tattn_fwd: embed_dim must be divisible by num_heads");
   VPTR_CHECK(Tq <= ATT_MAXT && Tk <= ATT_MAXT, "tattn_fwd: T must be <= %d", ATT_MAXT);
@@ -714,17 +730,17 @@ extern "C" int vptr_tattn_fwd(const float* q, const float* k, const float* v, fl
     const int items = (Tq > Tk ? Tq : Tk) * (att_pitch(hd) / 2);
     if (items <= 64 * TR_NIT && Nb * HW >= 64 * TR_PPW)
       tattn16_fwd_kernel<true><<<dim3(cdiv(cdiv(Nb * HW, TR_PPW), 8) * 8 * nh), 64, lds16, (hipStream_t)stream>>>(
-          q, k, v, o, Tq, Tk, HW, C, nh, causal, dropout_p, seed_dev, site, Nb * HW);
+          q, k, v, o, Tq, Tk, HW, C, nh, causal, dropout_p, seed_dev, site, Nb * HW, p16);
     else
       tattn16_fwd_kernel<false><<<dim3(cdiv(Nb * HW, 8) * 8 * nh), 64, lds16, (hipStream_t)stream>>>(q, k, v, o, Tq, Tk, HW, C, nh, causal,
-                                                                                                    dropout_p, seed_dev, site, Nb * HW);
+                                                                                                    dropout_p, seed_dev, site, Nb * HW, p16);
     VPTR_LAUNCH_CHECK();
     return 0;
   }
   const size_t lds = sizeof(float) * ((Tq + 2 * Tk) * (hd + 1) + Tq * (Tk + 1));
   VPTR_CHECK(lds <= 64 * 1024, "tattn_fwd: LDS budget exceeded (%zu B)", lds);
   tattn_fwd_kernel<<<dim3(Nb * HW, nh), 64, lds, (hipStream_t)stream>>>(q, k, v, o, Tq, Tk, HW, C, nh, causal, dropout_p, seed_dev,
-                                                                       site);
+                                                                       site, p16);
   VPTR_LAUNCH_CHECK();
   return 0;
 }
@@ -733,7 +749,7 @@ __global__ __launch_bounds__(64) void tattn_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ v, const float* __restrict__ dout,
                                                        float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
                                                        int Tq, int Tk, int HW, int C, int nh, int causal, float p,
-                                                       const uint64_t* seed_dev, uint32_t site, float dq_scale) {
+                                                       const uint64_t* seed_dev, uint32_t site, float dq_scale, int p16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int hd = C / nh, hp = hd + 1, Tp = Tk + 1;
   float* sq = smem;              // [Tq][hp]
@@ -800,7 +816,7 @@ __global__ __launch_bounds__(64) void tattn_bwd_kernel(const float* __restrict__
     const int i = e / hd, d = e - i * hd;
     float a = 0.f;
     for (int j = 0; j < Tk; ++j) a += sds[i * Tp + j] * sk[j * hp + d];
-    dq[((int64_t)(n * Tq + i) * HW + pix) * C + h * hd + d] = a * dq_scale;
+    store1(dq, ((int64_t)(n * Tq + i) * HW + pix) * C + h * hd + d, a * dq_scale, p16);
   }
   for (int e = lane; e < Tk * hd; e += 64) {
     const int j = e / hd, d = e - j * hd;
@@ -810,14 +826,15 @@ __global__ __launch_bounds__(64) void tattn_bwd_kernel(const float* __restrict__
       av += sp[i * Tp + j] * sdo[i * hp + d];
     }
     const int64_t g = ((int64_t)(n * Tk + j) * HW + pix) * C + h * hd + d;
-    dk[g] = ak;
-    dv[g] = av;
+    store1(dk, g, ak, p16);
+    store1(dv, g, av, p16);
   }
 }
 
 extern "C" int vptr_tattn_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,
                               float* dv, int Nb, int Tq, int Tk, int HW, int C, int nh, int causal, float dropout_p,
-                              const uint64_t* seed_dev, uint32_t site, float dq_scale, vptr_stream_t stream) {
+                              const uint64_t* seed_dev, uint32_t site, float dq_scale, int p16, vptr_stream_t stream) {
+  if (p16) VPTR_CHECK(C % 16 == 0, "tattn_bwd: P16 outputs need C %% 16 == 0 (got %d)", C);
   VPTR_CHECK(Nb > 0 && Tq > 0 && Tk > 0 && HW > 0 && C > 0 && nh > 0, "tattn_bwd: bad arguments");
   VPTR_CHECK(C % nh == 0 && Tq <= ATT_MAXT && Tk <= ATT_MAXT, "tattn_bwd: unsupported geometry");
   if (causal) VPTR_CHECK(Tq == Tk, "tattn_bwd: causal mask needs Tq == Tk");
@@ -828,10 +845,10 @@ extern "C" int vptr_tattn_bwd(const float* q, const float* k, const float* v, co
     const int items = (Tq > Tk ? Tq : Tk) * (att_pitch(hd) / 2);
     if (items <= 64 * TR_NIT && Nb * HW >= 64 * TR_PPW)
       tattn16_bwd_kernel<true><<<dim3(cdiv(cdiv(Nb * HW, TR_PPW), 8) * 8 * nh), 64, lds16, (hipStream_t)stream>>>(
-          q, k, v, dout, dq, dk, dv, Tq, Tk, HW, C, nh, causal, dropout_p, seed_dev, site, Nb * HW, dq_scale);
+          q, k, v, dout, dq, dk, dv, Tq, Tk, HW, C, nh, causal, dropout_p, seed_dev, site, Nb * HW, dq_scale, p16);
     else
       tattn16_bwd_kernel<false><<<dim3(cdiv(Nb * HW, 8) * 8 * nh), 64, lds16, (hipStream_t)stream>>>(
-          q, k, v, dout, dq, dk, dv, Tq, Tk, HW, C, nh, causal, dropout_p, seed_dev, site, Nb * HW, dq_scale);
+          q, k, v, dout, dq, dk, dv, Tq, Tk, HW, C, nh, causal, dropout_p, seed_dev, site, Nb * HW, dq_scale, p16);
     VPTR_LAUNCH_CHECK();
     return 0;
   }
@@ -840,7 +857,7 @@ extern "C" int vptr_tattn_bwd(const float* q, const float* k, const float* v, co
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)tattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   tattn_bwd_kernel<<<dim3(Nb * HW, nh), 64, lds, (hipStream_t)stream>>>(q, k, v, dout, dq, dk, dv, Tq, Tk, HW, C, nh, causal,
-                                                                       dropout_p, seed_dev, site, dq_scale);
+                                                                       dropout_p, seed_dev, site, dq_scale, p16);
   VPTR_LAUNCH_CHECK();
   return 0;
 }
@@ -863,7 +880,7 @@ __device__ __forceinline__ int64_t ts_row(int n, int T, int H, int W, int ws, in
 __global__ __launch_bounds__(256) void tsattn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, float* __restrict__ o, int Tq, int Tk,
                                                          int H, int W, int ws, int C, int nh, float p,
-                                                         const uint64_t* seed_dev, uint32_t site) {
+                                                         const uint64_t* seed_dev, uint32_t site, int p16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int hd = C / nh, hp = hd + 1, w2 = ws * ws;
   const int Lq = Tq * w2, Lk = Tk * w2, Lp = Lk + 1;
@@ -914,7 +931,7 @@ __global__ __launch_bounds__(256) void tsattn_fwd_kernel(const float* __restrict
     const int i = e / hd, d = e - i * hd;
     float a = 0.f;
     for (int j = 0; j < Lk; ++j) a += ss[i * Lp + j] * sv[j * hp + d];
-    o[ts_row(n, Tq, H, W, ws, qh, qw, i0 + i) * C + h * hd + d] = a;
+    store1(o, ts_row(n, Tq, H, W, ws, qh, qw, i0 + i) * C + h * hd + d, a, p16);
   }
 }
 
@@ -925,7 +942,7 @@ __global__ __launch_bounds__(512) void tsattn_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ v, const float* __restrict__ dout,
                                                          float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
                                                          int Tq, int Tk, int H, int W, int ws, int C, int nh, float p,
-                                                         const uint64_t* seed_dev, uint32_t site) {
+                                                         const uint64_t* seed_dev, uint32_t site, int p16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int hd = C / nh, hp = hd + 1, w2 = ws * ws;
   const int Lq = Tq * w2, Lk = Tk * w2, Lp = Lk + 1;
@@ -1011,7 +1028,7 @@ __global__ __launch_bounds__(512) void tsattn_bwd_kernel(const float* __restrict
       const int i = e / hd, d = e - i * hd;
       float a = 0.f;
       for (int j = 0; j < Lk; ++j) a += sds[i * Lp + j] * sk[j * hp + d];
-      dq[ts_row(n, Tq, H, W, ws, qh, qw, i0 + i) * C + h * hd + d] = a;
+      store1(dq, ts_row(n, Tq, H, W, ws, qh, qw, i0 + i) * C + h * hd + d, a, p16);
     }
     if (owner) {
 #pragma unroll 1
@@ -1034,8 +1051,8 @@ __global__ __launch_bounds__(512) void tsattn_bwd_kernel(const float* __restrict
       const int j = jg + u * jgroups;
       if (u < nu && j < Lk) {
         const int64_t g = ts_row(n, Tk, H, W, ws, qh, qw, j) * C + h * hd + od;
-        dk[g] = ak[u];
-        dv[g] = av[u];
+        store1(dk, g, ak[u], p16);
+        store1(dv, g, av[u], p16);
       }
     }
   }
@@ -1051,7 +1068,8 @@ static int tsattn_check(const char* who, int Nb, int Tq, int Tk, int H, int W, i
 
 extern "C" int vptr_tsattn_fwd(const float* q, const float* k, const float* v, float* o, int Nb, int Tq, int Tk, int H, int W,
                                int ws, int C, int nh, float dropout_p, const uint64_t* seed_dev, uint32_t site,
-                               vptr_stream_t stream) {
+                               int p16, vptr_stream_t stream) {
+  if (p16) VPTR_CHECK(C % 16 == 0, "tsattn_fwd: P16 outputs need C %% 16 == 0 (got %d)", C);
   if (tsattn_check("tsattn_fwd", Nb, Tq, Tk, H, W, ws, C, nh, dropout_p, seed_dev)) return -1;
   const int hd = C / nh, Lq = Tq * ws * ws, Lk = Tk * ws * ws;
   const size_t lds = sizeof(float) * ((size_t)(2 * Lk + TS_QC) * (hd + 1) + (size_t)TS_QC * (Lk + 1));
@@ -1060,14 +1078,15 @@ extern "C" int vptr_tsattn_fwd(const float* q, const float* k, const float* v, f
     (void)hipFuncSetAttribute((const void*)tsattn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int windows = Nb * (H / ws) * (W / ws);
   tsattn_fwd_kernel<<<dim3(windows, nh, cdiv(Lq, TS_QC)), 256, lds, (hipStream_t)stream>>>(q, k, v, o, Tq, Tk, H, W, ws, C, nh,
-                                                                                          dropout_p, seed_dev, site);
+                                                                                          dropout_p, seed_dev, site, p16);
   VPTR_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int vptr_tsattn_bwd(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,
                                float* dv, int Nb, int Tq, int Tk, int H, int W, int ws, int C, int nh, float dropout_p,
-                               const uint64_t* seed_dev, uint32_t site, vptr_stream_t stream) {
+                               const uint64_t* seed_dev, uint32_t site, int p16, vptr_stream_t stream) {
+  if (p16) VPTR_CHECK(C % 16 == 0, "tsattn_bwd: P16 outputs need C %% 16 == 0 (got %d)", C);
   if (tsattn_check("tsattn_bwd", Nb, Tq, Tk, H, W, ws, C, nh, dropout_p, seed_dev)) return -1;
   const int hd = C / nh, Lk = Tk * ws * ws;
   VPTR_CHECK(hd <= 512 && Lk <= TS_NACC * (512 / hd), "tsattn_bwd: Tk*ws*ws = %d exceeds %d keys per window", Lk, TS_NACC * (512 / hd));
@@ -1077,7 +1096,7 @@ extern "C" int vptr_tsattn_bwd(const float* q, const float* k, const float* v, c
     (void)hipFuncSetAttribute((const void*)tsattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int windows = Nb * (H / ws) * (W / ws);
   tsattn_bwd_kernel<<<dim3(windows, nh), 512, lds, (hipStream_t)stream>>>(q, k, v, dout, dq, dk, dv, Tq, Tk, H, W, ws, C, nh,
-                                                                         dropout_p, seed_dev, site);
+                                                                         dropout_p, seed_dev, site, p16);
   VPTR_LAUNCH_CHECK();
   return 0;
 }

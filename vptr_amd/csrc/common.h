@@ -51,6 +51,50 @@ __device__ __forceinline__ float vptr_drop_scale(uint64_t seed, uint32_t site, u
   return (h >= thr) ? 1.0f / (1.0f - p) : 0.0f;
 }
 
+// ---- P16 plane format (include/vptr_hip.h): 16-channel granules of 16 bf16 hi | 16 bf16 lo in the footprint of the fp32 tensor ----
+// two fp32 -> one dword of two bf16 (round-to-nearest-even): a single v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t vptr_pk_bf16(const float a, const float b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+  typedef __attribute__((ext_vector_type(2))) float f2_t;
+  const f2_t f = {a, b};
+  const bf2_t h = __builtin_convertvector(f, bf2_t);
+  return *reinterpret_cast<const uint32_t*>(&h);
+}
+// x = hi + lo + O(2^-17 |x|); hi = bf16(x), lo = bf16(x - hi).  6 VALU per pair.
+__device__ __forceinline__ void vptr_split2(const float a, const float b, uint32_t& hi, uint32_t& lo) {
+  hi = vptr_pk_bf16(a, b);
+  const float fa = __uint_as_float(hi << 16), fb = __uint_as_float(hi & 0xffff0000u);
+  lo = vptr_pk_bf16(a - fa, b - fb);
+}
+// store 4 consecutive channels starting at flat element index e (e % 4 == 0; row pitch % 16 == 0) of a P16 tensor
+__device__ __forceinline__ void vptr_p16_store4(unsigned char* __restrict__ base, const int64_t e, const float4 v) {
+  uint32_t h0, l0, h1, l1;
+  vptr_split2(v.x, v.y, h0, l0);
+  vptr_split2(v.z, v.w, h1, l1);
+  unsigned char* o = base + (e >> 4) * 64 + (e & 15) * 2;
+  *reinterpret_cast<uint2*>(o) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(o + 32) = make_uint2(l0, l1);
+}
+__device__ __forceinline__ void vptr_p16_store2(unsigned char* __restrict__ base, const int64_t e, const float a, const float b) {  // e even
+  uint32_t h, l;
+  vptr_split2(a, b, h, l);
+  unsigned char* o = base + (e >> 4) * 64 + (e & 15) * 2;
+  *reinterpret_cast<uint32_t*>(o) = h;
+  *reinterpret_cast<uint32_t*>(o + 32) = l;
+}
+__device__ __forceinline__ void vptr_p16_store1(unsigned char* __restrict__ base, const int64_t e, const float a) {
+  uint32_t h, l;
+  vptr_split2(a, 0.f, h, l);
+  unsigned char* o = base + (e >> 4) * 64 + (e & 15) * 2;
+  *reinterpret_cast<uint16_t*>(o) = (uint16_t)h;
+  *reinterpret_cast<uint16_t*>(o + 32) = (uint16_t)l;
+}
+// fp32 or P16 store of 4 consecutive channels at flat element index e into a tensor of either format
+__device__ __forceinline__ void vptr_store4_fmt(float* __restrict__ base, const int64_t e, const float4 v, const int p16) {
+  if (p16) vptr_p16_store4(reinterpret_cast<unsigned char*>(base), e, v);
+  else *reinterpret_cast<float4*>(base + e) = v;
+}
+
 // ---- activations --------------------------------------------------------------------------------
 // exact-erf GELU (nn.GELU()) and its derivative.  Phi(x) = 0.5 * (1 + erf(x / sqrt 2)) is evaluated with Abramowitz-Stegun
 // 7.1.26 (|error| <= 1.5e-7, far inside the fp32 parity budget): one v_rcp, one v_exp and five FMAs, and the exponential

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void act_bwd4_kernel(const float4* __restrict__ dy, const float4* __restrict__ h,
                                                        float4* __restrict__ dx, int rows, int C4, int act, float alpha,
                                                        const float* __restrict__ rowscale, int rs_div, int rs_mod, float p,
-                                                       const uint64_t* seed_dev, uint32_t site) {
+                                                       const uint64_t* seed_dev, uint32_t site, int out_p16) {
   uint64_t seed = 0;
   if (p > 0.f) seed = *seed_dev;
   const int64_t n = (int64_t)rows * C4;
@@ -110,23 +110,24 @@ __global__ __launch_bounds__(256) void act_bwd4_kernel(const float4* __restrict_
         else if (act == VPTR_ACT_LRELU) g[u] = hh[u] > 0.f ? g[u] : 0.2f * g[u];
       }
     }
-    dx[i] = make_float4(g[0], g[1], g[2], g[3]);
+    vptr_store4_fmt(reinterpret_cast<float*>(dx), i * 4, make_float4(g[0], g[1], g[2], g[3]), out_p16);
   }
 }
 extern "C" int vptr_act_bwd(const float* dy, const float* h, float* dx, int rows, int C, int act, float alpha,
                             const float* rowscale, int rs_div, int rs_mod, float dropout_p, const uint64_t* seed_dev,
-                            uint32_t site, vptr_stream_t stream) {
+                            uint32_t site, int out_p16, vptr_stream_t stream) {
   VPTR_CHECK(rows > 0 && C > 0, "act_bwd: empty input");
   if (act != VPTR_ACT_NONE) VPTR_CHECK(h != nullptr, "act_bwd: activation backward needs the saved pre-activation");
   if (rowscale) VPTR_CHECK(rs_div >= 1 && rs_mod >= 1, "act_bwd: rowscale needs rs_div, rs_mod >= 1");
   if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "act_bwd: dropout needs seed_dev");
   const int64_t n = (int64_t)rows * C;
   const bool al16 = ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(h)) & 15) == 0;
+  if (out_p16) VPTR_CHECK(C % 16 == 0 && al16 && (reinterpret_cast<uintptr_t>(dx) & 63) == 0, "act_bwd: a P16 output needs C %% 16 == 0 and aligned pointers");
   if (C % 4 == 0 && al16) {
     const int blocks4 = (int)hmin64((n / 4 + 255) / 256, 16384);
     act_bwd4_kernel<<<blocks4, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const float4*>(dy), reinterpret_cast<const float4*>(h),
                                                              reinterpret_cast<float4*>(dx), rows, C / 4, act, alpha, rowscale, rs_div,
-                                                             rs_mod, dropout_p, seed_dev, site);
+                                                             rs_mod, dropout_p, seed_dev, site, out_p16);
     VPTR_LAUNCH_CHECK();
     return 0;
   }

@@ -1,0 +1,447 @@
+// Split-bf16 MFMA GEMMs on "P16" operands (gfx950): the convert-once path of every nn.Linear forward, input gradient and
+// weight gradient of the VPTR transformers.
+//
+// P16 is the operand format: a [rows][C] matrix with the bytes, pitch and shape of its fp32 original (C % 16 == 0) in which
+// every 16-channel granule (64 bytes) holds 16 bf16 `hi` followed by 16 bf16 `lo`, x = hi + lo + O(2^-17 |x|).  The producer
+// of a tensor (LayerNorm, attention core, normalise + GELU, a GEMM epilogue, the optimizer for the weights) writes it once;
+// the GEMMs stage it with global_load_lds_dwordx4 -- no fp32 -> bf16 split and no ds_write in any main loop, which is what
+// bounded the register-staged kernels of gemm.hip.
+//
+//   nt  (vptr_gemm, a_mode = VPTR_A_P16, b_mode = VPTR_B_P16):  D[M,N] = epi( A[M,K] . B[N,K]^T ), both k-contiguous:
+//        forward (B = W planes) and input gradients (B = W^T planes); batch members and K segments as in gemm.hip.
+//   tn  (vptr_gemm_grouped, a_mode = VPTR_A_P16T, b_mode = VPTR_B_P16T):  dW[NG,KX] += alpha * G[T,NG]^T . X[T,KX], both
+//        operands TOKEN-major: the MFMA fragments (8 consecutive tokens per lane) come out of a [tokens][16 channels] LDS
+//        image through ds_read_b64_tr_b16; the bias gradient (column sums of G) rides in the otherwise idle 12th column
+//        fragment of the odd wave column as a product with a vector of ones.
+//
+// Tile 128 x 176 x 32, 8 waves (4 x 2) of 32 x 96, two 40 KB stages of 40 DMA pieces (1 KB = 8 rows x 128 B each: full
+// 128-byte lines on the global side), <= 128 VGPRs: two workgroups per CU.  tools/gemm_p16_probe.hip is the stand-alone
+// study (nt 290-315 TFLOP/s, tn 230-265 TFLOP/s at the model's shapes vs 200-237 / 159 for the register-staged kernels).
+#include "gemm_shared.h"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+constexpr int P16_STAGE = 40 * 1024;  // 16 pieces of A + 24 pieces of B
+
+#define P16_GLDS(laddr, gptr) \
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(laddr)), "v"(gptr) : "memory")
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 -> P16 (one pass; used where no producer kernel can emit the format itself)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void to_p16_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    vptr_p16_store4(out, i * 4, v);   // C % 16 == 0: granules never straddle rows, so the flat element index addresses them
+  }
+}
+extern "C" int vptr_to_p16(const float* x, void* out, int64_t rows, int C, vptr_stream_t stream) {
+  VPTR_CHECK(x && out && rows > 0 && C > 0 && C % 16 == 0, "to_p16: C must be a positive multiple of 16 (got %d)", C);
+  VPTR_CHECK(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "to_p16: pointers must be 16-byte aligned");
+  const int64_t n4 = rows * C / 4;
+  to_p16_kernel<<<(unsigned)hmin64((n4 + 255) / 256, 16384), 256, 0, (hipStream_t)stream>>>(x, reinterpret_cast<unsigned char*>(out), n4);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight planes: W[N][K] fp32 -> Wp[N][K] P16 (forward operand) and WT[K][N] P16 (input-gradient operand), for a whole table of
+// weights in one launch (once per optimizer step: 2 x 473 MB written for the K64 transformer, ~0.3 ms).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void weight_planes_kernel(const vptr_wplane_entry* __restrict__ tab, const int* __restrict__ tile_start,
+                                                            int count) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.x;
+  int lo = 0, hi = count - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_start[mid] <= b) lo = mid;
+    else hi = mid - 1;
+  }
+  const vptr_wplane_entry e = tab[lo];
+  const int t = b - tile_start[lo], tk = (e.K + 31) >> 5;
+  const int n0 = (t / tk) * 32, k0 = (t % tk) * 32;
+  const int r = threadIdx.x >> 3, c = (threadIdx.x & 7) * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool ok = n0 + r < e.N && k0 + c < e.K;   // K % 16 == 0: a float4 is inside or outside as a whole
+  if (ok) {
+    v = *reinterpret_cast<const float4*>(e.W + (int64_t)(n0 + r) * e.ldw + k0 + c);
+    vptr_p16_store4(reinterpret_cast<unsigned char*>(e.Wp), (int64_t)(n0 + r) * e.K + k0 + c, v);
+  }
+  tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
+  __syncthreads();
+  if (k0 + r < e.K && n0 + c < e.N) {
+    const float4 w = make_float4(tile[c][r], tile[c + 1][r], tile[c + 2][r], tile[c + 3][r]);
+    vptr_p16_store4(reinterpret_cast<unsigned char*>(e.WT), (int64_t)(k0 + r) * e.N + n0 + c, w);
+  }
+}
+extern "C" int vptr_weight_planes(const vptr_wplane_entry* table_dev, const int* tile_start_dev, int count, int total_tiles,
+                                  vptr_stream_t stream) {
+  VPTR_CHECK(table_dev && tile_start_dev && count > 0 && total_tiles > 0, "weight_planes: bad arguments");
+  weight_planes_kernel<<<total_tiles, 256, 0, (hipStream_t)stream>>>(table_dev, tile_start_dev, count);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// nt kernel.  Stage: piece u < 16 = rows 8u .. 8u+7 of the A tile, piece 16 + v = rows 8v .. of the B tile; a piece row is the
+// 128 bytes of one K-step (two granules: hi16 | lo16 | hi16 | lo16), chunk c of row r at physical chunk c ^ ((r >> 1) & 7):
+// the 16 rows of a ds_read_b128 fragment read hit 16 different 16-byte bank groups.  The fragment of lane (lr, lq) is
+// k = 8 lq .. 8 lq + 7 of row lr: hi chunk (lq >> 1) * 4 + (lq & 1), lo chunk = hi chunk + 2.
+// K % 32 == 16: the last step's second granule does not exist; its DMA lanes re-fetch the first one (always valid memory)
+// and the A fragments of lanes lq >= 2 are zeroed.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GNT, 4) void vptr_gemm_p16_kernel(const vptr_gemm_desc p, const int epi_rows) {
+  constexpr int NFN = 11, BN = 176;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lq = lane >> 4;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles = tiles_n * ((p.M + GBM - 1) / GBM);
+  const int lg = xcd_logical_block();
+  const int grp = lg / tiles, tile = lg - grp * tiles;
+  const Member mb = member_of(p, p.batch > 1 ? grp : 0);
+  const int m0 = (tile / tiles_n) * GBM, n0 = (tile % tiles_n) * BN;
+  const int nk = (p.K + 31) >> 5;
+  const bool ktail = (p.K & 16) != 0;
+  const int nseg = p.ksegs > 1 ? p.ksegs : 1;
+  const int64_t pa = p.lda * 4, pb = p.ldb * 4;
+  const unsigned char* Ab = reinterpret_cast<const unsigned char*>(mb.A);
+  const unsigned char* Bb = reinterpret_cast<const unsigned char*>(mb.B);
+  // K segments: byte offsets of segment s relative to segment 0 (plain integers, see KSEG_OFFSETS in gemm.hip)
+  const int64_t sA1 = nseg > 1 ? (p.A_x1 - p.A) * 4 : 0, sA2 = nseg > 2 ? (p.A_x2 - p.A) * 4 : 0;
+  const int64_t sB1 = nseg > 1 ? (p.B_x1 - p.B) * 4 : 0, sB2 = nseg > 2 ? (p.B_x2 - p.B) * 4 : 0;
+
+  const unsigned char* srcA[2];
+  const unsigned char* srcB[3];
+  int tadj;   // this lane's chunk is in the second granule of a K-step: -64 in a tail step (the same for all its pieces)
+  {
+    const int pch = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int prow = (wave + 8 * i) * 8 + (lane >> 3);
+      const int c = pch ^ ((prow >> 1) & 7);
+      srcA[i] = Ab + (int64_t)min(m0 + prow, p.M - 1) * pa + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int prow = (wave + 8 * i) * 8 + (lane >> 3);
+      const int c = pch ^ ((prow >> 1) & 7);
+      srcB[i] = Bb + (int64_t)min(n0 + prow, p.N - 1) * pb + c * 16;
+    }
+    // rows 8u + (lane >> 3) with u = wave + 8 i: (prow >> 1) & 7 = ((lane >> 4) + 4 * wave) & 7 for every piece of this lane
+    const int c = pch ^ (((lane >> 4) + 4 * wave) & 7);
+    tadj = c >= 4 ? -64 : 0;
+  }
+  auto issue = [&](const int kt, const int stage) {
+    const int sg = (int)(kt >= nk) + (int)(kt >= 2 * nk);
+    const int kk = kt - sg * nk;
+    const int64_t oa = (sg == 0 ? (int64_t)0 : (sg == 1 ? sA1 : sA2)) + (int64_t)kk * 128 + ((ktail && kk == nk - 1) ? tadj : 0);
+    const int64_t ob = (sg == 0 ? (int64_t)0 : (sg == 1 ? sB1 : sB2)) + (int64_t)kk * 128 + ((ktail && kk == nk - 1) ? tadj : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) P16_GLDS((uint32_t)(stage * P16_STAGE + (wave + 8 * i) * 1024), srcA[i] + oa);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) P16_GLDS((uint32_t)(stage * P16_STAGE + 16384 + (wave + 8 * i) * 1024), srcB[i] + ob);
+  };
+
+  f32x4 acc[2][6];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int offAh[2], offBh[6];   // byte offsets of the hi fragments inside a stage; lo = chunk + 2
+  const int ch = (lq >> 1) * 4 + (lq & 1);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int r = wm * 32 + mi * 16 + lr, f = (r >> 1) & 7;
+    offAh[mi] = r * 128 + ((ch ^ f) << 4);
+  }
+#pragma unroll
+  for (int ni = 0; ni < 6; ++ni) {
+    const int r = (wn * 6 + ni) * 16 + lr, f = (r >> 1) & 7;
+    offBh[ni] = 16384 + r * 128 + ((ch ^ f) << 4);
+  }
+  // lo chunk = hi chunk + 2 under the XOR swizzle: (ch + 2) ^ f = (ch ^ f) ^ 2 because bit 1 of ch is clear
+  const int nkt = nk * nseg;
+  issue(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): step kt has landed (the only DMA in flight)
+    __syncthreads();                      // ... for every wave, and everyone is done reading the other stage
+    if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+    const unsigned char* st = p16_smem + (kt & 1) * P16_STAGE;
+    bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      ah[mi] = *reinterpret_cast<const bf16x8*>(st + offAh[mi]);
+      al[mi] = *reinterpret_cast<const bf16x8*>(st + (offAh[mi] ^ 32));
+    }
+    if (ktail) {
+      const int sg = (int)(kt >= nk) + (int)(kt >= 2 * nk);
+      if (kt - sg * nk == nk - 1 && lq >= 2) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          ah[mi] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          al[mi] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+      }
+    }
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) {
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(st + offBh[ni]);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(st + (offBh[ni] ^ 32));
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+      }
+    }
+  }
+  if ((epi_rows || p.d_p16) && !p.atomic && epi_vec_ok(p)) {
+    __syncthreads();  // the last stage is still being read by slower waves
+    gemm_epilogue_rows_halves<NFN>(p, mb, acc, reinterpret_cast<float*>(p16_smem), m0, n0, wm, wn, lr, lq, tid, true, false);
+  } else {
+    gemm_epilogue_serial<NFN>(p, mb, acc, m0, n0, wm, wn, lr, lq, true, p.atomic != 0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// tn kernel (grouped weight gradients).  Per K-step (32 tokens) and operand the stage holds, for every PAIR of granules of the
+// tile, 4 pieces of [8 tokens][128 B]; a piece is laid out as 4 mini-subtiles [8 tokens][16 channels] (g0 hi, g0 lo, g1 hi,
+// g1 lo; 256 B each, 32-byte channel rows): DMA lane L fetches chunk (L >> 4) * 2 + (L & 1) of token row (L & 15) >> 1 -- whole
+// 128-byte lines on the global side.  ds_read_b64_tr_b16 hands lane (i, q) of a 16-lane group the 4 values of channel i from
+// the 4 token rows whose addresses lanes 4j .. 4j+3 of the group supply; read j of lane group q takes token block j ^ (q & 1)
+// of piece q (so that the two groups served in one LDS cycle sit in different halves of the banks).  Both operands use the same
+// token <-> (lane group, element) map, which is all the MFMA's K index needs.
+// T % 32 != 0: the last step's DMA rows are clamped to the last token and the A fragments of tokens >= T are zeroed.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 p16_tr_frag(const unsigned char* st, const int off, const int rb0) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + off + rb0));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + off + (128 - rb0)));
+  const s16x8 c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, c);
+}
+
+__global__ __launch_bounds__(GNT, 4) void vptr_wgrad_p16_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
+                                                                const int count) {
+  constexpr int BN = 176;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
+  const int lg = xcd_logical_block();
+  int lo = 0, hi = count - 1;  // last g with tile_start[g] <= lg (workgroup-uniform scalar search)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_start[mid] <= lg) lo = mid;
+    else hi = mid - 1;
+  }
+  const vptr_gemm_desc& p = descs[lo];
+  const int NG = p.M, KX = p.N, T = p.K;   // D[NG][KX] += alpha * G[T][NG]^T . X[T][KX]
+  const int tile = lg - tile_start[lo];
+  const int tiles_n = (KX + BN - 1) / BN;
+  const int m0 = (tile / tiles_n) * GBM, n0 = (tile % tiles_n) * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lq = lane >> 4;
+  const int nk = (T + 31) >> 5;
+  const int64_t pg = p.lda * 4, px = p.ldb * 4;
+  const unsigned char* Gb = reinterpret_cast<const unsigned char*>(p.A);
+  const unsigned char* Xb = reinterpret_cast<const unsigned char*>(p.B);
+
+  // DMA pieces: u = wave + 8 i; A pieces u < 16: granule pair u >> 2, token block u & 3; B pieces v = u - 16 likewise
+  int colA[2], colB[3], trow[5];
+  {
+    const int ms = lane >> 4, half = lane & 1, t = (lane & 15) >> 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = wave + 8 * i;
+      const int gran = min((m0 >> 4) + (u >> 2) * 2 + (ms >> 1), (NG >> 4) - 1);
+      colA[i] = gran * 64 + (ms & 1) * 32 + half * 16;
+      trow[i] = (u & 3) * 8 + t;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int v = wave + 8 * i;
+      const int gran = min((n0 >> 4) + (v >> 2) * 2 + (ms >> 1), (KX >> 4) - 1);
+      colB[i] = gran * 64 + (ms & 1) * 32 + half * 16;
+      trow[2 + i] = (v & 3) * 8 + t;
+    }
+  }
+  auto issue = [&](const int kt, const int stage) {
+    const int t0 = kt * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      P16_GLDS((uint32_t)(stage * P16_STAGE + (wave + 8 * i) * 1024), Gb + (int64_t)min(t0 + trow[i], T - 1) * pg + colA[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      P16_GLDS((uint32_t)(stage * P16_STAGE + 16384 + (wave + 8 * i) * 1024), Xb + (int64_t)min(t0 + trow[2 + i], T - 1) * px + colB[i]);
+  };
+
+  f32x4 acc[2][6];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // fragment f (granule f of the operand's tile), plane pl: piece (f >> 1) * 4 + lq, mini-subtile (f & 1) * 2 + pl
+  const int lane_off = lq * 1024 + (lr >> 2) * 32 + (lr & 3) * 8;
+  const int rb0 = (lq & 1) * 128;
+  int offA[2], offB[6];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int f = wm * 2 + mi;
+    offA[mi] = (f >> 1) * 4096 + (f & 1) * 512 + lane_off;
+  }
+#pragma unroll
+  for (int ni = 0; ni < 6; ++ni) {
+    const int f = wn * 6 + ni;
+    offB[ni] = 16384 + (f >> 1) * 4096 + (f & 1) * 512 + lane_off;
+  }
+  // bias gradient: column tile 0 only, odd wave column, its 6th (otherwise idle) fragment multiplies by ones: acc[mi][5][r] =
+  // sum_t G[t][row] for every column of the fragment
+  const bool want_rowsum = p.a_rowsum != nullptr && n0 == 0 && wn == 1;   // wave-uniform
+  const __bf16 one = (__bf16)1.0f, zero = (__bf16)0.0f;
+  const bf16x8 ones = {one, one, one, one, one, one, one, one};
+  const bf16x8 zeros = {zero, zero, zero, zero, zero, zero, zero, zero};
+  const bool ttail = (T & 31) != 0;
+
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    const unsigned char* st = p16_smem + (kt & 1) * P16_STAGE;
+    bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      ah[mi] = p16_tr_frag(st, offA[mi], rb0);
+      al[mi] = p16_tr_frag(st, offA[mi] + 256, rb0);
+    }
+    if (ttail && kt == nk - 1) {   // workgroup-uniform: zero the A values of tokens beyond T
+      const int tv = T - kt * 32;  // valid tokens of this step
+      // element e of this lane: token 8 lq + 4 (j ^ (lq & 1)) + (e & 3), j = e >> 2
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int tok = 8 * lq + 4 * ((e >> 2) ^ (lq & 1)) + (e & 3);
+        if (tok >= tv) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) { ah[mi][e] = zero; al[mi][e] = zero; }
+        }
+      }
+    }
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) {
+      bf16x8 bh, bl;
+      if (ni == 5 && want_rowsum) {
+        bh = ones;
+        bl = zeros;
+      } else {
+        bh = p16_tr_frag(st, offB[ni], rb0);
+        bl = p16_tr_frag(st, offB[ni] + 256, rb0);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: D += alpha * acc (fp32 atomics into the gradient slab: the same weight may receive several contributions)
+  const float alpha = p.alpha;
+#pragma unroll
+  for (int ni = 0; ni < 6; ++ni) {
+    const int nf = wn * 6 + ni, col = n0 + nf * 16 + lr;
+    if (nf < 11 && col < KX) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm * 32 + mi * 16 + lq * 4 + r;
+          if (row < NG) {
+            float* dst = p.D + (int64_t)row * p.ldd + col;
+            if (p.atomic) unsafeAtomicAdd(dst, acc[mi][ni][r] * alpha);
+            else *dst = acc[mi][ni][r] * alpha;
+          }
+        }
+    }
+  }
+  if (want_rowsum && lr == 0) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 32 + mi * 16 + lq * 4 + r;
+        if (row < NG) unsafeAtomicAdd(p.a_rowsum + row, acc[mi][5][r] * alpha);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+static int p16_epi_rows_flag() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VPTR_GEMM_EPI_ROWS");
+    v = e ? atoi(e) : 3;
+  }
+  return v;
+}
+
+int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
+  VPTR_CHECK(d.a_mode == VPTR_A_P16 && d.b_mode == VPTR_B_P16, "vptr_gemm(p16): both operands must be P16 (a_mode %d, b_mode %d)", d.a_mode, d.b_mode);
+  VPTR_CHECK(d.K % 16 == 0 && d.lda % 16 == 0 && d.ldb % 16 == 0, "vptr_gemm(p16): K, lda, ldb must be multiples of 16 (K %d)", d.K);
+  VPTR_CHECK(d.split_k <= 1 && d.precision == 3 && !d.a_rowsum && !d.D_planes, "vptr_gemm(p16): split_k = 1, precision 3, no a_rowsum / D_planes");
+  if (d.alpha == 0.f) d.alpha = 1.f;
+  if (d.batch < 1) d.batch = 1;
+  if (d.ksegs < 1) d.ksegs = 1;
+  VPTR_CHECK(d.batch <= 3 && d.ksegs <= 3 && (d.batch == 1 || d.ksegs == 1), "vptr_gemm(p16): at most 3 batch members or 3 K segments");
+  uintptr_t bits = reinterpret_cast<uintptr_t>(d.A) | reinterpret_cast<uintptr_t>(d.B);
+  const int extra = (d.batch > 1 ? d.batch : d.ksegs) - 1;
+  if (extra >= 1) {
+    VPTR_CHECK(d.A_x1 && d.B_x1, "vptr_gemm(p16): member / segment 1 needs A_x1, B_x1");
+    bits |= reinterpret_cast<uintptr_t>(d.A_x1) | reinterpret_cast<uintptr_t>(d.B_x1);
+  }
+  if (extra >= 2) {
+    VPTR_CHECK(d.A_x2 && d.B_x2, "vptr_gemm(p16): member / segment 2 needs A_x2, B_x2");
+    bits |= reinterpret_cast<uintptr_t>(d.A_x2) | reinterpret_cast<uintptr_t>(d.B_x2);
+  }
+  VPTR_CHECK((bits & 63) == 0, "vptr_gemm(p16): operands must be 64-byte aligned (whole granules)");
+  if (d.batch > 1) {
+    VPTR_CHECK(d.D_x1 && (d.batch < 3 || d.D_x2) && !d.Dpre && !d.residual && !d.atomic, "vptr_gemm(p16): bad batch members");
+    if (d.alpha_x1 == 0.f) d.alpha_x1 = 1.f;
+    if (d.alpha_x2 == 0.f) d.alpha_x2 = 1.f;
+  }
+  if (d.rowscale) VPTR_CHECK(d.rs_div >= 1 && d.rs_mod >= 1, "vptr_gemm: rowscale needs rs_div, rs_mod >= 1");
+  if (d.dropout_p > 0.f) VPTR_CHECK(d.seed_dev != nullptr && d.dropout_p < 1.f, "vptr_gemm: dropout needs seed_dev and p < 1");
+  if (d.d_p16)
+    VPTR_CHECK(!d.atomic && d.N % 16 == 0 && d.ldd % 16 == 0 && (d.ldr & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(d.D) | reinterpret_cast<uintptr_t>(d.D_x1) | reinterpret_cast<uintptr_t>(d.D_x2)) & 63) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(d.residual) | reinterpret_cast<uintptr_t>(d.bias) | reinterpret_cast<uintptr_t>(d.colscale) |
+                     reinterpret_cast<uintptr_t>(d.Dpre) | reinterpret_cast<uintptr_t>(d.bias_x1) | reinterpret_cast<uintptr_t>(d.bias_x2)) & 15) == 0,
+               "vptr_gemm(p16): a P16 output needs N, ldd multiples of 16, 64-byte aligned D and 16-byte aligned epilogue operands, no atomics");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess) {
+      vptr_set_error("vptr_gemm(p16): cannot reserve %d bytes of LDS", 2 * P16_STAGE);
+      return -1;
+    }
+    attr_set = true;
+  }
+  const int tiles = ((d.M + GBM - 1) / GBM) * ((d.N + 175) / 176) * d.batch;
+  vptr_gemm_p16_kernel<<<tiles, GNT, 2 * P16_STAGE, st>>>(d, p16_epi_rows_flag() & 2);
+  return 0;
+}
+
+int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* descs_dev, const int* tile_start_dev, int count, int total_tiles,
+                          hipStream_t st) {
+  VPTR_CHECK(proto->b_mode == VPTR_B_P16T && proto->precision == 3, "vptr_gemm_grouped(p16): both operands token-major P16, precision 3");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess) {
+      vptr_set_error("vptr_gemm_grouped(p16): cannot reserve %d bytes of LDS", 2 * P16_STAGE);
+      return -1;
+    }
+    attr_set = true;
+  }
+  vptr_wgrad_p16_kernel<<<total_tiles, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count);
+  return 0;
+}

@@ -11,7 +11,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, check, lib, ptr, stream
+from ._lib import GemmDesc, WPlaneEntry, check, lib, ptr, stream
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU = 0, 1, 2, 3
 PAD_MODES = {"zero": 0, "reflect": 1, "replicate": 2}
@@ -28,6 +28,9 @@ class _Config:
     gemm_precision = 3
     group_wgrads = True
     weights_frozen = False  # set by the frozen_weights scope only
+    # P16 ("convert once") operands for every nn.Linear-shaped GEMM whose dimensions are multiples of 16 (precision 3 only):
+    # the GEMMs stage pre-split bf16 hi / lo granules with global_load_lds instead of splitting fp32 in their main loops
+    use_p16 = os.environ.get("VPTR_P16", "1") != "0"
 
 
 config = _Config()
@@ -90,7 +93,7 @@ def _c(t):
 def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None, colscale=None, alpha=1.0, act=ACT_NONE,
              Dpre=None, rowscale=None, rs_div=1, rs_mod=1, dropout_p=0.0, site=0, residual=None, act_after=False,
              atomic=False, split_k=1, conv=None, precision=None, seed=None, a_rowsum=None, batch_extra=None, kseg_extra=None,
-             planes_out=None):
+             planes_out=None, d_p16=False):
     """One vptr_gemm launch.  batch_extra = [(A, B, D, bias, alpha), ...] adds up to two same-shaped independent problems to
     the grid; kseg_extra = [(A, B), ...] adds up to two K-segments accumulated into the same D (include/vptr_hip.h)."""
     d = GemmDesc()
@@ -106,6 +109,7 @@ def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None
             setattr(d, "A_x%d" % i, A2.data_ptr()), setattr(d, "B_x%d" % i, B2.data_ptr())
     d.a_rowsum = ptr(a_rowsum)
     d.D_planes = ptr(planes_out)
+    d.d_p16 = int(bool(d_p16))
     d.A, d.B, d.D, d.Dpre = ptr(A), ptr(B), ptr(D), ptr(Dpre)
     d.lda = lda if lda is not None else (A.stride(0) if a_mode != 2 else 0)
     d.ldb = ldb if ldb is not None else B.stride(0)
@@ -158,6 +162,140 @@ def gemm_nfn(N):
     return best[1]
 
 
+# ---- P16 operands ("convert once") --------------------------------------------------------------------------------------
+# A P16 tensor is an ordinary float32 torch tensor of the logical shape [rows, C] whose BYTES are 16-channel granules of
+# 16 bf16 hi | 16 bf16 lo (include/vptr_hip.h).  Same shape, dtype and size as the fp32 tensor it replaces, so it travels through
+# autograd unchanged; which tensors are P16 is static knowledge of the call sites (`*_p16` flags), never inferred.
+A_P16, B_P16, A_P16T, B_P16T = 5, 3, 6, 4
+
+
+def p16_ok(*dims):
+    """True when GEMM dimensions qualify for the P16 kernels (multiples of 16, split-bf16 precision, feature enabled)"""
+    return config.use_p16 and config.gemm_precision == 3 and all(d % 16 == 0 for d in dims)
+
+
+def to_p16(x):
+    """fp32 [rows, C] -> P16 (one HBM pass; producers that can write P16 themselves make this unnecessary)"""
+    x = _c(x)
+    out = torch.empty_like(x)
+    rows = x.numel() // x.shape[-1]
+    check(lib.vptr_to_p16(ptr(x), ptr(out), rows, x.shape[-1], stream()), "vptr_to_p16")
+    return out
+
+
+def p16_decode(t):
+    """P16 -> fp32 values with plain torch ops (tests / debugging only)"""
+    C = t.shape[-1]
+    b = t.contiguous().view(torch.bfloat16).reshape(-1, C // 16, 2, 16).float()
+    return (b[:, :, 0] + b[:, :, 1]).reshape(t.shape)
+
+
+class WeightPlanes:
+    """P16 images of a set of nn.Linear-shaped weights ([N, K] views with N, K multiples of 16), rebuilt by ONE launch
+    (vptr_weight_planes) after every optimizer step: Wp [N, K] for the forward GEMMs and WT [K, N] for the input-gradient GEMMs."""
+
+    def __init__(self, weights):
+        self.weights = [w for w in weights]
+        dev = self.weights[0].device
+        total = sum(w.shape[0] * w.shape[1] for w in self.weights)
+        self.wp = torch.empty(total, device=dev, dtype=torch.float32)
+        self.wt = torch.empty(total, device=dev, dtype=torch.float32)
+        ents = (WPlaneEntry * len(self.weights))()
+        starts, off, tiles = [], 0, 0
+        self.index = []   # (ptr, nbytes, offset, N, K, weight tensor)
+        for i, w in enumerate(self.weights):
+            N, K = w.shape
+            if N % 16 or K % 16 or w.stride(1) != 1:
+                raise RuntimeError("WeightPlanes: weight %d of shape %s is not P16-eligible" % (i, tuple(w.shape)))
+            e = ents[i]
+            e.W, e.ldw, e.N, e.K = w.data_ptr(), w.stride(0), N, K
+            e.Wp = self.wp.data_ptr() + off * 4
+            e.WT = self.wt.data_ptr() + off * 4
+            self.index.append((w.data_ptr(), N * w.stride(0) * 4, off, N, K, w))
+            starts.append(tiles)
+            tiles += ((N + 31) // 32) * ((K + 31) // 32)
+            off += N * K
+        import struct
+        self.table = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(dev)
+        self.starts = torch.frombuffer(bytearray(struct.pack("%di" % len(starts), *starts)), dtype=torch.uint8).to(dev)
+        self.tiles, self.versions = tiles, None
+        self.index.sort(key=lambda t: t[0])
+        self.refresh()
+
+    def refresh(self):
+        check(lib.vptr_weight_planes(ptr(self.table), ptr(self.starts), len(self.weights), self.tiles, stream()), "vptr_weight_planes")
+        self.versions = [t[5]._version for t in self.index]
+
+    def lookup(self, W):
+        """(Wp, ld, WT, ld) for W = a registered weight or a whole-row slice of one, or None; stale planes (the weight changed
+        through torch since the last refresh) are rebuilt first"""
+        p = W.data_ptr()
+        for i, (base, nbytes, off, N, K, w) in enumerate(self.index):
+            if base <= p < base + nbytes:
+                if w.stride(0) != K or W.shape[1] != K or W.stride(0) != K or (p - base) % (K * 4):
+                    return None
+                if self.versions[i] != w._version:
+                    self.refresh()
+                r0, n = (p - base) // (K * 4), W.shape[0]
+                if r0 % 16 or n % 16:
+                    return None
+                wp = self.wp[off + r0 * K: off + (r0 + n) * K].view(n, K)
+                wt = self.wt[off: off + N * K].view(K, N)[:, r0:r0 + n]
+                return wp, K, wt, N
+        return None
+
+
+_wplane_stores = []      # weakrefs of WeightPlanes registered by the trainers (FlatAdamW slabs)
+_wplane_cache = {}       # (ptr, version, N, K, ld) -> (WeightPlanes, bytes): weights outside any store (eval / tests), LRU by bytes
+_WPLANE_CACHE_BYTES = 3 << 30
+
+
+def register_weight_planes(store):
+    import weakref
+    _wplane_stores.append(weakref.ref(store))
+
+
+def weight_planes_for(W):
+    """P16 planes (Wp [N,K], ld, WT [K,N] view, ld) of a Linear-shaped weight: from a trainer's store, else from a small cache"""
+    for ref in list(_wplane_stores):
+        st = ref()
+        if st is None:
+            _wplane_stores.remove(ref)
+            continue
+        hit = st.lookup(W)
+        if hit is not None:
+            return hit
+    key = (W.data_ptr(), W._version, W.shape[0], W.shape[1], W.stride(0))
+    hit = _wplane_cache.get(key)
+    if hit is None:
+        with torch.no_grad():
+            st = WeightPlanes([W.detach()])
+        nbytes = 8 * W.shape[0] * W.shape[1]
+        tot = nbytes + sum(v[1] for v in _wplane_cache.values())
+        for k in list(_wplane_cache):      # insertion order = least recently built first
+            if tot <= _WPLANE_CACHE_BYTES:
+                break
+            tot -= _wplane_cache.pop(k)[1]
+        hit = _wplane_cache[key] = (st, nbytes)
+    N, K = W.shape
+    return hit[0].wp.view(N, K), K, hit[0].wt.view(K, N), N
+
+
+def linear_weights_of(params):
+    """the nn.Linear-shaped members of a parameter list ([N, K] or 1x1-conv [N, K, 1, 1]; N, K multiples of 16) as [N, K] views"""
+    out = []
+    for p in params:
+        if p.dim() == 4 and p.shape[2] == 1 and p.shape[3] == 1 and p.is_contiguous():
+            w = p.detach().view(p.shape[0], p.shape[1])
+        elif p.dim() == 2 and p.is_contiguous():
+            w = p.detach()
+        else:
+            continue
+        if w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0:
+            out.append(w)
+    return out
+
+
 # ---- deferred, grouped weight gradients ---------------------------------------------------------------------------------
 # dW = dY^T . X of one nn.Linear is 12-60 output tiles with K = all tokens: alone it cannot fill 256 CUs without ~30
 # K-splits (each paying a prologue and a 90 KB atomic epilogue; measured 80 TFLOP/s).  When the weight's gradient lives
@@ -167,10 +305,10 @@ def gemm_nfn(N):
 _wgrad_q = []
 
 
-def defer_wgrad(g, x, dW, N, K, M, db=None, alpha=1.0):
+def defer_wgrad(g, x, dW, N, K, M, db=None, alpha=1.0, p16=False):
     """record dW[N,K] += g[M,N]^T . x[M,K] (dW, and db if given, must be views of a flat gradient slab); with db the bias
-    gradient db[N] += column sums of g rides on the same launch (vptr_gemm_desc::a_rowsum)"""
-    _wgrad_q.append((g, x, dW, N, K, M, config.gemm_precision, db, float(alpha)))
+    gradient db[N] += column sums of g rides on the same launch (vptr_gemm_desc::a_rowsum).  p16: g and x are P16 tensors."""
+    _wgrad_q.append((g, x, dW, N, K, M, config.gemm_precision, db, float(alpha), bool(p16)))
     # one end-of-backward callback per recorded call: flush_wgrads is idempotent, and registering every time stays correct
     # when an earlier backward died before its callbacks ran (a "callback already queued" flag would then be stale)
     try:
@@ -238,20 +376,22 @@ def _to_device_async(host_bytes, dev):
 def _launch_wgrad_group(its):
     groups = {}
     for it in its:
-        groups.setdefault((int(lib.vptr_gemm_tile_cols(it[4])), it[6]), []).append(it)
-    for (cols, prec), grp in groups.items():
+        p16 = it[9]
+        groups.setdefault((176 if p16 else int(lib.vptr_gemm_tile_cols(it[4])), it[6], p16), []).append(it)
+    for (cols, prec, p16), grp in groups.items():
         n = len(grp)
         descs = (GemmDesc * n)()
         starts = []
         total = 0
         flops = 0.0
-        for i, (g, x, dW, N, K, M, _, db, alpha) in enumerate(grp):
+        for i, (g, x, dW, N, K, M, _, db, alpha, _p) in enumerate(grp):
             d = descs[i]
             d.A, d.B, d.D = ptr(g), ptr(x), ptr(dW)
             d.a_rowsum = ptr(db)
             d.lda, d.ldb, d.ldd = g.stride(0), x.stride(0), dW.stride(0)
             d.M, d.N, d.K = N, K, M
-            d.a_mode, d.b_mode, d.precision, d.split_k, d.atomic, d.alpha = 1, 1, prec, 1, 1, alpha
+            d.a_mode, d.b_mode = (A_P16T, B_P16T) if p16 else (1, 1)
+            d.precision, d.split_k, d.atomic, d.alpha = prec, 1, 1, alpha
             starts.append(total)
             total += ((N + 127) // 128) * ((K + cols - 1) // cols)
             flops += 2.0 * M * N * K
@@ -266,7 +406,7 @@ def _launch_wgrad_group(its):
         check(lib.vptr_gemm_grouped(ctypes.byref(descs[0]), ptr(raw), ptr(st), n, total, stream()), "vptr_gemm_grouped")
         if prof is not None:
             e1.record()
-            prof.append(((cols // 16, prec, 1, 1, "grouped"), flops, e0, e1))
+            prof.append(((cols // 16, prec, 6 if p16 else 1, 4 if p16 else 1, "grouped"), flops, e0, e1))
 
 
 def flush_wgrads(chunks=1, on_chunk=None):
@@ -341,7 +481,7 @@ def flat_grad_for(t):
     return None
 
 
-def _linear_param_grads(g, x, W, bias_ref, need_w, need_b, alpha=1.0):
+def _linear_param_grads(g, x, W, bias_ref, need_w, need_b, alpha=1.0, p16=False):
     """dW[N,K] (+)= alpha * g^T . x and db (+)= alpha * column sums of g for y = x W^T + b with g = dL/dy [M, N].  With a flat
     gradient slab the products are recorded for the grouped end-of-backward launch (which also takes the bias gradient from
     its A staging registers) and (None, None) is returned; otherwise fresh tensors are."""
@@ -353,8 +493,21 @@ def _linear_param_grads(g, x, W, bias_ref, need_w, need_b, alpha=1.0):
         slab = flat_grad_for(W)          # accumulate straight into the flat gradient slab when there is one
         if slab is not None and config.group_wgrads:
             bslab = flat_grad_for(bias_ref) if (bias_ref is not None and need_b) else None
-            defer_wgrad(g, x, slab, N, K, M, db=bslab, alpha=alpha)   # grouped at the end of backward
+            defer_wgrad(g, x, slab, N, K, M, db=bslab, alpha=alpha, p16=p16)   # grouped at the end of backward
             bias_done = bslab is not None
+        elif p16:
+            # P16 operands outside a flat slab (tests, stand-alone modules): the token-major kernel as a group of one
+            dW = slab if slab is not None else torch.zeros((N, K), device=g.device, dtype=torch.float32)
+            if bias_ref is not None and need_b:
+                bs = flat_grad_for(bias_ref)
+                db = bs if bs is not None else torch.zeros((N,), device=g.device, dtype=torch.float32)
+                bias_done = True
+            _launch_wgrad_group([(g, x, dW, N, K, M, 3, db, float(alpha), True)])
+            if slab is not None:
+                dW = None
+            if db is not None and flat_grad_for(bias_ref) is not None:
+                db = None
+            return dW, db
         else:
             if alpha != 1.0:
                 raise RuntimeError("an output scale is only folded into grouped weight gradients")
@@ -364,8 +517,8 @@ def _linear_param_grads(g, x, W, bias_ref, need_w, need_b, alpha=1.0):
             if slab is not None:
                 dW = None
     if bias_ref is not None and need_b and not bias_done:
-        if alpha != 1.0:
-            raise RuntimeError("an output scale is only folded into grouped weight gradients")
+        if alpha != 1.0 or p16:
+            raise RuntimeError("a bias gradient without its weight gradient is not available for scaled / P16 gradients")
         slab = flat_grad_for(bias_ref)
         db = slab if slab is not None else torch.zeros((N,), device=g.device, dtype=torch.float32)
         check(lib.vptr_colsum(ptr(g), ptr(db), M, N, stream()), "vptr_colsum")
@@ -378,33 +531,49 @@ class _LinearFn(torch.autograd.Function):
     """y = dropout(rowscale * act((x W^T + b) * alpha)) + residual   -- one GEMM launch with a fused epilogue.
 
     Replaces F.linear call sites (MultiHeadAttentionRPE.py:543-545,687-688; VidHRFormer_modules.py:87-89,190-192)
-    and the 1x1 convs of MlpDWBN (:430,:436).  Backward: epilogue-gradient kernel, dgrad GEMM (B k-strided), wgrad GEMM
-    (both operands k-strided, split-K with fp32 atomics), bias gradient by column sum.
+    and the 1x1 convs of MlpDWBN (:430,:436).  Backward: epilogue-gradient kernel, input-gradient GEMM, weight (+ bias)
+    gradient recorded for the grouped end-of-backward launch.
+
+    P16 path (all of K, N multiples of 16, precision 3): operands are P16 tensors staged by DMA.  x_p16: x already is P16 (its
+    producer wrote it); otherwise one conversion pass.  out_p16: y is written as P16 (it only feeds another GEMM).  dy_p16: the
+    incoming gradient is P16 (its producer wrote it for this node alone; no epilogue terms may need a gradient pass then).
     """
 
     @staticmethod
-    def forward(ctx, x, W, b, residual, rowscale, alpha, act, rs_div, rs_mod, dropout_p, site):
+    def forward(ctx, x, W, b, residual, rowscale, alpha, act, rs_div, rs_mod, dropout_p, site, x_p16, out_p16, dy_p16):
         _lib.require_cuda(x, W)
         if act == ACT_RELU and (residual is not None or rowscale is not None or dropout_p > 0):
             raise RuntimeError("linear: a ReLU epilogue cannot be combined with residual/rowscale/dropout")
         x, W = _c(x), _c(W)
         M, K = x.shape
         N = W.shape[0]
+        use = p16_ok(K, N)
+        if (x_p16 or out_p16 or dy_p16) and not use:
+            raise RuntimeError("linear: P16 operands need K, N multiples of 16 and the split-bf16 precision (K %d, N %d)" % (K, N))
         y = torch.empty((M, N), device=x.device, dtype=torch.float32)
         pre = torch.empty_like(y) if act == ACT_GELU else None
         res = _c(residual) if residual is not None else None
         ctx.seed = seed_tensor(x.device) if dropout_p > 0 else None
-        gemm_raw(x, W, y, M, N, K, 0, 0, bias=b, alpha=alpha, act=act, Dpre=pre, rowscale=rowscale, rs_div=rs_div,
-                 rs_mod=rs_mod, dropout_p=dropout_p, site=site, residual=res, seed=ctx.seed)
-        ctx.save_for_backward(x, W, pre if act == ACT_GELU else (y if act == ACT_RELU else None), rowscale)
-        ctx.cfg = (alpha, act, rs_div, rs_mod, dropout_p, site, b is not None, residual is not None)
+        if use:
+            xs = x if x_p16 else to_p16(x)
+            Wp, ldw, _, _ = weight_planes_for(W)
+            gemm_raw(xs, Wp, y, M, N, K, A_P16, B_P16, lda=K, ldb=ldw, bias=b, alpha=alpha, act=act, Dpre=pre, rowscale=rowscale,
+                     rs_div=rs_div, rs_mod=rs_mod, dropout_p=dropout_p, site=site, residual=res, seed=ctx.seed, d_p16=out_p16)
+        else:
+            xs = x
+            gemm_raw(x, W, y, M, N, K, 0, 0, bias=b, alpha=alpha, act=act, Dpre=pre, rowscale=rowscale, rs_div=rs_div,
+                     rs_mod=rs_mod, dropout_p=dropout_p, site=site, residual=res, seed=ctx.seed)
+        if act == ACT_RELU and out_p16:
+            raise RuntimeError("linear: a ReLU epilogue saves its output for backward and cannot write it as P16")
+        ctx.save_for_backward(xs, W, pre if act == ACT_GELU else (y if act == ACT_RELU else None), rowscale)
+        ctx.cfg = (alpha, act, rs_div, rs_mod, dropout_p, site, b is not None, residual is not None, use, dy_p16)
         ctx.bias_ref = b.detach() if b is not None else None  # only its address is used (flat gradient slab lookup)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, W, h, rowscale = ctx.saved_tensors
-        alpha, act, rs_div, rs_mod, p, site, has_b, has_res = ctx.cfg
+        alpha, act, rs_div, rs_mod, p, site, has_b, has_res, use, dy_p16 = ctx.cfg
         dy = _c(dy)
         M, K = x.shape
         N = W.shape[0]
@@ -418,23 +587,37 @@ class _LinearFn(torch.autograd.Function):
         if (act != ACT_NONE or alpha != 1.0 or rowscale is not None or p > 0) and not fold_alpha:
             if act == ACT_RELU and (p > 0 or rowscale is not None):
                 raise RuntimeError("ReLU epilogue with dropout/rowscale is not differentiable from its output")
+            if dy_p16:
+                raise RuntimeError("linear: a P16 gradient cannot pass through an activation / dropout / scale epilogue")
             g = torch.empty_like(dy)
             check(lib.vptr_act_bwd(ptr(dy), ptr(h), ptr(g), M, N, act, alpha, ptr(rowscale), rs_div, rs_mod, p,
-                                   ptr(ctx.seed), site, stream()), "vptr_act_bwd")
+                                   ptr(ctx.seed), site, int(use), stream()), "vptr_act_bwd")
+        elif use and not dy_p16:
+            g = to_p16(dy)
         else:
             g = dy
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), device=dy.device, dtype=torch.float32)
-            gemm_raw(g, W, dx, M, K, N, 0, 1, alpha=galpha)        # dx[M,K] = g[M,N] . W[N,K]
-        dW, db = _linear_param_grads(g, x, W, ctx.bias_ref if has_b else None, ctx.needs_input_grad[1], ctx.needs_input_grad[2], galpha)
-        dres = dy if (has_res and ctx.needs_input_grad[3]) else None
-        return dx, dW, db, dres, None, None, None, None, None, None, None
+            if use:
+                _, _, WT, ldt = weight_planes_for(W)
+                gemm_raw(g, WT, dx, M, K, N, A_P16, B_P16, lda=N, ldb=ldt, alpha=galpha)   # dx[M,K] = g[M,N] . W[N,K]
+            else:
+                gemm_raw(g, W, dx, M, K, N, 0, 1, alpha=galpha)
+        dW, db = _linear_param_grads(g, x, W, ctx.bias_ref if has_b else None, ctx.needs_input_grad[1], ctx.needs_input_grad[2], galpha,
+                                     p16=use)
+        dres = None
+        if has_res and ctx.needs_input_grad[3]:
+            if dy_p16:
+                raise RuntimeError("linear: the residual branch needs the fp32 gradient")
+            dres = dy
+        return (dx, dW, db, dres) + (None,) * 10
 
 
-def linear(x, W, b=None, residual=None, alpha=1.0, act=ACT_NONE, rowscale=None, rs_div=1, rs_mod=1, dropout_p=0.0, site=0):
+def linear(x, W, b=None, residual=None, alpha=1.0, act=ACT_NONE, rowscale=None, rs_div=1, rs_mod=1, dropout_p=0.0, site=0,
+           x_p16=False, out_p16=False, dy_p16=False):
     return _LinearFn.apply(x, W, b, residual, rowscale, float(alpha), int(act), int(rs_div), int(rs_mod), float(dropout_p),
-                           int(site))
+                           int(site), bool(x_p16), bool(out_p16), bool(dy_p16))
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -544,7 +727,7 @@ class _WinAttnFn(torch.autograd.Function):
         o = torch.empty_like(q)
         ctx.seed = seed_tensor(q.device) if p > 0 else None
         check(lib.vptr_winattn_fwd(ptr(q), ptr(k), ptr(v), ptr(table), ptr(rel_index), ptr(o), B, H, W, C, nh, ws, p,
-                                   ptr(ctx.seed), site, stream()), "vptr_winattn_fwd")
+                                   ptr(ctx.seed), site, 0, stream()), "vptr_winattn_fwd")
         ctx.save_for_backward(q, k, v, table, rel_index)
         ctx.cfg = (B, H, W, nh, ws, p, site)
         return o
@@ -558,7 +741,7 @@ class _WinAttnFn(torch.autograd.Function):
         slab = flat_grad_for(table)
         dtable = slab if slab is not None else (torch.zeros_like(table) if table is not None else None)
         check(lib.vptr_winattn_bwd(ptr(q), ptr(k), ptr(v), ptr(table), ptr(rel_index), ptr(do), ptr(dq), ptr(dk), ptr(dv),
-                                   ptr(dtable), B, H, W, q.shape[1], nh, ws, p, ptr(ctx.seed), site, 1.0, stream()),
+                                   ptr(dtable), B, H, W, q.shape[1], nh, ws, p, ptr(ctx.seed), site, 1.0, 0, stream()),
               "vptr_winattn_bwd")
         if slab is not None:
             dtable = None
@@ -578,7 +761,7 @@ class _TAttnFn(torch.autograd.Function):
         o = torch.empty_like(q)
         ctx.seed = seed_tensor(q.device) if p > 0 else None
         check(lib.vptr_tattn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), Nb, Tq, Tk, HW, C, nh, causal, p, ptr(ctx.seed), site,
-                                 stream()), "vptr_tattn_fwd")
+                                 0, stream()), "vptr_tattn_fwd")
         ctx.save_for_backward(q, k, v)
         ctx.cfg = (Nb, Tq, Tk, HW, nh, causal, p, site)
         return o
@@ -590,7 +773,7 @@ class _TAttnFn(torch.autograd.Function):
         do = _c(do)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         check(lib.vptr_tattn_bwd(ptr(q), ptr(k), ptr(v), ptr(do), ptr(dq), ptr(dk), ptr(dv), Nb, Tq, Tk, HW, q.shape[1], nh,
-                                 causal, p, ptr(ctx.seed), site, 1.0, stream()), "vptr_tattn_bwd")
+                                 causal, p, ptr(ctx.seed), site, 1.0, 0, stream()), "vptr_tattn_bwd")
         return dq, dk, dv, None, None, None, None, None, None, None, None
 
 
@@ -616,7 +799,7 @@ class _ProjAttnFn(torch.autograd.Function):
     (xq = xv + a constant table): the whole input gradient is then returned for xq and None for xv."""
 
     @staticmethod
-    def forward(ctx, xq, xk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, kind, geom, nh, p, site, same_qk, same_v, merge_v):
+    def forward(ctx, xq, xk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, kind, geom, nh, p, site, same_qk, same_v, merge_v, x_p16, o_p16):
         _lib.require_cuda(xq, xk, xv, Wq)
         xq, xk, xv = _c(xq), _c(xk), _c(xv)
         Wq, Wk, Wv = _c(Wq), _c(Wk), _c(Wv)
@@ -625,10 +808,28 @@ class _ProjAttnFn(torch.autograd.Function):
         N = Wq.shape[0]
         alpha = float(N // nh) ** -0.5
         dev = xq.device
+        use = p16_ok(K, N)
+        if (x_p16 or o_p16) and not use:
+            raise RuntimeError("attention: P16 operands need the embedding width to be a multiple of 16 (got %d)" % K)
         q = torch.empty((Mq, N), device=dev, dtype=torch.float32)
         k = torch.empty((Mk, N), device=dev, dtype=torch.float32)
         v = torch.empty((Mk, N), device=dev, dtype=torch.float32)
-        if Mq == Mk:
+        if use:
+            if not x_p16:   # one conversion pass per distinct input
+                cq = to_p16(xq)
+                ck = cq if same_qk else to_p16(xk)
+                cv = cq if same_v else to_p16(xv)
+                xq, xk, xv = cq, ck, cv
+            (Pq, lq, _, _), (Pk, lk, _, _), (Pv, lv, _, _) = weight_planes_for(Wq), weight_planes_for(Wk), weight_planes_for(Wv)
+            if not (lq == lk == lv):
+                raise RuntimeError("attention: q/k/v weight planes with different pitches")
+            if Mq == Mk:
+                gemm_raw(xq, Pq, q, Mq, N, K, A_P16, B_P16, lda=K, ldb=lq, bias=bq, alpha=alpha,
+                         batch_extra=[(xk, Pk, k, bk, 1.0), (xv, Pv, v, bv, 1.0)])
+            else:
+                gemm_raw(xq, Pq, q, Mq, N, K, A_P16, B_P16, lda=K, ldb=lq, bias=bq, alpha=alpha)
+                gemm_raw(xk, Pk, k, Mk, N, K, A_P16, B_P16, lda=K, ldb=lk, bias=bk, batch_extra=[(xv, Pv, v, bv, 1.0)])
+        elif Mq == Mk:
             gemm_raw(xq, Wq, q, Mq, N, K, 0, 0, bias=bq, alpha=alpha, batch_extra=[(xk, Wk, k, bk, 1.0), (xv, Wv, v, bv, 1.0)])
         else:
             gemm_raw(xq, Wq, q, Mq, N, K, 0, 0, bias=bq, alpha=alpha)
@@ -638,20 +839,20 @@ class _ProjAttnFn(torch.autograd.Function):
         if kind == 0:
             B, H, W, ws = geom
             check(lib.vptr_winattn_fwd(ptr(q), ptr(k), ptr(v), ptr(table), ptr(rel_index), ptr(o), B, H, W, N, nh, ws, p,
-                                       ptr(ctx.seed), site, stream()), "vptr_winattn_fwd")
+                                       ptr(ctx.seed), site, int(o_p16), stream()), "vptr_winattn_fwd")
         else:
             Nb, Tq, Tk, HW, causal = geom
             check(lib.vptr_tattn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), Nb, Tq, Tk, HW, N, nh, causal, p, ptr(ctx.seed), site,
-                                     stream()), "vptr_tattn_fwd")
+                                     int(o_p16), stream()), "vptr_tattn_fwd")
         ctx.save_for_backward(xq, xk, xv, Wq, Wk, Wv, q, k, v, table, rel_index)
         ctx.bias_refs = tuple(b.detach() if b is not None else None for b in (bq, bk, bv))
-        ctx.cfg = (kind, geom, nh, p, site, alpha, same_qk, same_v, merge_v)
+        ctx.cfg = (kind, geom, nh, p, site, alpha, same_qk, same_v, merge_v, use)
         return o
 
     @staticmethod
     def backward(ctx, do):
         xq, xk, xv, Wq, Wk, Wv, q, k, v, table, rel_index = ctx.saved_tensors
-        kind, geom, nh, p, site, alpha, same_qk, same_v, merge_v = ctx.cfg
+        kind, geom, nh, p, site, alpha, same_qk, same_v, merge_v, use = ctx.cfg
         do = _c(do)
         Mq, K = xq.shape
         Mk = xk.shape[0]
@@ -663,66 +864,75 @@ class _ProjAttnFn(torch.autograd.Function):
             slab = flat_grad_for(table) if table is not None else None
             dtable = slab if slab is not None else (torch.zeros_like(table) if table is not None else None)
             check(lib.vptr_winattn_bwd(ptr(q), ptr(k), ptr(v), ptr(table), ptr(rel_index), ptr(do), ptr(dq), ptr(dk), ptr(dv),
-                                       ptr(dtable), B, H, W, N, nh, ws, p, ptr(ctx.seed), site, alpha, stream()), "vptr_winattn_bwd")
+                                       ptr(dtable), B, H, W, N, nh, ws, p, ptr(ctx.seed), site, alpha, int(use), stream()), "vptr_winattn_bwd")
             if slab is not None:
                 dtable = None
         else:
             Nb, Tq, Tk, HW, causal = geom
             check(lib.vptr_tattn_bwd(ptr(q), ptr(k), ptr(v), ptr(do), ptr(dq), ptr(dk), ptr(dv), Nb, Tq, Tk, HW, N, nh, causal, p,
-                                     ptr(ctx.seed), site, alpha, stream()), "vptr_tattn_bwd")
+                                     ptr(ctx.seed), site, alpha, int(use), stream()), "vptr_tattn_bwd")
         need = ctx.needs_input_grad
         rq, rk, rv = ctx.bias_refs
-        dWq, dbq = _linear_param_grads(dq, xq, Wq, rq, need[3], need[4])
-        dWk, dbk = _linear_param_grads(dk, xk, Wk, rk, need[5], need[6])
-        dWv, dbv = _linear_param_grads(dv, xv, Wv, rv, need[7], need[8])
+        dWq, dbq = _linear_param_grads(dq, xq, Wq, rq, need[3], need[4], p16=use)
+        dWk, dbk = _linear_param_grads(dk, xk, Wk, rk, need[5], need[6], p16=use)
+        dWv, dbv = _linear_param_grads(dv, xv, Wv, rv, need[7], need[8], p16=use)
 
         def new(M):
             return torch.empty((M, K), device=do.device, dtype=torch.float32)
+        if use:
+            (_, _, Tq_, lt), (_, _, Tk_, _), (_, _, Tv_, _) = weight_planes_for(Wq), weight_planes_for(Wk), weight_planes_for(Wv)
+            am, bm, lda, ldb = A_P16, B_P16, N, lt
+        else:
+            Tq_, Tk_, Tv_ = Wq, Wk, Wv
+            am, bm, lda, ldb = 0, 1, None, None
+
+        def dgrad(g, WT, out, M, **kw):
+            return gemm_raw(g, WT, out, M, K, N, am, bm, lda=lda, ldb=ldb, **kw)
         dxq = dxk = dxv = None
         if same_qk and (same_v or merge_v):
             if need[0] or need[1] or need[2]:
-                dxq = gemm_raw(dq, Wq, new(Mq), Mq, K, N, 0, 1, kseg_extra=[(dk, Wk), (dv, Wv)])
+                dxq = dgrad(dq, Tq_, new(Mq), Mq, kseg_extra=[(dk, Tk_), (dv, Tv_)])
         elif same_qk:
             if need[0] or need[1]:
-                dxq = gemm_raw(dq, Wq, new(Mq), Mq, K, N, 0, 1, kseg_extra=[(dk, Wk)])
+                dxq = dgrad(dq, Tq_, new(Mq), Mq, kseg_extra=[(dk, Tk_)])
             if need[2]:
-                dxv = gemm_raw(dv, Wv, new(Mk), Mk, K, N, 0, 1)
+                dxv = dgrad(dv, Tv_, new(Mk), Mk)
         elif need[0] and need[1] and need[2] and Mq == Mk:
             dxq, dxk, dxv = new(Mq), new(Mk), new(Mk)
-            gemm_raw(dq, Wq, dxq, Mq, K, N, 0, 1, batch_extra=[(dk, Wk, dxk, None, 1.0), (dv, Wv, dxv, None, 1.0)])
+            dgrad(dq, Tq_, dxq, Mq, batch_extra=[(dk, Tk_, dxk, None, 1.0), (dv, Tv_, dxv, None, 1.0)])
         else:
             if need[0]:
-                dxq = gemm_raw(dq, Wq, new(Mq), Mq, K, N, 0, 1)
+                dxq = dgrad(dq, Tq_, new(Mq), Mq)
             if need[1] and need[2]:
                 dxk, dxv = new(Mk), new(Mk)
-                gemm_raw(dk, Wk, dxk, Mk, K, N, 0, 1, batch_extra=[(dv, Wv, dxv, None, 1.0)])
+                dgrad(dk, Tk_, dxk, Mk, batch_extra=[(dv, Tv_, dxv, None, 1.0)])
             elif need[1]:
-                dxk = gemm_raw(dk, Wk, new(Mk), Mk, K, N, 0, 1)
+                dxk = dgrad(dk, Tk_, new(Mk), Mk)
             elif need[2]:
-                dxv = gemm_raw(dv, Wv, new(Mk), Mk, K, N, 0, 1)
-        return (dxq, dxk, dxv, dWq, dbq, dWk, dbk, dWv, dbv, dtable) + (None,) * 9
+                dxv = dgrad(dv, Tv_, new(Mk), Mk)
+        return (dxq, dxk, dxv, dWq, dbq, dWk, dbk, dWv, dbv, dtable) + (None,) * 11
 
 
-def _proj_attention(xq, xk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, kind, geom, nh, p, site, merge_v_grad):
+def _proj_attention(xq, xk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, kind, geom, nh, p, site, merge_v_grad, x_p16=False, o_p16=False):
     same_qk = xk is xq
     same_v = same_qk and xv is xq
     return _ProjAttnFn.apply(xq, xk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, kind, geom, int(nh), float(p), int(site),
-                             same_qk, same_v, bool(merge_v_grad) and same_qk)
+                             same_qk, same_v, bool(merge_v_grad) and same_qk, bool(x_p16), bool(o_p16))
 
 
 def proj_window_attention(xqk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, B, H, W, nh, ws, dropout_p=0.0, site=0,
-                          merge_v_grad=False):
+                          merge_v_grad=False, x_p16=False, o_p16=False):
     """Window attention INCLUDING its q/k/v projections (q and k from xqk, v from xv; [B*H*W, C] tokens); returns the
     [B*H*W, C] heads before out_proj.  merge_v_grad: see _ProjAttnFn."""
     return _proj_attention(xqk, xqk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, 0, (int(B), int(H), int(W), int(ws)), nh,
-                           dropout_p, site, merge_v_grad)
+                           dropout_p, site, merge_v_grad, x_p16, o_p16)
 
 
 def proj_temporal_attention(q_in, k_in, v_in, Wq, bq, Wk, bk, Wv, bv, Nb, Tq, Tk, HW, nh, causal=False, dropout_p=0.0, site=0,
-                            merge_v_grad=False):
+                            merge_v_grad=False, x_p16=False, o_p16=False):
     """Temporal attention INCLUDING its q/k/v projections; q_in [(n,tq,p), C], k_in, v_in [(n,tk,p), C]."""
     return _proj_attention(q_in, k_in, v_in, Wq, bq, Wk, bk, Wv, bv, None, None, 1,
-                           (int(Nb), int(Tq), int(Tk), int(HW), int(bool(causal))), nh, dropout_p, site, merge_v_grad)
+                           (int(Nb), int(Tq), int(Tk), int(HW), int(bool(causal))), nh, dropout_p, site, merge_v_grad, x_p16, o_p16)
 
 
 class _TSAttnFn(torch.autograd.Function):
@@ -732,7 +942,7 @@ class _TSAttnFn(torch.autograd.Function):
         C = q.shape[1]
         o = torch.empty_like(q)
         ctx.seed = seed_tensor(q.device) if p > 0 else None
-        check(lib.vptr_tsattn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), Nb, Tq, Tk, H, W, ws, C, nh, p, ptr(ctx.seed), site, stream()),
+        check(lib.vptr_tsattn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), Nb, Tq, Tk, H, W, ws, C, nh, p, ptr(ctx.seed), site, 0, stream()),
               "vptr_tsattn_fwd")
         ctx.save_for_backward(q, k, v)
         ctx.cfg = (Nb, Tq, Tk, H, W, ws, nh, p, site)
@@ -745,7 +955,7 @@ class _TSAttnFn(torch.autograd.Function):
         do = _c(do)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         check(lib.vptr_tsattn_bwd(ptr(q), ptr(k), ptr(v), ptr(do), ptr(dq), ptr(dk), ptr(dv), Nb, Tq, Tk, H, W, ws, q.shape[1], nh,
-                                  p, ptr(ctx.seed), site, stream()), "vptr_tsattn_bwd")
+                                  p, ptr(ctx.seed), site, 0, stream()), "vptr_tsattn_bwd")
         return dq, dk, dv, None, None, None, None, None, None, None, None, None
 
 
@@ -1102,7 +1312,7 @@ class _Conv2dNHWCFn(torch.autograd.Function):
             if act == ACT_GELU:
                 raise RuntimeError("conv2d_nhwc: GELU epilogue is not differentiable from its output")
             g = torch.empty_like(dy)
-            check(lib.vptr_act_bwd(ptr(dy), ptr(y), ptr(g), pix_o, Cout, act, 1.0, None, 1, 1, 0.0, None, 0, stream()), "vptr_act_bwd")
+            check(lib.vptr_act_bwd(ptr(dy), ptr(y), ptr(g), pix_o, Cout, act, 1.0, None, 1, 1, 0.0, None, 0, 0, stream()), "vptr_act_bwd")
         else:
             g = dy
         dx = dW = db = None
