@@ -171,7 +171,7 @@ int vptr_gemm_grouped(const vptr_gemm_desc* proto, const vptr_gemm_desc* descs_d
  * ---------------------------------------------------------------------------------------------- */
 int vptr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* y2, const float* tab,
                        int tab_div, int tab_mod, float* mean, float* rstd, int rows, int C, float eps,
-                       vptr_stream_t stream);
+                       int p16 /* != 0: y and y2 are written in the P16 plane format (they only feed GEMMs) */, vptr_stream_t stream);
 /* dx = LN'(dy + dy2) + dx_add; dgamma/dbeta are ACCUMULATED (+=) with atomics; dy2 and dx_add may be null.
  * dx_add [rows, C] is the gradient that reaches x through the residual connection around the pre-norm sub-layer
  * (x + f(LN(x)), VidHRFormer_modules.py:68-93): added here, it needs no accumulation pass of its own. */
@@ -245,14 +245,14 @@ int vptr_groupstats(const float* x, float* mean, float* var, float* rstd, float 
 int vptr_norm_act_fwd(const float* x, const float* mean, const float* rstd, const float* w, const float* b, float* y,
                       int rows, int F, int HW, int per_col, int act, float dropout_p, const uint64_t* seed_dev,
                       uint32_t site, const float* rowscale, int rs_div, int rs_mod, const float* residual,
-                      vptr_stream_t stream);
+                      int p16 /* != 0: y is written in the P16 plane format */, vptr_stream_t stream);
 /* backward: dx written; dw/db ACCUMULATED (same layout as w/b).  scratch (initialised inside): per_col: >= 2*F floats;
  * per-frame: >= 2*frames*(1 + 4*ceil(HW*F/1024)) floats, frames = rows/HW (frame sums + per-wave partials).
  * const_stats != 0: mean/rstd are constants (BatchNorm in eval mode) -> no statistics terms in dx. */
 int vptr_norm_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w, const float* b,
                       float* dx, float* dw, float* db, float* scratch, int rows, int F, int HW, int per_col, int act,
                       int const_stats, float dropout_p, const uint64_t* seed_dev, uint32_t site, const float* rowscale,
-                      int rs_div, int rs_mod, vptr_stream_t stream);
+                      int rs_div, int rs_mod, int p16 /* != 0: dx is written in the P16 plane format */, vptr_stream_t stream);
 /* depthwise 3x3, pad 1 (VidHRFormer_modules.py:404-409,433); w given tap-major [9, F]. */
 int vptr_dwconv3x3_fwd(const float* x, const float* w9, const float* b, float* y, int frames, int H, int W, int F,
                        vptr_stream_t stream);

@@ -65,7 +65,9 @@ def test_flat_adamw_state_round_trip_through_torch_adamw(dev, fixture):
     torch.nn.utils.clip_grad_norm_(T2.parameters(), 1.0)
     topt.step()
     e = _update_err(T.state_dict(), T2.state_dict(), before, [k for k, _ in T2.named_parameters()])
-    assert e < 1e-4, "third step after exporting the state to torch.optim.AdamW: update differs by %.3e" % e
+    # parameters are O(1) fp32 numbers and one update is ~lr = 1e-4: one ulp of rounding difference between the two
+    # implementations (fma contraction) is already ~5e-4 of the update; a scrambled or stale optimizer state gives O(1)
+    assert e < 2e-3, "third step after exporting the state to torch.optim.AdamW: update differs by %.3e" % e
 
     # ---- torch.optim.AdamW -> a fresh FlatAdamW (what resuming from a reference checkpoint does)
     enc3, dec3, T3 = models()
@@ -81,4 +83,4 @@ def test_flat_adamw_state_round_trip_through_torch_adamw(dev, fixture):
     torch.nn.utils.clip_grad_norm_(T2.parameters(), 1.0)
     topt.step()
     e = _update_err(T3.state_dict(), T2.state_dict(), before, [k for k, _ in T2.named_parameters()])
-    assert e < 1e-4, "fourth step after importing torch.optim.AdamW state: update differs by %.3e" % e
+    assert e < 2e-3, "fourth step after importing torch.optim.AdamW state: update differs by %.3e" % e

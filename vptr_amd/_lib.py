@@ -55,7 +55,7 @@ SIGNATURES = {
     "vptr_to_p16": [P, P, L, I, P],
     "vptr_weight_planes": [P, P, I, I, P],
     "vptr_gemm_grouped": [ctypes.POINTER(GemmDesc), P, P, I, I, P],
-    "vptr_layernorm_fwd": [P, P, P, P, P, P, I, I, P, P, I, I, F, P],
+    "vptr_layernorm_fwd": [P, P, P, P, P, P, I, I, P, P, I, I, F, I, P],
     "vptr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, I, P, P],
     "vptr_rowmod_sum": [P, P, I, I, I, I, P],
     "vptr_colsum": [P, P, I, I, P],
@@ -69,8 +69,8 @@ SIGNATURES = {
     "vptr_tsattn_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P, U, I, P],
     "vptr_colstats": [P, P, P, P, F, P, I, I, P],
     "vptr_groupstats": [P, P, P, P, F, I, I, P],
-    "vptr_norm_act_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, P, U, P, I, I, P, P],
-    "vptr_norm_act_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, P, I, I, P],
+    "vptr_norm_act_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, P, U, P, I, I, P, I, P],
+    "vptr_norm_act_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, P, I, I, I, P],
     "vptr_dwconv3x3_fwd": [P, P, P, P, I, I, I, I, P],
     "vptr_dwconv3x3_bwd": [P, P, P, P, P, P, I, I, I, I, P],
     "vptr_nchw_to_tokens": [P, P, I, I, I, P],

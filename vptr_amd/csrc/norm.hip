@@ -10,7 +10,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ beta, float* __restrict__ y,
                                                      float* __restrict__ y2, const float* __restrict__ tab, int tab_div,
                                                      int tab_mod, float* __restrict__ mean, float* __restrict__ rstd,
-                                                     int rows, int C, float eps) {
+                                                     int rows, int C, float eps, int p16) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -42,11 +42,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     float4 o;
     o.x = (v.x - mu) * rs * g.x + b.x; o.y = (v.y - mu) * rs * g.y + b.y;
     o.z = (v.z - mu) * rs * g.z + b.z; o.w = (v.w - mu) * rs * g.w + b.w;
-    reinterpret_cast<float4*>(yr)[i] = o;
+    vptr_store4_fmt(y, (int64_t)row * C + 4 * i, o, p16);   // p16: the outputs only feed GEMMs (C % 16 == 0)
     if (y2r) {
       const float4 t = reinterpret_cast<const float4*>(tr)[i];
       o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
-      reinterpret_cast<float4*>(y2r)[i] = o;
+      vptr_store4_fmt(y2, (int64_t)row * C + 4 * i, o, p16);
     }
   }
   for (int i = (C4 << 2) + lane; i < C; i += 64) {
@@ -58,12 +58,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 extern "C" int vptr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* y2,
                                   const float* tab, int tab_div, int tab_mod, float* mean, float* rstd, int rows, int C,
-                                  float eps, vptr_stream_t stream) {
+                                  float eps, int p16, vptr_stream_t stream) {
+  if (p16) VPTR_CHECK(C % 16 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y2)) & 63) == 0,
+                      "layernorm_fwd: P16 outputs need C %% 16 == 0 and 64-byte aligned y, y2");
   VPTR_CHECK(rows > 0 && C > 0, "layernorm_fwd: empty input");
   VPTR_CHECK(C % 4 == 0, "layernorm_fwd: C must be a multiple of 4 (got %d)", C);
   if (y2) VPTR_CHECK(tab && tab_div >= 1 && tab_mod >= 1, "layernorm_fwd: y2 needs tab, tab_div, tab_mod");
   ln_fwd_kernel<<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(x, gamma, beta, y, y2, y2 ? tab : nullptr, tab_div, tab_mod,
-                                                                mean, rstd, rows, C, eps);
+                                                                mean, rstd, rows, C, eps, p16);
   VPTR_LAUNCH_CHECK();
   return 0;
 }
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const float* __restri
                                                            const float* __restrict__ b, float* __restrict__ y, int rows,
                                                            int F4, int HW, int act, float p, const uint64_t* seed_dev,
                                                            uint32_t site, const float* __restrict__ rowscale, int rs_div,
-                                                           int rs_mod, const float* __restrict__ residual) {
+                                                           int rs_mod, const float* __restrict__ residual, int p16) {
   const int64_t total = (int64_t)rows * F4;
   uint64_t seed = 0;
   if (p > 0.f) seed = *seed_dev;
@@ -468,23 +470,24 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const float* __restri
       const float4 rv = reinterpret_cast<const float4*>(residual)[i];
       o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
     }
-    reinterpret_cast<float4*>(y)[i] = o;
+    vptr_store4_fmt(y, i * 4, o, p16);
   }
 }
 
 extern "C" int vptr_norm_act_fwd(const float* x, const float* mean, const float* rstd, const float* w, const float* b,
                                  float* y, int rows, int F, int HW, int per_col, int act, float dropout_p,
                                  const uint64_t* seed_dev, uint32_t site, const float* rowscale, int rs_div, int rs_mod,
-                                 const float* residual, vptr_stream_t stream) {
+                                 const float* residual, int p16, vptr_stream_t stream) {
   VPTR_CHECK(rows > 0 && F > 0 && F % 4 == 0 && HW >= 1, "norm_act_fwd: bad arguments");
+  if (p16) VPTR_CHECK(F % 16 == 0 && (reinterpret_cast<uintptr_t>(y) & 63) == 0, "norm_act_fwd: a P16 output needs F %% 16 == 0 and a 64-byte aligned y");
   if (!per_col) VPTR_CHECK(rows % HW == 0, "norm_act_fwd: rows must be a multiple of HW");
   if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "norm_act_fwd: dropout needs seed_dev");
   const int64_t total = (int64_t)rows * (F / 4);
   const int blocks = (int)hmin64((total + 255) / 256, 8192);
   hipStream_t st = (hipStream_t)stream;
   if (rowscale) VPTR_CHECK(rs_div >= 1 && rs_mod >= 1, "norm_act_fwd: rowscale needs rs_div, rs_mod >= 1");
-  if (per_col) norm_act_fwd_kernel<true><<<blocks, 256, 0, st>>>(x, mean, rstd, w, b, y, rows, F / 4, HW, act, dropout_p, seed_dev, site, rowscale, rs_div, rs_mod, residual);
-  else norm_act_fwd_kernel<false><<<blocks, 256, 0, st>>>(x, mean, rstd, w, b, y, rows, F / 4, HW, act, dropout_p, seed_dev, site, rowscale, rs_div, rs_mod, residual);
+  if (per_col) norm_act_fwd_kernel<true><<<blocks, 256, 0, st>>>(x, mean, rstd, w, b, y, rows, F / 4, HW, act, dropout_p, seed_dev, site, rowscale, rs_div, rs_mod, residual, p16);
+  else norm_act_fwd_kernel<false><<<blocks, 256, 0, st>>>(x, mean, rstd, w, b, y, rows, F / 4, HW, act, dropout_p, seed_dev, site, rowscale, rs_div, rs_mod, residual, p16);
   VPTR_LAUNCH_CHECK();
   return 0;
 }
@@ -631,6 +634,58 @@ __global__ __launch_bounds__(256) void norm_act_bwd_dx_kernel(const float* __res
     dx[i] = rs * (g * ww - s1 * inv_n - xh * s2 * inv_n);
   }
 }
+// the same for F % 4 == 0: four channels per thread, 16-byte accesses, and optionally a P16 output (dx only feeds the input- and
+// weight-gradient GEMMs of the 1x1 convolution in front of this normalisation)
+template <bool PER_COL>
+__global__ __launch_bounds__(256) void norm_act_bwd_dx4_kernel(const float4* __restrict__ dy, const float4* __restrict__ x,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ w, const float* __restrict__ b,
+                                                               const float* __restrict__ acc, float* __restrict__ dx, int rows,
+                                                               int F4, int HW, int act, float p, const uint64_t* seed_dev,
+                                                               uint32_t site, int nacc, int const_stats,
+                                                               const float* __restrict__ rowscale, int rs_div, int rs_mod, int p16) {
+  const int64_t total = (int64_t)rows * F4;
+  const int F = F4 * 4;
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  const float inv_n = PER_COL ? 1.f / (float)rows : 1.f / (float)((int64_t)HW * F);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int row = (int)(i / F4), c4 = (int)(i - (int64_t)row * F4);
+    const float4 xv = x[i], dv = dy[i];
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds4[4] = {dv.x, dv.y, dv.z, dv.w};
+    float4 ww, bb;
+    float mu[4], rs[4], s1[4], s2[4];
+    if (PER_COL) {
+      ww = reinterpret_cast<const float4*>(w)[c4];
+      bb = reinterpret_cast<const float4*>(b)[c4];
+      const float4 m4 = reinterpret_cast<const float4*>(mean)[c4], r4 = reinterpret_cast<const float4*>(rstd)[c4];
+      const float4 a1 = reinterpret_cast<const float4*>(acc + nacc)[c4], a2 = reinterpret_cast<const float4*>(acc)[c4];
+      mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
+      rs[0] = r4.x; rs[1] = r4.y; rs[2] = r4.z; rs[3] = r4.w;
+      s1[0] = ww.x * a1.x; s1[1] = ww.y * a1.y; s1[2] = ww.z * a1.z; s1[3] = ww.w * a1.w;   // w * sum g
+      s2[0] = ww.x * a2.x; s2[1] = ww.y * a2.y; s2[2] = ww.z * a2.z; s2[3] = ww.w * a2.w;   // w * sum g*xhat
+    } else {
+      const int f = row / HW, hw = row - f * HW;
+      ww = reinterpret_cast<const float4*>(w)[(int64_t)hw * F4 + c4];
+      bb = reinterpret_cast<const float4*>(b)[(int64_t)hw * F4 + c4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { mu[u] = mean[f]; rs[u] = rstd[f]; s1[u] = acc[f]; s2[u] = acc[nacc + f]; }
+    }
+    const float wv[4] = {ww.x, ww.y, ww.z, ww.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w};
+    const float rsc = rowscale ? rowscale[(row / rs_div) % rs_mod] : 1.f;
+    float o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float xh = (xs[u] - mu[u]) * rs[u];
+      float dsc = p > 0.f ? vptr_drop_scale(seed, site, (uint64_t)i * 4 + u, p) : 1.f;
+      dsc *= rsc;
+      const float g = norm_act_g(ds4[u], xh, wv[u], bv[u], act, dsc);
+      const float t1 = const_stats ? 0.f : s1[u], t2 = const_stats ? 0.f : s2[u];
+      o[u] = rs[u] * (g * wv[u] - t1 * inv_n - xh * t2 * inv_n);
+    }
+    vptr_store4_fmt(dx, i * 4, make_float4(o[0], o[1], o[2], o[3]), p16);
+  }
+}
 // phase 1c: s1[f], s2[f] = sum of the per-wave partials of phase 1
 __global__ __launch_bounds__(64) void norm_act_bwd_frame_final(const float* __restrict__ part, float* __restrict__ fsum, int nparts,
                                                               int frames) {
@@ -659,8 +714,14 @@ __global__ void zero_fill_kernel(float* __restrict__ p, int n) {
 extern "C" int vptr_norm_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
                                  const float* b, float* dx, float* dw, float* db, float* scratch, int rows, int F, int HW,
                                  int per_col, int act, int const_stats, float dropout_p, const uint64_t* seed_dev,
-                                 uint32_t site, const float* rowscale, int rs_div, int rs_mod, vptr_stream_t stream) {
+                                 uint32_t site, const float* rowscale, int rs_div, int rs_mod, int p16, vptr_stream_t stream) {
   VPTR_CHECK(rows > 0 && F > 0 && HW >= 1 && scratch && dx && dw && db, "norm_act_bwd: bad arguments");
+  if (p16) VPTR_CHECK(F % 16 == 0 && (reinterpret_cast<uintptr_t>(dx) & 63) == 0, "norm_act_bwd: a P16 dx needs F %% 16 == 0 and a 64-byte aligned dx");
+  const bool vec4 = F % 4 == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
+                                     reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(mean) |
+                                     reinterpret_cast<uintptr_t>(rstd) | reinterpret_cast<uintptr_t>(scratch)) & 15) == 0;
+  const int blocks4 = (int)hmin64(((int64_t)rows * (F / 4) + 255) / 256, 8192);
+  if (p16) VPTR_CHECK(vec4, "norm_act_bwd: a P16 dx needs 16-byte aligned operands");
   if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "norm_act_bwd: dropout needs seed_dev");
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)rows * F;
@@ -670,6 +731,11 @@ extern "C" int vptr_norm_act_bwd(const float* dy, const float* x, const float* m
     const int rpb = 64;
     norm_act_bwd_col_reduce<<<dim3(cdiv(F, 256), cdiv(rows, rpb)), 256, 0, st>>>(dy, x, mean, rstd, w, b, scratch, rows, F, act,
                                                                                  dropout_p, seed_dev, site, rpb, rowscale, rs_div, rs_mod);
+    if (vec4)
+      norm_act_bwd_dx4_kernel<true><<<blocks4, 256, 0, st>>>(reinterpret_cast<const float4*>(dy), reinterpret_cast<const float4*>(x), mean, rstd, w, b,
+                                                             scratch, dx, rows, F / 4, HW, act, dropout_p, seed_dev, site, F, const_stats,
+                                                             rowscale, rs_div, rs_mod, p16);
+    else
     norm_act_bwd_dx_kernel<true><<<blocks, 256, 0, st>>>(dy, x, mean, rstd, w, b, scratch, dx, rows, F, HW, act, dropout_p,
                                                          seed_dev, site, F, const_stats, rowscale, rs_div, rs_mod);
     accum2_kernel<<<cdiv(F, 256), 256, 0, st>>>(scratch, dw, db, F);
@@ -685,6 +751,11 @@ extern "C" int vptr_norm_act_bwd(const float* dy, const float* x, const float* m
                                                                                      dropout_p, seed_dev, site, frames, fpb, rowscale,
                                                                                      rs_div, rs_mod);
     norm_act_bwd_frame_final<<<frames, 64, 0, st>>>(part, scratch, nparts, frames);
+    if (vec4)
+      norm_act_bwd_dx4_kernel<false><<<blocks4, 256, 0, st>>>(reinterpret_cast<const float4*>(dy), reinterpret_cast<const float4*>(x), mean, rstd, w, b,
+                                                              scratch, dx, rows, F / 4, HW, act, dropout_p, seed_dev, site, frames, const_stats,
+                                                              rowscale, rs_div, rs_mod, p16);
+    else
     norm_act_bwd_dx_kernel<false><<<blocks, 256, 0, st>>>(dy, x, mean, rstd, w, b, scratch, dx, rows, F, HW, act, dropout_p,
                                                           seed_dev, site, frames, const_stats, rowscale, rs_div, rs_mod);
   }

@@ -122,8 +122,11 @@ class SpatialLocalMultiheadAttention(nn.Module):
             self._lw_tab[key] = lw_pos[hh[:, None], ww[None, :]].reshape(H * W, -1).contiguous()
         return self._lw_tab[key]
 
-    def forward_tokens(self, xqk, xv, residual, g, lw_pos, site, rowscale=None, rs_div=1, rs_mod=1):
+    def forward_tokens(self, xqk, xv, residual, g, lw_pos, site, rowscale=None, rs_div=1, rs_mod=1, x_p16=False):
+        """x_p16: xqk and xv are P16 tensors (written by the LayerNorm in front; rpe=True only).  Padding / cropping move whole
+        token rows, which is format-agnostic."""
         C, nh, ws = self.dim, self.num_heads, self.window_size
+        P = ops.p16_ok(C)
         p = self.dropout if self.training else 0.0
         a = self.attn
         frames, H, W = g.N * g.T, g.H, g.W
@@ -143,11 +146,13 @@ class SpatialLocalMultiheadAttention(nn.Module):
             bq, bk, bv = a.in_proj_bias[:C], a.in_proj_bias[C:2 * C], a.in_proj_bias[2 * C:]
             table, index = None, None
         # q/k/v projections (one batched launch) + attention core; q is scaled by head_dim^-0.5 in the GEMM epilogue
-        o = ops.proj_window_attention(xin, xv, Wq, bq, Wk, bk, Wv, bv, table, index, frames, H, W, nh, ws, p, site)
+        if x_p16 and not self.rpe:
+            raise RuntimeError("the positional add of the rpe=False window attention needs fp32 inputs")
+        o = ops.proj_window_attention(xin, xv, Wq, bq, Wk, bk, Wv, bv, table, index, frames, H, W, nh, ws, p, site, x_p16=x_p16, o_p16=P)
         if padded:  # the out-projection is per token, so cropping first is equivalent to depad_if_needed after it (:347-351)
             o = ops.crop_tokens(o, frames, H, W, g.H, g.W)
         return ops.linear(o, a.out_proj.weight, a.out_proj.bias, residual=residual, rowscale=rowscale, rs_div=rs_div,
-                          rs_mod=rs_mod)
+                          rs_mod=rs_mod, x_p16=P)
 
     def extra_repr(self):
         return f"dim={self.dim}, window_size={self.window_size}, num_heads={self.num_heads}"
@@ -237,28 +242,33 @@ class MlpDWBN(nn.Module):
         return ops.norm_act(h, norm.weight, norm.bias, "bn", HW, self.training, norm.running_mean, norm.running_var,
                             eps=norm.eps, momentum=norm.momentum, **kw)
 
-    def forward_tokens(self, u, residual, g, site, rowscale=None, rs_div=1, rs_mod=1):
+    def forward_tokens(self, u, residual, g, site, rowscale=None, rs_div=1, rs_mod=1, x_p16=False):
+        """x_p16: u is a P16 tensor.  With P16-eligible widths the tensors that only connect a normalisation to a 1x1 convolution
+        never exist as fp32: norm2 writes fc2's input as P16, and the backward passes of norm3 / norm1 hand fc2 / fc1 their
+        incoming gradient as P16 (each of those tensors has exactly one consumer)."""
         p = self.drop_p if self.training else 0.0
         F, C = self.fc1.weight.shape[0], self.fc1.weight.shape[1]
-        h = ops.linear(u, self.fc1.weight.view(F, C), self.fc1.bias)
-        h = self._norm_act(h, self.norm1, g)
+        P = ops.p16_ok(C, F, self.out_features)
+        h = ops.linear(u, self.fc1.weight.view(F, C), self.fc1.bias, x_p16=x_p16, dy_p16=P)
+        h = self._norm_act(h, self.norm1, g, dx_p16=P)
         h = ops.dwconv3x3(h, self.dw3x3.weight, self.dw3x3.bias, g.N * g.T, g.H, g.W)
-        h = self._norm_act(h, self.norm2, g, dropout_p=p, site=site)
-        h = ops.linear(h, self.fc2.weight.view(self.out_features, F), self.fc2.bias)
+        h = self._norm_act(h, self.norm2, g, dropout_p=p, site=site, out_p16=P)
+        h = ops.linear(h, self.fc2.weight.view(self.out_features, F), self.fc2.bias, x_p16=P, dy_p16=P)
         return self._norm_act(h, self.norm3, g, dropout_p=p, site=site + 1, rowscale=rowscale, rs_div=rs_div, rs_mod=rs_mod,
-                              residual=residual)
+                              residual=residual, dx_p16=P)
 
 
 def _mha_tokens(mha, q_in, k_in, v_in, residual, Nb, Tq, Tk, HW, causal, p_attn, site, out_dropout=0.0, out_site=0,
-                rowscale=None, rs_div=1, rs_mod=1, merge_v_grad=False):
+                rowscale=None, rs_div=1, rs_mod=1, merge_v_grad=False, x_p16=False):
     """Stock nn.MultiheadAttention (packed in_proj) over time on token-major inputs (VidHRFormer_modules.py:79-84).
     merge_v_grad: q_in is k_in = v_in + a table that needs no gradient, so the three input gradients may be returned as one."""
     C, nh = mha.embed_dim, mha.num_heads
     w, b = mha.in_proj_weight, mha.in_proj_bias
+    P = ops.p16_ok(C)
     o = ops.proj_temporal_attention(q_in, k_in, v_in, w[:C], b[:C], w[C:2 * C], b[C:2 * C], w[2 * C:], b[2 * C:], Nb, Tq, Tk, HW, nh,
-                                    causal, p_attn, site, merge_v_grad=merge_v_grad)
+                                    causal, p_attn, site, merge_v_grad=merge_v_grad, x_p16=x_p16, o_p16=P)
     return ops.linear(o, mha.out_proj.weight, mha.out_proj.bias, residual=residual, dropout_p=out_dropout, site=out_site,
-                      rowscale=rowscale, rs_div=rs_div, rs_mod=rs_mod)
+                      rowscale=rowscale, rs_div=rs_div, rs_mod=rs_mod, x_p16=P)
 
 
 class VidHRFormerBlockEnc(nn.Module):
@@ -297,18 +307,21 @@ class VidHRFormerBlockEnc(nn.Module):
         per_n = g.T * HW
         # every pre-norm LayerNorm also returns its input as a pass-through output xr, used as the sub-layer's residual: the
         # residual gradient then comes back through the LayerNorm node and is added inside its backward kernel
-        u, xr = ops.layernorm(x, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps, passthrough=True)
-        x = self.SLMHSA.forward_tokens(u, u, xr, g, lw_pos, s + 0, rowscale=dp, rs_div=per_n, rs_mod=g.N)
+        # P: the LayerNorm outputs (which only feed GEMMs) are written in the P16 operand format, see ops.p16_ok / include/vptr_hip.h
+        P = ops.p16_ok(self.embed_dim, self.linear1.weight.shape[0])
+        Pw = P and self.SLMHSA.rpe
+        u, xr = ops.layernorm(x, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps, passthrough=True, out_p16=Pw)
+        x = self.SLMHSA.forward_tokens(u, u, xr, g, lw_pos, s + 0, rowscale=dp, rs_div=per_n, rs_mod=g.N, x_p16=Pw)
         dp = _droppath_scale(self.drop_path_p, self.training, g.N, x.device)
-        u, xr = ops.layernorm(x, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps, passthrough=True)
-        x = self.SpatialFFN.forward_tokens(u, xr, g, s + 1, rowscale=dp, rs_div=per_n, rs_mod=g.N)
+        u, xr = ops.layernorm(x, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps, passthrough=True, out_p16=P)
+        x = self.SpatialFFN.forward_tokens(u, xr, g, s + 1, rowscale=dp, rs_div=per_n, rs_mod=g.N, x_p16=P)
         u, uq, xr = ops.layernorm(x, self.norm3.weight, self.norm3.bias, tab=tpos, tab_div=HW, tab_mod=g.T, eps=self.norm3.eps,
-                                  passthrough=True)
+                                  passthrough=True, out_p16=P)
         x = _mha_tokens(self.temporal_MHSA, uq, uq, u, xr, g.N, g.T, g.T, HW, self.far, p, s + 3, out_dropout=p, out_site=s + 4,
-                        merge_v_grad=not tpos.requires_grad)
-        u, xr = ops.layernorm(x, self.norm4.weight, self.norm4.bias, eps=self.norm4.eps, passthrough=True)
-        h = ops.linear(u, self.linear1.weight, self.linear1.bias, act=ops.ACT_GELU, dropout_p=p, site=s + 5)
-        return ops.linear(h, self.linear2.weight, self.linear2.bias, residual=xr, dropout_p=p, site=s + 6)
+                        merge_v_grad=not tpos.requires_grad, x_p16=P)
+        u, xr = ops.layernorm(x, self.norm4.weight, self.norm4.bias, eps=self.norm4.eps, passthrough=True, out_p16=P)
+        h = ops.linear(u, self.linear1.weight, self.linear1.bias, act=ops.ACT_GELU, dropout_p=p, site=s + 5, x_p16=P, out_p16=P)
+        return ops.linear(h, self.linear2.weight, self.linear2.bias, residual=xr, dropout_p=p, site=s + 6, x_p16=P)
 
 
 class VidHRFormerEncoder(nn.Module):
@@ -372,19 +385,21 @@ class VidHRFormerBlockDecNAR(nn.Module):
         per_n = T2 * HW
         dp = _droppath_scale(self.drop_path_p, self.training, g.N, tgt.device)
         # (pass-through outputs xr: see VidHRFormerBlockEnc.forward_tokens)
+        P = ops.p16_ok(self.embed_dim, self.linear1.weight.shape[0])   # as in VidHRFormerBlockEnc.forward_tokens
+        Pw = P and self.SLMHSA.rpe
         t, tq, xr = ops.layernorm(tgt, self.norm1.weight, self.norm1.bias, tab=qpos_tab, tab_div=1, tab_mod=per_n, eps=self.norm1.eps,
-                                  passthrough=True)
-        x = self.SLMHSA.forward_tokens(tq, t, xr, g, lw_pos, s + 0, rowscale=dp, rs_div=per_n, rs_mod=g.N)
+                                  passthrough=True, out_p16=Pw)
+        x = self.SLMHSA.forward_tokens(tq, t, xr, g, lw_pos, s + 0, rowscale=dp, rs_div=per_n, rs_mod=g.N, x_p16=Pw)
         dp = _droppath_scale(self.drop_path_p, self.training, g.N, tgt.device)
-        u, xr = ops.layernorm(x, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps, passthrough=True)
-        x = self.SpatialFFN.forward_tokens(u, xr, g, s + 1, rowscale=dp, rs_div=per_n, rs_mod=g.N)
+        u, xr = ops.layernorm(x, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps, passthrough=True, out_p16=P)
+        x = self.SpatialFFN.forward_tokens(u, xr, g, s + 1, rowscale=dp, rs_div=per_n, rs_mod=g.N, x_p16=P)
         u, uq, xr = ops.layernorm(x, self.norm3.weight, self.norm3.bias, tab=tpos_f, tab_div=HW, tab_mod=T2, eps=self.norm3.eps,
-                                  passthrough=True)
+                                  passthrough=True, out_p16=P)
         x = _mha_tokens(self.temporal_MHSA, uq, uq, u, xr, g.N, T2, T2, HW, False, p, s + 3, out_dropout=p, out_site=s + 4,
-                        merge_v_grad=not tpos_f.requires_grad)
-        u, xr = ops.layernorm(x, self.norm4.weight, self.norm4.bias, eps=self.norm4.eps, passthrough=True)
-        h = ops.linear(u, self.linear1.weight, self.linear1.bias, act=ops.ACT_GELU, dropout_p=p, site=s + 5)
-        x = ops.linear(h, self.linear2.weight, self.linear2.bias, residual=xr, dropout_p=p, site=s + 6)
+                        merge_v_grad=not tpos_f.requires_grad, x_p16=P)
+        u, xr = ops.layernorm(x, self.norm4.weight, self.norm4.bias, eps=self.norm4.eps, passthrough=True, out_p16=P)
+        h = ops.linear(u, self.linear1.weight, self.linear1.bias, act=ops.ACT_GELU, dropout_p=p, site=s + 5, x_p16=P, out_p16=P)
+        x = ops.linear(h, self.linear2.weight, self.linear2.bias, residual=xr, dropout_p=p, site=s + 6, x_p16=P)
         # encoder-decoder attention; the reference applies drop_path1 to a (T2, N*HW, C) tensor, i.e. along TIME
         # (VidHRFormer_modules.py:204) -- reproduced: scale indexed by t = (row // HW) % T2
         if self.TSLMA_flag:
@@ -395,12 +410,14 @@ class VidHRFormerBlockDecNAR(nn.Module):
             x = self.TSLMA.forward_tokens(mem, uq, xr, g, T1, Tlw_pos, s + 7, rowscale=dp, rs_div=per_n, rs_mod=g.N)
         else:
             dpt = _droppath_scale(self.drop_path_p, self.training, T2, tgt.device)
+            # mem / mem_k arrive as P16 tensors when P (converted once per forward by VidHRformerDecoderNAR.forward_tokens)
             _, uq, xr = ops.layernorm(x, self.norm5.weight, self.norm5.bias, tab=qpos_tpos_tab, tab_div=1, tab_mod=per_n,
-                                      eps=self.norm5.eps, passthrough=True)
-            x = _mha_tokens(self.EncDecAttn, uq, mem_k, mem, xr, g.N, T2, T1, HW, False, p, s + 7, rowscale=dpt, rs_div=HW, rs_mod=T2)
+                                      eps=self.norm5.eps, passthrough=True, out_p16=P)
+            x = _mha_tokens(self.EncDecAttn, uq, mem_k, mem, xr, g.N, T2, T1, HW, False, p, s + 7, rowscale=dpt, rs_div=HW, rs_mod=T2,
+                            x_p16=P)
         dp = _droppath_scale(self.drop_path_p, self.training, g.N, tgt.device)
-        u, xr = ops.layernorm(x, self.norm6.weight, self.norm6.bias, eps=self.norm6.eps, passthrough=True)
-        return self.SpatialFFN1.forward_tokens(u, xr, g, s + 8, rowscale=dp, rs_div=per_n, rs_mod=g.N)
+        u, xr = ops.layernorm(x, self.norm6.weight, self.norm6.bias, eps=self.norm6.eps, passthrough=True, out_p16=P)
+        return self.SpatialFFN1.forward_tokens(u, xr, g, s + 8, rowscale=dp, rs_div=per_n, rs_mod=g.N, x_p16=P)
 
 
 class VidHRformerDecoderNAR(nn.Module):
@@ -416,6 +433,10 @@ class VidHRformerDecoderNAR(nn.Module):
         qpos_tab = frame_queries.reshape(g.T * HW, C)
         qpos_tpos_tab = (frame_queries.reshape(g.T, HW, C) + tpos_f[:, None, :]).reshape(g.T * HW, C)
         mem_k = ops.add_rowtab(mem, tpos_p, HW, T1)
+        layer0 = self.layers[0]
+        if not layer0.TSLMA_flag and ops.p16_ok(C, layer0.linear1.weight.shape[0]):
+            # the encoder-decoder attentions of all layers project the same memory: its two P16 images are made once
+            mem, mem_k = ops.as_p16(mem), ops.as_p16(mem_k)
         x = tgt
         for layer in self.layers:
             x = layer.forward_tokens(x, g, qpos_tab, qpos_tpos_tab, mem, mem_k, T1, lw_pos, tpos_f, Tlw_pos)

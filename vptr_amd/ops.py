@@ -4,6 +4,7 @@ Every forward/backward here is a call into libvptr_hip.so (vptr_amd/_lib.py); to
 streams and autograd bookkeeping only.  Activations are token-major, channel-last 2-D tensors [rows, C] with
 rows = (n, t, h, w) flattened -- the reference's window partition and (T, N*HW, C) permutes never materialise.
 """
+import bisect
 import ctypes
 import os
 import math
@@ -183,6 +184,21 @@ def to_p16(x):
     return out
 
 
+class _AsP16Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return to_p16(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy
+
+
+def as_p16(x):
+    """autograd-aware fp32 -> P16 conversion: the gradient of the P16 tensor (an ordinary fp32 tensor) passes through"""
+    return _AsP16Fn.apply(x)
+
+
 def p16_decode(t):
     """P16 -> fp32 values with plain torch ops (tests / debugging only)"""
     C = t.shape[-1]
@@ -218,8 +234,9 @@ class WeightPlanes:
         import struct
         self.table = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(dev)
         self.starts = torch.frombuffer(bytearray(struct.pack("%di" % len(starts), *starts)), dtype=torch.uint8).to(dev)
-        self.tiles, self.versions = tiles, None
+        self.tiles, self.versions, self._views = tiles, None, {}
         self.index.sort(key=lambda t: t[0])
+        self.bases = [t[0] for t in self.index]
         self.refresh()
 
     def refresh(self):
@@ -230,19 +247,26 @@ class WeightPlanes:
         """(Wp, ld, WT, ld) for W = a registered weight or a whole-row slice of one, or None; stale planes (the weight changed
         through torch since the last refresh) are rebuilt first"""
         p = W.data_ptr()
-        for i, (base, nbytes, off, N, K, w) in enumerate(self.index):
-            if base <= p < base + nbytes:
-                if w.stride(0) != K or W.shape[1] != K or W.stride(0) != K or (p - base) % (K * 4):
-                    return None
-                if self.versions[i] != w._version:
-                    self.refresh()
-                r0, n = (p - base) // (K * 4), W.shape[0]
-                if r0 % 16 or n % 16:
-                    return None
-                wp = self.wp[off + r0 * K: off + (r0 + n) * K].view(n, K)
-                wt = self.wt[off: off + N * K].view(K, N)[:, r0:r0 + n]
-                return wp, K, wt, N
-        return None
+        i = bisect.bisect_right(self.bases, p) - 1
+        if i < 0:
+            return None
+        base, nbytes, off, N, K, w = self.index[i]
+        if not (base <= p < base + nbytes):
+            return None
+        if w.stride(0) != K or W.shape[1] != K or W.stride(0) != K or (p - base) % (K * 4):
+            return None
+        if self.versions[i] != w._version:
+            self.refresh()
+        r0, n = (p - base) // (K * 4), W.shape[0]
+        if r0 % 16 or n % 16 or r0 + n > N:
+            return None
+        key = (i, r0, n)
+        hit = self._views.get(key)
+        if hit is None:   # view construction costs ~10 us of host time per call site and step otherwise
+            wp = self.wp[off + r0 * K: off + (r0 + n) * K].view(n, K)
+            wt = self.wt[off: off + N * K].view(K, N)[:, r0:r0 + n]
+            hit = self._views[key] = (wp, K, wt, N)
+        return hit
 
 
 _wplane_stores = []      # weakrefs of WeightPlanes registered by the trainers (FlatAdamW slabs)
@@ -629,7 +653,7 @@ class _LayerNormFn(torch.autograd.Function):
     (dx_add) instead of by an autograd accumulation pass."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, tab, tab_div, tab_mod, eps, passthrough):
+    def forward(ctx, x, gamma, beta, tab, tab_div, tab_mod, eps, passthrough, out_p16):
         _lib.require_cuda(x)
         ctx.set_materialize_grads(False)  # an unused output (e.g. y when only y + tab is consumed) arrives as None, not zeros
         x = _c(x)
@@ -640,7 +664,7 @@ class _LayerNormFn(torch.autograd.Function):
         rstd = torch.empty_like(mean)
         tab_c = _c(tab) if tab is not None else None
         check(lib.vptr_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(y2), ptr(tab_c), tab_div, tab_mod, ptr(mean),
-                                     ptr(rstd), rows, C, eps, stream()), "vptr_layernorm_fwd")
+                                     ptr(rstd), rows, C, eps, int(out_p16), stream()), "vptr_layernorm_fwd")
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.beta_ref = beta.detach()
         ctx.tab = (tab is not None, tab_div, tab_mod, tuple(tab.shape) if tab is not None else None)
@@ -663,7 +687,7 @@ class _LayerNormFn(torch.autograd.Function):
         dres = _c(dres) if dres is not None else None
         if dy is None:  # only the position-added output was consumed
             if dy2 is None:
-                return (dres,) + (None,) * 7
+                return (dres,) + (None,) * 8
             k1, k2 = dy2, None
         else:
             k1, k2 = _c(dy), dy2
@@ -681,13 +705,14 @@ class _LayerNormFn(torch.autograd.Function):
             dtab = torch.zeros((tab_mod, C), device=x.device, dtype=torch.float32)
             check(lib.vptr_rowmod_sum(ptr(dy2), ptr(dtab), rows, C, tab_div, tab_mod, stream()), "vptr_rowmod_sum")
             dtab = dtab.reshape(tab_shape)
-        return dx, dgamma, dbeta, dtab, None, None, None, None
+        return dx, dgamma, dbeta, dtab, None, None, None, None, None
 
 
-def layernorm(x, gamma, beta, tab=None, tab_div=1, tab_mod=1, eps=1e-5, passthrough=False):
+def layernorm(x, gamma, beta, tab=None, tab_div=1, tab_mod=1, eps=1e-5, passthrough=False, out_p16=False):
     """y = LN(x) [, y2 = y + tab[(row // tab_div) % tab_mod]] [, xr]; x [rows, C]; tab [tab_mod, C].
-    passthrough=True appends xr (= x, for use as the residual of the sub-layer this LayerNorm feeds; see _LayerNormFn)."""
-    return _LayerNormFn.apply(x, gamma, beta, tab, int(tab_div), int(tab_mod), float(eps), bool(passthrough))
+    passthrough=True appends xr (= x, for use as the residual of the sub-layer this LayerNorm feeds; see _LayerNormFn).
+    out_p16: y and y2 are written as P16 tensors (they only feed GEMMs; their gradients arrive as ordinary fp32)."""
+    return _LayerNormFn.apply(x, gamma, beta, tab, int(tab_div), int(tab_mod), float(eps), bool(passthrough), bool(out_p16))
 
 
 class _AddRowTabFn(torch.autograd.Function):
@@ -977,7 +1002,7 @@ class _NormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, running_mean, running_var, mode, HW, training, act, eps, p, site, momentum, rowscale, rs_div,
-                rs_mod, residual):
+                rs_mod, residual, out_p16, dx_p16):
         x, w, b = _c(x), _c(w), _c(b)
         residual = _c(residual) if residual is not None else None
         rows, F = x.shape
@@ -1010,15 +1035,15 @@ class _NormActFn(torch.autograd.Function):
         ctx.seed = seed_tensor(dev) if p > 0 else None
         check(lib.vptr_norm_act_fwd(ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(b), ptr(y), rows, F, HW, int(per_col), act, p,
                                     ptr(ctx.seed), site, ptr(rowscale), rs_div, rs_mod,
-                                    ptr(residual), stream()), "vptr_norm_act_fwd")
+                                    ptr(residual), int(out_p16), stream()), "vptr_norm_act_fwd")
         ctx.save_for_backward(x, w, b, mean, rstd, rowscale)
-        ctx.cfg = (HW, per_col, act, const_stats, p, site, rs_div, rs_mod, residual is not None)
+        ctx.cfg = (HW, per_col, act, const_stats, p, site, rs_div, rs_mod, residual is not None, dx_p16)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, b, mean, rstd, rowscale = ctx.saved_tensors
-        HW, per_col, act, const_stats, p, site, rs_div, rs_mod, has_res = ctx.cfg
+        HW, per_col, act, const_stats, p, site, rs_div, rs_mod, has_res, dx_p16 = ctx.cfg
         dy = _c(dy)
         rows, F = x.shape
         dx = torch.empty_like(x)
@@ -1029,19 +1054,22 @@ class _NormActFn(torch.autograd.Function):
         scratch = torch.empty((max(2 * F, 2 * frames * (1 + 4 * ((HW * F // 4 + 255) // 256))),), device=x.device, dtype=torch.float32)
         check(lib.vptr_norm_act_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(b), ptr(dx), ptr(dw), ptr(db),
                                     ptr(scratch), rows, F, HW, int(per_col), act, int(const_stats), p,
-                                    ptr(ctx.seed), site, ptr(rowscale), rs_div, rs_mod,
+                                    ptr(ctx.seed), site, ptr(rowscale), rs_div, rs_mod, int(dx_p16),
                                     stream()), "vptr_norm_act_bwd")
         dres = dy if has_res else None
         if in_slab:
             dw = db = None
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None, dres
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None, dres, None, None
 
 
 def norm_act(x, w, b, mode, HW, training, running_mean=None, running_var=None, act=ACT_GELU, eps=1e-5, dropout_p=0.0, site=0,
-             momentum=0.1, rowscale=None, rs_div=1, rs_mod=1, residual=None):
-    """y = rowscale * dropout(act(norm(x)*w + b)) + residual  (one elementwise pass; see _NormActFn)."""
+             momentum=0.1, rowscale=None, rs_div=1, rs_mod=1, residual=None, out_p16=False, dx_p16=False):
+    """y = rowscale * dropout(act(norm(x)*w + b)) + residual  (one elementwise pass; see _NormActFn).
+    out_p16: y is written as a P16 tensor (it only feeds a GEMM); dx_p16: the gradient w.r.t. x is returned as a P16 tensor (x is
+    the output of a linear(..., dy_p16=True) and nothing else)."""
     return _NormActFn.apply(x, w, b, running_mean, running_var, mode, int(HW), bool(training), int(act), float(eps),
-                            float(dropout_p), int(site), float(momentum), rowscale, int(rs_div), int(rs_mod), residual)
+                            float(dropout_p), int(site), float(momentum), rowscale, int(rs_div), int(rs_mod), residual,
+                            bool(out_p16), bool(dx_p16))
 
 
 class _DWConvFn(torch.autograd.Function):

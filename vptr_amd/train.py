@@ -72,6 +72,13 @@ class FlatAdamW:
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.float32)
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
         ops.register_flat_slab(self.flat, self.grad)  # backward kernels accumulate weight gradients in place
+        # P16 planes of every nn.Linear-shaped weight of the slab (forward operand and transposed input-gradient operand), rebuilt
+        # by one launch after each step: the GEMMs then stage weights by DMA instead of splitting fp32 per tile (ops.WeightPlanes)
+        self.planes = None
+        lin = ops.linear_weights_of(self.params) if ops.config.use_p16 else []
+        if lin:
+            self.planes = ops.WeightPlanes(lin)
+            ops.register_weight_planes(self.planes)
 
     # -- torch.optim.AdamW-compatible state (checkpoints of the reference carry `optimizer_T.state_dict()`) ------------------
     def _logical(self, slab, i):
@@ -143,6 +150,8 @@ class FlatAdamW:
                              self.eps, self.weight_decay, ptr(self.step_dev),
                              ptr(self.sumsq) if self.max_grad_norm is not None else None,
                              float(self.max_grad_norm or 0.0), float(grad_scale), stream()), "vptr_adamw")
+        if self.planes is not None:
+            self.planes.refresh()
 
 
 def _channel_last_ids(transformer):
