@@ -162,6 +162,91 @@ def gemm_roofline(trainer, past, fut, precision):
     }
 
 
+def _time_steps(step, warm=2, timed=3):
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / timed * 1e3
+
+
+def other_configs(dev, enc, T_k64, trainer, dropout):
+    """ms/step of BASELINE.json's other configurations on this GPU (rank 0, after the timed region, 2 warm-up + 3 timed steps each;
+    reported, never part of `value`): config 2 (MNIST NAR: the K64 shapes with a Sigmoid decoder), config 4 (BAIR FAR at its literal
+    size: 3-channel zero-padded auto-encoder, VPTRFormerFAR(2, 28), T_in = 29, per-GPU batch 16 = train_FAR_mp.py's 64 over 4 GPUs)
+    and config 5 (KTH 128x128 10 -> 40, 16x16 features, 8x8 windows, per-GPU batch 2)."""
+    import contextlib
+    import io
+    import vptr_amd.model as M
+    import vptr_amd.ops as ops
+    from vptr_amd.train import FARTrainer, NARTrainer
+    out = {}
+
+    def init(*mods):
+        with contextlib.redirect_stdout(io.StringIO()):
+            for m in mods:
+                M.init_weights(m)
+
+    def rnd(*shape):
+        return torch.rand(shape, device=dev) * 0.36 - 0.22
+    # ---- config 2: same transformer / slab, Sigmoid decoder
+    try:
+        dec2 = M.VPTRDec(1, feat_dim=528, n_downsampling=3, out_layer="Sigmoid", padding_type="reflect")
+        init(dec2)
+        dec2 = dec2.to(dev).eval()
+        for p in dec2.parameters():
+            p.requires_grad_(True)
+        for mod in dec2.modules():
+            mod._vptr_frozen = True
+        keep = trainer.dec
+        trainer.dec = dec2
+        past, fut = rnd(PER_GPU_BATCH, TP, 1, 64, 64), torch.rand((PER_GPU_BATCH, TF, 1, 64, 64), device=dev)
+        ms = _time_steps(lambda: trainer.step(past, fut))
+        trainer.dec = keep
+        out["config2_mnist_nar_sigmoid"] = {"ms_per_step": round(ms, 2), "per_gpu_batch": PER_GPU_BATCH,
+                                            "frames_per_s": round(PER_GPU_BATCH * TF / ms * 1e3, 1)}
+        del dec2
+    except Exception as e:  # noqa
+        out["config2_mnist_nar_sigmoid"] = {"error": str(e)[:160]}
+    # ---- config 4: BAIR FAR 2 -> 28
+    try:
+        n = 16
+        enc4 = M.VPTREnc(3, feat_dim=528, n_downsampling=3, padding_type="zero")
+        dec4 = M.VPTRDec(3, feat_dim=528, n_downsampling=3, out_layer="Tanh", padding_type="zero")
+        init(enc4, dec4)
+        far = M.VPTRFormerFAR(2, 28, 8, 8, 528, 8, 12, dropout, 4, 4, True)
+        tr4 = FARTrainer(enc4.to(dev), dec4.to(dev), far.to(dev), lr=1e-4, max_grad_norm=1.0)
+        past, fut = rnd(n, 2, 3, 64, 64), rnd(n, 28, 3, 64, 64)
+        ms = _time_steps(lambda: tr4.step(past, fut))
+        out["config4_bair_far_2to28"] = {"ms_per_step": round(ms, 2), "per_gpu_batch": n, "T_in": 29,
+                                          "frames_per_s": round(n * 29 / ms * 1e3, 1)}
+        del tr4, far, enc4, dec4
+    except Exception as e:  # noqa
+        out["config4_bair_far_2to28"] = {"error": str(e)[:160]}
+    torch.cuda.empty_cache()
+    # ---- config 5: KTH 128x128 10 -> 40
+    try:
+        n = 2
+        enc5 = M.VPTREnc(1, feat_dim=528, n_downsampling=3, padding_type="reflect")
+        dec5 = M.VPTRDec(1, feat_dim=528, n_downsampling=3, out_layer="Tanh", padding_type="reflect")
+        init(enc5, dec5)
+        nar5 = M.VPTRFormerNAR(10, 40, 16, 16, 528, 8, 4, 8, dropout, 8, 4, False, True)
+        tr5 = NARTrainer(enc5.to(dev), dec5.to(dev), nar5.to(dev), batch_size=n, lr=1e-4, max_grad_norm=1.0, lam_pc=0.1)
+        past, fut = rnd(n, 10, 1, 128, 128), rnd(n, 40, 1, 128, 128)
+        ms = _time_steps(lambda: tr5.step(past, fut))
+        out["config5_kth128_nar_10to40"] = {"ms_per_step": round(ms, 2), "per_gpu_batch": n,
+                                            "frames_per_s": round(n * 40 / ms * 1e3, 1)}
+        del tr5, nar5, enc5, dec5
+    except Exception as e:  # noqa
+        out["config5_kth128_nar_10to40"] = {"error": str(e)[:160]}
+    torch.cuda.empty_cache()
+    ops.unregister_flat_slabs()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,6 +260,11 @@ def main():
                     help="1: capture the step in a hipGraph (1 GPU). Default 0: the step is GPU-bound, eager == graph speed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the ms/step lines of BASELINE configs 2 / 4 / 5")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): --batch clips per GPU; strong: the reference's DistributedSampler semantics, a fixed "
+                         "--global-batch split as global // world per rank (utils/dataset.py:72)")
+    ap.add_argument("--global-batch", type=int, default=64, help="global batch of --scaling strong (train_FAR_mp.py:300 uses 64)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -199,6 +289,9 @@ def main():
 
     import vptr_amd.ops as ops
     from vptr_amd.train import NARTrainer
+    if args.scaling == "strong":
+        from vptr_amd.parallel import shard_batch
+        args.batch = shard_batch(args.global_batch, rank, world)[1]
     ops.config.gemm_precision = args.precision
     enc, dec, T = build_models(dev, args.dropout)
     if world > 1:  # identical replicas: broadcast rank 0's parameters and buffers (what the DDP constructor does)
@@ -243,7 +336,7 @@ def main():
         res = {
             "metric": "predicted frames/sec (train step) NAR KTH 10->10 @64x64",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate/storage)" if args.precision == 3 else "bf16 (1-pass MFMA, fp32 accumulate/storage)",
             "data": "synthetic",
             "config": {"workload": "K64: KTH 64x64x1 10->10, VPTREnc/Dec(528, Tanh, reflect) + VPTRFormerNAR(4 enc + 8 dec, d=528, 8 heads, "
@@ -262,6 +355,8 @@ def main():
             except Exception as e:  # noqa
                 res["roofline"] = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
                                    "traffic": None, "error": str(e)[:200]}
+        if world == 1 and not args.no_other_configs:
+            res["other_configs"] = other_configs(dev, enc, T, trainer, args.dropout)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
