@@ -13,14 +13,54 @@ and against the fixtures under `tests/golden/` that the same script generated.
 `tests/test_oracle_golden.py` re-checks the pin on every CPU test run.
 
 Every function cites the reference file:line it follows (paths relative to
-the reference repo root).  Dropout / DropPath are identity here: the reference
-RNG stream is not reproducible across implementations, so parity is defined at
-dropout = 0.
+the reference repo root).  Dropout / DropPath are identity by default: the
+reference RNG stream is not reproducible across implementations, so the golden
+fixtures are defined at dropout = 0.  For the
+trained configuration (dropout 0.1) the masks can be INJECTED: inside a
+`with dropout_masks({site: scale tensor})` scope every nn.Dropout / attention
+dropout / DropPath site of the reference multiplies by the given tensor
+(values 0 or 1/keep), which lets a test run this oracle with exactly the masks
+another implementation drew (tests/test_dropout_parity_gpu.py).
 """
 import math
 
 import torch
 import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------
+# injected dropout / DropPath masks (test infrastructure)
+# ----------------------------------------------------------------------------
+_MASKS = [None]
+
+
+class dropout_masks:
+    """scope in which `_drop(site, x)` multiplies by masks[site]; a site that is reached without a mask raises KeyError"""
+
+    def __init__(self, masks):
+        self.masks = masks
+
+    def __enter__(self):
+        self.prev = _MASKS[0]
+        _MASKS[0] = self.masks
+        return self
+
+    def __exit__(self, *exc):
+        _MASKS[0] = self.prev
+        return False
+
+
+def _drop(site, x, dims=None):
+    """nn.Dropout / F.dropout / drop_path at `site`: identity outside a dropout_masks scope.  dims: for DropPath, the leading
+    dimensions the scale vector indexes (VidHRFormer_modules.py:563-575 draws one number per index of dim 0)."""
+    m = _MASKS[0]
+    if m is None:
+        return x
+    k = m[site].to(x.dtype)
+    if dims is not None:
+        k = k.reshape(tuple(k.shape) + (1,) * (x.dim() - k.dim()))
+    elif k.shape != x.shape:
+        raise ValueError("dropout mask of %s has shape %s, the tensor %s" % (site, tuple(k.shape), tuple(x.shape)))
+    return x * k
 
 # ----------------------------------------------------------------------------
 # position tables  (utils/position_encoding.py:29-49, 67-93, 117-161)
@@ -110,8 +150,9 @@ def _heads(x, nh):
     return x.reshape(B, L, nh, C // nh).transpose(1, 2)
 
 
-def _attend(q, k, v, bias=None, causal=False):
-    """q already scaled. q (B,nh,Lq,hd), k/v (B,nh,Lk,hd)."""
+def _attend(q, k, v, bias=None, causal=False, drop_site=None):
+    """q already scaled. q (B,nh,Lq,hd), k/v (B,nh,Lk,hd).  drop_site: dropout on the attention probabilities
+    (MultiHeadAttentionRPE.py:677-680; F.multi_head_attention_forward's dropout_p)."""
     s = q @ k.transpose(-1, -2)
     if bias is not None:
         s = s + bias
@@ -120,6 +161,8 @@ def _attend(q, k, v, bias=None, causal=False):
         m = torch.triu(torch.ones(Lq, Lk, dtype=torch.bool), diagonal=1)
         s = s.masked_fill(m, float("-inf"))
     p = s.softmax(dim=-1)
+    if drop_site is not None:
+        p = _drop(drop_site, p)
     o = p @ v
     B, nh, L, hd = o.shape
     return o.transpose(1, 2).reshape(B, L, nh * hd)
@@ -152,7 +195,7 @@ def win_attn(P, pre, xqk, xv, ws, nh, rpe, lw_pos=None):
         k = F.linear(Xq, Wk, bk)
         v = F.linear(Xv, Wv, bv)
         bias = None
-    o = _attend(_heads(q, nh), _heads(k, nh), _heads(v, nh), bias)
+    o = _attend(_heads(q, nh), _heads(k, nh), _heads(v, nh), bias, drop_site=a + "probs")
     o = F.linear(o, P[a + "out_proj.weight"], P[a + "out_proj.bias"])
     return win_reverse(o, N * T, H, W, ws).reshape(N, T, H, W, C)
 
@@ -166,7 +209,7 @@ def mha(P, pre, qi, ki, vi, nh, causal=False):
     q = F.linear(qi, Wq, bq).transpose(0, 1) * (hd ** -0.5)
     k = F.linear(ki, Wk, bk).transpose(0, 1)
     v = F.linear(vi, Wv, bv).transpose(0, 1)
-    o = _attend(_heads(q, nh), _heads(k, nh), _heads(v, nh), None, causal)
+    o = _attend(_heads(q, nh), _heads(k, nh), _heads(v, nh), None, causal, drop_site=pre + "probs")
     o = F.linear(o, P[pre + "out_proj.weight"], P[pre + "out_proj.bias"])
     return o.transpose(0, 1)
 
@@ -191,9 +234,9 @@ def conv_ffn(P, pre, x, norm, training):
     y = F.conv2d(y, P[pre + "fc1.weight"], P[pre + "fc1.bias"])
     y = F.gelu(_ffn_norm(P, pre + "norm1.", y, norm, training))
     y = F.conv2d(y, P[pre + "dw3x3.weight"], P[pre + "dw3x3.bias"], padding=1, groups=y.shape[1])
-    y = F.gelu(_ffn_norm(P, pre + "norm2.", y, norm, training))
+    y = _drop(pre + "drop.0", F.gelu(_ffn_norm(P, pre + "norm2.", y, norm, training)))      # self.drop, :431
     y = F.conv2d(y, P[pre + "fc2.weight"], P[pre + "fc2.bias"])
-    y = F.gelu(_ffn_norm(P, pre + "norm3.", y, norm, training))
+    y = _drop(pre + "drop.1", F.gelu(_ffn_norm(P, pre + "norm3.", y, norm, training)))      # self.drop again, :435
     return y.permute(0, 2, 3, 1).reshape(N, T, H, W, -1)
 
 
@@ -210,15 +253,16 @@ def enc_block(P, pre, x, lw_pos, tpos, cfg, far, training):
     N, T, H, W, C = x.shape
     nh, ws, rpe = cfg["nhead"], cfg["window_size"], cfg["rpe"]
     u = _ln(P, pre + "norm1.", x)
-    x = x + win_attn(P, pre + "SLMHSA.", u, u, ws, nh, rpe, lw_pos)
-    x = x + conv_ffn(P, pre + "SpatialFFN.", _ln(P, pre + "norm2.", x), "ln" if far else "bn", training)
+    x = x + _drop(pre + "drop_path.0", win_attn(P, pre + "SLMHSA.", u, u, ws, nh, rpe, lw_pos), dims=1)          # :68, per sample
+    x = x + _drop(pre + "drop_path.1", conv_ffn(P, pre + "SpatialFFN.", _ln(P, pre + "norm2.", x), "ln" if far else "bn", training),
+                  dims=1)                                                                                           # :71
     x = x.permute(1, 0, 2, 3, 4).reshape(T, N * H * W, C)
     u = _ln(P, pre + "norm3.", x)
     qk = u + tpos[:, None, :]
-    x = x + mha(P, pre + "temporal_MHSA.", qk, qk, u, nh, causal=far)
+    x = x + _drop(pre + "drop1", mha(P, pre + "temporal_MHSA.", qk, qk, u, nh, causal=far))                       # :79-84
     u = _ln(P, pre + "norm4.", x)
-    x = x + F.linear(F.gelu(F.linear(u, P[pre + "linear1.weight"], P[pre + "linear1.bias"])),
-                     P[pre + "linear2.weight"], P[pre + "linear2.bias"])
+    h = _drop(pre + "drop2", F.gelu(F.linear(u, P[pre + "linear1.weight"], P[pre + "linear1.bias"])))             # :88
+    x = x + _drop(pre + "drop3", F.linear(h, P[pre + "linear2.weight"], P[pre + "linear2.bias"]))                 # :89
     return x.reshape(T, N, H, W, C).permute(1, 0, 2, 3, 4)
 
 
@@ -251,26 +295,28 @@ def dec_block(P, pre, tgt, qpos, mem, lw_pos, tpos_f, tpos_p, cfg, training):
     T1 = mem.shape[1]
     nh, ws, rpe = cfg["nhead"], cfg["window_size"], cfg["rpe"]
     t = _ln(P, pre + "norm1.", tgt)
-    x = tgt + win_attn(P, pre + "SLMHSA.", t + qpos, t, ws, nh, rpe, lw_pos)
-    x = x + conv_ffn(P, pre + "SpatialFFN.", _ln(P, pre + "norm2.", x), "ln", training)
+    x = tgt + _drop(pre + "drop_path.0", win_attn(P, pre + "SLMHSA.", t + qpos, t, ws, nh, rpe, lw_pos), dims=1)   # :177
+    x = x + _drop(pre + "drop_path.1", conv_ffn(P, pre + "SpatialFFN.", _ln(P, pre + "norm2.", x), "ln", training), dims=1)  # :179
     x = x.permute(1, 0, 2, 3, 4).reshape(T2, N * H * W, C)
     u = _ln(P, pre + "norm3.", x)
     qk = u + tpos_f[:, None, :]
-    x = x + mha(P, pre + "temporal_MHSA.", qk, qk, u, nh)
+    x = x + _drop(pre + "drop1", mha(P, pre + "temporal_MHSA.", qk, qk, u, nh))                                     # :184-187
     u = _ln(P, pre + "norm4.", x)
-    x = x + F.linear(F.gelu(F.linear(u, P[pre + "linear1.weight"], P[pre + "linear1.bias"])),
-                     P[pre + "linear2.weight"], P[pre + "linear2.bias"])
+    h = _drop(pre + "drop2", F.gelu(F.linear(u, P[pre + "linear1.weight"], P[pre + "linear1.bias"])))               # :191
+    x = x + _drop(pre + "drop3", F.linear(h, P[pre + "linear2.weight"], P[pre + "linear2.bias"]))                   # :192
     if cfg.get("TSLMA", False):       # VidHRFormer_modules.py:195-199
         x = x.reshape(T2, N, H, W, C).permute(1, 0, 2, 3, 4)
         u = _ln(P, pre + "norm5.", x)
-        x = x + tslma(P, pre + "TSLMA.", mem, u + qpos, P["Tlw_pos"], ws, nh)
+        x = x + _drop(pre + "drop_path1.0", tslma(P, pre + "TSLMA.", mem, u + qpos, P["Tlw_pos"], ws, nh), dims=1)  # per sample
     else:
         u = _ln(P, pre + "norm5.", x)
         mem_s = mem.permute(1, 0, 2, 3, 4).reshape(T1, N * H * W, C)
         qpos_s = qpos.permute(1, 0, 2, 3, 4).reshape(T2, N * H * W, C)
-        x = x + mha(P, pre + "EncDecAttn.", u + qpos_s + tpos_f[:, None, :], mem_s + tpos_p[:, None, :], mem_s, nh)
+        # :204 applies drop_path1 to a (T2, N*H*W, C) tensor: ONE draw per TIME STEP, not per sample
+        x = x + _drop(pre + "drop_path1.0", mha(P, pre + "EncDecAttn.", u + qpos_s + tpos_f[:, None, :], mem_s + tpos_p[:, None, :],
+                                                mem_s, nh), dims=1)
         x = x.reshape(T2, N, H, W, C).permute(1, 0, 2, 3, 4)
-    x = x + conv_ffn(P, pre + "SpatialFFN1.", _ln(P, pre + "norm6.", x), "ln", training)
+    x = x + _drop(pre + "drop_path1.1", conv_ffn(P, pre + "SpatialFFN1.", _ln(P, pre + "norm6.", x), "ln", training), dims=1)  # :209
     return x
 
 

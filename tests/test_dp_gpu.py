@@ -1,0 +1,110 @@
+"""The data-parallel train step on real kernels: 2 ranks sharing cuda:0, gradient exchange through gloo (what one-GPU boxes can
+run; RCCL takes the same torch.distributed calls).  FARTrainer (no train-mode BatchNorm, so DP == one replica on the
+concatenated batch):
+
+  overlapped chunked exchange == plain exchange after backward == single replica on the global batch
+  (gradient slab before the optimizer step and parameters after two steps)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"] = str(rank)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import vptr_amd.model as pkg
+        from helpers import build_transformer, jload, load
+        from oracle import fill
+        from vptr_amd import ops
+        from vptr_amd.parallel import broadcast_module, shard_batch
+        from vptr_amd.train import FARTrainer
+        dev = torch.device("cuda:0")
+        z = load("step_far_tiny")
+        cfg, meta = jload(z, "cfg"), jload(z, "meta")
+        G = 4                                    # global batch, 2 per rank
+
+        def make(seed_shift):
+            enc = pkg.VPTREnc(1, meta["feat"], 3, "reflect")
+            dec = pkg.VPTRDec(1, meta["feat"], 3, meta["out_layer"], "reflect")
+            T = build_transformer(pkg, cfg, True)
+            fill.apply_fill(enc, meta["seed"])
+            fill.apply_fill(dec, meta["seed"] + 10)
+            fill.apply_fill(T, meta["seed"] + 20 + seed_shift)     # rank-dependent init: the broadcast must equalise it
+            return enc.to(dev), dec.to(dev), T.to(dev)
+
+        def batch(s):
+            past = fill.rand_input((G, cfg["Tp"], 1, meta["HW"], meta["HW"]), meta["seed"] + 100 + s).to(dev)
+            fut = fill.rand_input((G, cfg["Tf"], 1, meta["HW"], meta["HW"]), meta["seed"] + 200 + s).to(dev)
+            return past, fut
+
+        def run(parallel, overlap):
+            os.environ["VPTR_DP_OVERLAP"] = "1" if overlap else "0"
+            ops.unregister_flat_slabs()
+            enc, dec, T = make(rank if parallel else 0)
+            if parallel:
+                broadcast_module(T, 0)
+            tr = FARTrainer(enc, dec, T, lr=1e-4, max_grad_norm=1.0, process_group=dist.group.WORLD if parallel else None)
+            off, per = shard_batch(G, rank, world) if parallel else (0, G)
+            grads = []
+            for s in range(2):
+                past, fut = batch(s)
+                out = tr.step(past[off:off + per], fut[off:off + per])
+                grads.append(tr.opt.grad.detach().clone())
+            return grads, tr.opt.flat.detach().clone(), float(out["grad_norm"])
+
+        g_ov, p_ov, n_ov = run(True, True)
+        g_pl, p_pl, n_pl = run(True, False)
+        g_1, p_1, n_1 = run(False, False)
+
+        def rel(a, b):
+            return float((a.double() - b.double()).norm() / b.double().norm())
+        res = {"rank": rank,
+               "grad_overlap_vs_plain": max(rel(a, b) for a, b in zip(g_ov, g_pl)),
+               "grad_dp_vs_single": max(rel(a, b) for a, b in zip(g_pl, g_1)),
+               "param_overlap_vs_plain": rel(p_ov, p_pl), "param_dp_vs_single": rel(p_pl, p_1),
+               "norms": (n_ov, n_pl, n_1), "param_digest": float(p_ov.double().sum())}
+        q.put(res)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_two_ranks_on_one_gpu():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r["rank"])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in res:
+        assert r["grad_overlap_vs_plain"] < 1e-5, r
+        assert r["grad_dp_vs_single"] < 1e-4, r          # fp32 atomics + a different reduction order over the batch
+        assert r["param_overlap_vs_plain"] < 1e-6, r
+        assert r["param_dp_vs_single"] < 1e-5, r
+        assert abs(r["norms"][0] - r["norms"][2]) < 1e-3 * r["norms"][2], r
+    assert res[0]["param_digest"] == res[1]["param_digest"], "replicas diverged"

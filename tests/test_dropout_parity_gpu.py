@@ -1,0 +1,128 @@
+"""Mask-exact parity of the TRAINED configuration (dropout 0.1 everywhere, DropPath, the time-axis drop_path1 quirk of
+VidHRFormer_modules.py:204): the HIP model runs one train-mode forward + backward with its own counter-based masks; the same
+masks are then regenerated through the C ABI (vptr_dropout on a tensor of ones with the forward's seed and each call site's id),
+laid out the way the reference indexes each site, and injected into the reference-pinned oracle (`oracle.dropout_masks`).
+Forward output, input gradient and every parameter gradient must agree within the 1e-3 bar -- which they only do if every mask
+is applied at the position, with the index order and the scaling the reference uses, in forward AND backward."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_transformer, grad_floor, rel
+from oracle import fill
+from oracle import vptr_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+P_DROP = 0.1
+
+
+def _scale(ops, dev, seed, site, shape, p=P_DROP):
+    """the scale tensor (0 or 1/keep) the kernels apply at `site` for flat element indices 0 .. numel-1, as `shape`"""
+    from vptr_amd._lib import check, lib, ptr, stream
+    n = int(np.prod(shape))
+    ones = torch.ones(n, device=dev)
+    out = torch.empty(n, device=dev)
+    check(lib.vptr_dropout(ptr(ones), ptr(out), n, p, ptr(seed), site, stream()), "vptr_dropout")
+    return out.reshape(shape).cpu()
+
+
+@pytest.mark.parametrize("far", [False, True])
+def test_dropout_and_droppath_masks_match_reference_semantics(dev, far):
+    import vptr_amd.model as pkg
+    import vptr_amd.model.vidhrformer as V
+    from vptr_amd import ops
+    N, T, H, W, C, nh, ws = 3, 3, 8, 8, 48, 8, 4
+    cfg = dict(Tp=T, Tf=T, H=H, W=W, C=C, nhead=nh, window_size=ws, num_encoder_layers=2, num_decoder_layers=2, rpe=True)
+    m = build_transformer(pkg, cfg, far, dropout=P_DROP)
+    fill.apply_fill(m, 321)
+    P = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(dev).train()
+    x = fill.rand_normal((N, T, C, H, W), 322).abs()
+
+    # ---- DropPath scale vectors: record what the model draws, in call order
+    drawn = []
+    orig = V._droppath_scale
+
+    def recording(p, training, count, device):
+        t = orig(p, training, count, device)
+        drawn.append(t)
+        return t
+    V._droppath_scale = recording
+    try:
+        xd = x.to(dev).requires_grad_(True)
+        out = m(xd)
+    finally:
+        V._droppath_scale = orig
+    seed = ops.seed_tensor(dev).clone()      # the snapshot every op (and its backward) of this forward uses
+    HW, F = H * W, 4 * C
+    nwin = N * T * (H // ws) * (W // ws)
+    masks, it = {}, iter(drawn)
+
+    def tok(site, width, Tn):      # [rows = (n,t,h,w), width] -> (N, Tn, H, W, width)
+        return _scale(ops, dev, seed, site, (N, Tn, H, W, width))
+
+    def seq(t5):                   # (N,T,H,W,C) -> the reference's (T, N*H*W, C)
+        return t5.permute(1, 0, 2, 3, 4).reshape(t5.shape[1], N * HW, t5.shape[-1])
+
+    def nchw(t5):                  # (N,T,H,W,F) -> (N*T, F, H, W)
+        return t5.reshape(N * t5.shape[1], H, W, t5.shape[-1]).permute(0, 3, 1, 2)
+
+    def block(pre, s, Tn, dec, Tmem=None):
+        masks[pre + "SLMHSA.attn.probs"] = _scale(ops, dev, seed, s + 0, (nwin if Tn == T else N * Tn * (H // ws) * (W // ws), nh, ws * ws, ws * ws))
+        masks[pre + "drop_path.0"] = next(it).cpu()
+        masks[pre + "drop_path.1"] = next(it).cpu()
+        masks[pre + "SpatialFFN.drop.0"] = nchw(tok(s + 1, F, Tn))
+        masks[pre + "SpatialFFN.drop.1"] = nchw(tok(s + 2, C, Tn))
+        masks[pre + "temporal_MHSA.probs"] = _scale(ops, dev, seed, s + 3, (N * HW, nh, Tn, Tn))
+        masks[pre + "drop1"] = seq(tok(s + 4, C, Tn))
+        masks[pre + "drop2"] = seq(tok(s + 5, F, Tn))
+        masks[pre + "drop3"] = seq(tok(s + 6, C, Tn))
+        if dec:
+            masks[pre + "EncDecAttn.probs"] = _scale(ops, dev, seed, s + 7, (N * HW, nh, Tn, Tmem))
+            masks[pre + "drop_path1.0"] = next(it).cpu()      # T2 entries: one per TIME STEP (:204)
+            assert masks[pre + "drop_path1.0"].numel() == Tn
+            masks[pre + "drop_path1.1"] = next(it).cpu()
+            masks[pre + "SpatialFFN1.drop.0"] = nchw(tok(s + 8, F, Tn))
+            masks[pre + "SpatialFFN1.drop.1"] = nchw(tok(s + 9, C, Tn))
+
+    site = 0
+    for i in range(cfg["num_encoder_layers"]):
+        block("transformer.encoder.layers.%d." % i, site, T, False)
+        site += 16
+    if not far:
+        for i in range(cfg["num_decoder_layers"]):
+            block("transformer.decoder.layers.%d." % i, site, T, True, Tmem=T)
+            site += 16
+    assert next(it, None) is None, "the model drew more DropPath vectors than the reference has sites"
+    dropped = sum(float((v == 0).float().mean()) for v in masks.values()) / len(masks)
+    assert 0.05 < dropped < 0.15, dropped          # the masks really are ~10 % zeros
+
+    # ---- oracle with the injected masks
+    Pt = {k: v.clone() for k, v in P.items()}
+    for k, v in Pt.items():
+        if v.is_floating_point() and not (k.endswith("running_mean") or k.endswith("running_var") or k in ("temporal_pos", "lw_pos", "Tlw_pos")):
+            v.requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    fwd = O.far_forward if far else O.nar_forward
+    with O.dropout_masks(masks):
+        ref, pre = fwd(Pt, xr, cfg, training=True, return_pre=True)
+    g = fill.rand_normal(tuple(ref.shape), 323)
+    g = torch.where(pre.detach().abs() < 2e-3, torch.zeros_like(g), g)     # stay off the final ReLU's kink (oracle/make_golden.py)
+    (ref * g).sum().backward()
+    e = rel(out, ref)
+    assert e < TOL, "train forward with dropout: %.3e" % e
+    # sanity: without the masks the oracle is far away (the test would be vacuous otherwise)
+    with torch.no_grad():
+        assert rel(fwd({k: v.detach() for k, v in Pt.items()}, x, cfg, training=True), ref) > 10 * TOL
+    (out * g.to(dev)).sum().backward()
+    assert rel(xd.grad, xr.grad) < TOL, "input gradient with dropout: %.3e" % rel(xd.grad, xr.grad)
+    refg = {k: v.grad for k, v in Pt.items() if v.requires_grad and v.grad is not None}
+    floor = grad_floor(float(v.norm()) for v in refg.values())
+    worst = ("", 0.0)
+    for k, p in m.named_parameters():
+        if k in refg:
+            e = rel(p.grad, refg[k], floor)
+            if e > worst[1]:
+                worst = (k, e)
+    assert worst[1] < TOL, "parameter gradient %s with dropout: %.3e" % worst

@@ -75,7 +75,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 4) void gemm_nt(const unsign
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   constexpr int MI = 128 / (NW / 2) / 16, PPW = 40 / NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lq = lane >> 4;
+  // PROB = wave map variant: 0: wm = wave >> 1, wn = wave & 1;  1, 2: wm = wave & (NW/2 - 1), wn = wave / (NW/2) (waves w and w + 4 share
+  // a SIMD, so every SIMD then hosts one wave of each column half); 2: the 12th (padding) fragment of the odd half is skipped
+  const int wm = PROB ? (wave & (NW / 2 - 1)) : (wave >> 1), wn = PROB ? (wave / (NW / 2)) : (wave & 1), lr = lane & 15, lq = lane >> 4;
   const int tiles_n = (N + BN - 1) / BN, tiles = tiles_n * ((M + BM - 1) / BM);
   const int lg = xcd_logical();
   const int prob = lg / tiles, tile = lg - prob * tiles;
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 4) void gemm_nt(const unsign
     }
 #pragma unroll
     for (int ni = 0; ni < 6; ++ni) {
+      if (PROB == 2 && ni == 5 && wn == 1) break;   // wave-uniform
       const bf16x8 bh = *reinterpret_cast<const bf16x8*>(st + offBh[ni]);
       const bf16x8 bl = *reinterpret_cast<const bf16x8*>(st + offBl[ni]);
 #pragma unroll
@@ -314,8 +317,9 @@ static int run_nt(int M, int N, int K, int P) {
   CK(hipDeviceSynchronize());
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   std::vector<float> hD((size_t)M * N);
-  for (int nw = 4; nw <= 8; nw += 4) {
-    auto kern = nw == 4 ? gemm_nt<4, 0> : gemm_nt<8, 0>;
+  for (int var = 0; var < 4; ++var) {
+    const int nw = var == 0 ? 4 : 8;
+    auto kern = var == 0 ? gemm_nt<4, 0> : (var == 1 ? gemm_nt<8, 0> : (var == 2 ? gemm_nt<8, 1> : gemm_nt<8, 2>));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B));
     CK(hipMemset(D, 0, sd * P));
     auto launch = [&]() { kern<<<tiles * P, nw * 64, 2 * STAGE_B>>>(pA, pB, D, M, N, K, (int64_t)sa, (int64_t)sb, (int64_t)M * N); };
@@ -331,8 +335,8 @@ static int run_nt(int M, int N, int K, int P) {
       den += ref * ref;
     }
     const float us = time_us(launch, 20);
-    printf("nt %dw  M %d N %d K %d x%d  tiles %d  %8.1f us  %7.1f TFLOP/s  rel-L2 %.2e\n", nw, M, N, K, P, tiles * P, us, 2.0 * M * N * K * P / us / 1e6,
-           sqrt(num / den));
+    printf("nt %dw map%d  M %d N %d K %d x%d  tiles %d  %8.1f us  %7.1f TFLOP/s  rel-L2 %.2e\n", nw, var > 1 ? var - 1 : 0, M, N, K, P, tiles * P, us,
+           2.0 * M * N * K * P / us / 1e6, sqrt(num / den));
   }
   hipFree(dA); hipFree(dB); hipFree(D); hipFree(pA); hipFree(pB);
   return 0;

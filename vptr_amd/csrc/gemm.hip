@@ -688,7 +688,7 @@ __global__ __launch_bounds__(GNT, 4) void vptr_conv_planes_kernel(const vptr_gem
   constexpr int NFN = 11, BN = 176;
   extern __shared__ __attribute__((aligned(1024))) unsigned char pl_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lq = lane >> 4;
+  const int wm = wave & 3, wn = wave >> 2, lr = lane & 15, lq = lane >> 4;   // SIMD-balanced column halves, see gemm_p16.hip
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles = tiles_n * ((p.M + GBM - 1) / GBM);
   const int grp = xcd_logical_block() / tiles, logical = xcd_logical_block() - grp * tiles;
@@ -797,6 +797,7 @@ __global__ __launch_bounds__(GNT, 4) void vptr_conv_planes_kernel(const vptr_gem
     }
 #pragma unroll
     for (int ni = 0; ni < 6; ++ni) {
+      if (ni == 5 && wn == 1) break;   // wave-uniform: the 12th fragment of a 176-wide tile is padding
       const bf16x8 bh = *reinterpret_cast<const bf16x8*>(st + offBh[ni]);
       const bf16x8 bl = *reinterpret_cast<const bf16x8*>(st + offBl[ni]);
 #pragma unroll

@@ -32,6 +32,9 @@ class _Config:
     # P16 ("convert once") operands for every nn.Linear-shaped GEMM whose dimensions are multiples of 16 (precision 3 only):
     # the GEMMs stage pre-split bf16 hi / lo granules with global_load_lds instead of splitting fp32 in their main loops
     use_p16 = os.environ.get("VPTR_P16", "1") != "0"
+    # weight-gradient chunks on a side stream during backward (see _flush_wgrads_side); 0 = one grouped launch at the end
+    wgrad_async = os.environ.get("VPTR_WGRAD_ASYNC", "0") == "1"
+    wgrad_chunk_tiles = int(os.environ.get("VPTR_WGRAD_CHUNK", "600"))
 
 
 config = _Config()
@@ -333,6 +336,10 @@ def defer_wgrad(g, x, dW, N, K, M, db=None, alpha=1.0, p16=False):
     """record dW[N,K] += g[M,N]^T . x[M,K] (dW, and db if given, must be views of a flat gradient slab); with db the bias
     gradient db[N] += column sums of g rides on the same launch (vptr_gemm_desc::a_rowsum).  p16: g and x are P16 tensors."""
     _wgrad_q.append((g, x, dW, N, K, M, config.gemm_precision, db, float(alpha), bool(p16)))
+    if config.wgrad_async and not _wgrad_hold[0]:
+        _wgrad_side["tiles"] += ((N + 127) // 128) * ((K + 175) // 176)
+        if _wgrad_side["tiles"] >= config.wgrad_chunk_tiles:
+            _flush_wgrads_side()
     # one end-of-backward callback per recorded call: flush_wgrads is idempotent, and registering every time stays correct
     # when an earlier backward died before its callbacks ran (a "callback already queued" flag would then be stale)
     try:
@@ -364,9 +371,47 @@ class hold_wgrads:
         return False
 
 
+# ---- weight gradients on a side stream, overlapped with the rest of the backward pass -------------------------------------------
+# The grouped weight-gradient launch is MFMA-bound, about half of the backward pass's other kernels are HBM-bound (normalisation,
+# attention cores, LayerNorm) or leave CUs idle (240-tile GEMMs): instead of one launch at the very end, the recorded problems are
+# flushed in chunks of >= config.wgrad_chunk_tiles tiles onto a second HIP stream while backward keeps running on the main one.
+# g and x stay alive through record_stream (the caching allocator defers their reuse until the side stream has passed them).
+_wgrad_side = {"stream": None, "tiles": 0, "dirty": False}
+
+
+def _flush_wgrads_side():
+    items = list(_wgrad_q)
+    del _wgrad_q[:]
+    _wgrad_side["tiles"] = 0
+    if not items:
+        return
+    cur = torch.cuda.current_stream()
+    if _wgrad_side["stream"] is None:
+        _wgrad_side["stream"] = torch.cuda.Stream()
+    side = _wgrad_side["stream"]
+    side.wait_stream(cur)          # every operand recorded so far has been produced on the main stream
+    with torch.cuda.stream(side):
+        _launch_wgrad_group(items)
+    for it in items:
+        it[0].record_stream(side)
+        it[1].record_stream(side)
+    _wgrad_side["dirty"] = True
+
+
+def join_wgrad_stream():
+    """make the current stream wait for weight-gradient chunks still running on the side stream (before the optimizer reads them)"""
+    if _wgrad_side["dirty"]:
+        torch.cuda.current_stream().wait_stream(_wgrad_side["stream"])
+        _wgrad_side["dirty"] = False
+
+
 def _auto_flush_wgrads():
     if not _wgrad_hold[0]:
-        flush_wgrads()
+        if config.wgrad_async and _wgrad_q:
+            _flush_wgrads_side()
+        else:
+            flush_wgrads()
+        join_wgrad_stream()
 
 
 _pin_pool = {"slots": [], "next": 0}

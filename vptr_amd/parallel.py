@@ -40,6 +40,35 @@ def broadcast_buffers(module, src=0, group=None):
             _broadcast_any(b, src, group)
 
 
+class BufferSync:
+    """DDP's per-forward buffer broadcast (`broadcast_buffers=True`, the default the reference relies on: train_NAR_mp.py:94-95,118)
+    for the only buffers that change during training -- the BatchNorm running statistics of the NAR-encoder conv-FFNs -- as ONE
+    flat collective per step instead of one per buffer: rank `src`'s running_mean / running_var / num_batches_tracked replace
+    everybody's before the forward pass, so evaluation and checkpoints agree across ranks."""
+
+    def __init__(self, module, src=0, group=None):
+        self.src, self.group = src, group
+        self.bufs = []
+        for m in module.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats:
+                self.bufs += [m.running_mean, m.running_var, m.num_batches_tracked]
+
+    def __bool__(self):
+        return bool(self.bufs)
+
+    def sync(self):
+        if not self.bufs or dist.get_world_size(self.group) == 1:
+            return
+        with torch.no_grad():
+            flat = torch.cat([b.reshape(-1).to(torch.float32) for b in self.bufs])   # num_batches_tracked: exact in fp32 below 2^24
+            dist.broadcast(flat, self.src, group=self.group)
+            off = 0
+            for b in self.bufs:
+                n = b.numel()
+                b.copy_(flat[off:off + n].view(b.shape))
+                off += n
+
+
 def allreduce_mean_(flat, group=None, bucket_elems=16 << 20):
     """In-place mean over ranks of a flat tensor, in buckets of `bucket_elems` elements (64 MB fp32 by default)."""
     world = dist.get_world_size(group)

@@ -192,6 +192,10 @@ class NARTrainer:
         self.mse, self.gdl = MSELoss(), GDL(alpha=1)
         self.bpnce = BiPatchNCE(batch_size, self.T.num_future_frames, self.T.transformer.H, self.T.transformer.W, 1.0).to(dev)
         self.lam_pc = lam_pc
+        self._bufsync = None
+        if process_group is not None and torch.distributed.get_world_size(process_group) > 1:
+            from .parallel import BufferSync
+            self._bufsync = BufferSync(self.T, 0, process_group)   # DDP's per-forward broadcast of rank 0's BatchNorm statistics
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.bucket_elems = bucket_mb * (1 << 20) // 4
@@ -291,6 +295,8 @@ class NARTrainer:
         self.opt.zero_grad()
         if self.dec_weight_grads:
             self.dec.zero_grad(set_to_none=True)  # train_NAR.py:61
+        if self._bufsync:
+            self._bufsync.sync()
         pred_feats = self.T(past_feats)
         pred_frames = self.dec(pred_feats)
         extra = {}
@@ -366,9 +372,7 @@ class FARTrainer(NARTrainer):
             mod._vptr_frozen = True
         self.opt = FlatAdamW(self.T.parameters(), lr=lr, max_grad_norm=max_grad_norm, channel_last=_channel_last_ids(self.T))
         self.mse, self.gdl = MSELoss(), GDL(alpha=1)
-        self.pg = process_group
-        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
-        self.bucket_elems = bucket_mb * (1 << 20) // 4
+        self._bufsync = None   # the FAR transformer has no BatchNorm (LayerNorm conv-FFNs): nothing to broadcast per forward
         self._graph = None
 
     def _step_impl(self, past, future):
