@@ -136,30 +136,88 @@ def gemm_roofline(trainer, past, fut, precision):
     tot_ms = sum(d[2] for d in by.values())
     dom = max(by.items(), key=lambda kv: kv[1][2])
     (nfn, prec, am, bm), (cnt, fl, ms) = (dom[0][:4], dom[1])
-    kname = "vptr_gemm_grouped_kernel" if len(dom[0]) > 4 else "vptr_gemm_kernel_p"
+    grouped = len(dom[0]) > 4
+
+    def kernel_name(nfn, prec, am, bm, grouped):
+        if am == 5:
+            return "vptr_gemm_p16_kernel"
+        if am == 6:
+            return "vptr_wgrad_p16_kernel"
+        if am == 3:
+            return "vptr_conv_planes_kernel<true>"
+        return "%s<%d, %d, %d, %d>" % ("vptr_gemm_grouped_kernel" if grouped else "vptr_gemm_kernel_p", nfn, prec, am, bm)
+    kname = kernel_name(nfn, prec, am, bm, grouped)
     peak = MFMA_PEAK_TFLOPS
     ach = fl / (ms * 1e-3) / 1e12
-    # HBM-side bytes per launch of that kernel: PMC counters cannot be read in-process, so this is the committed
-    # rocprofv3 measurement of this same command (tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes; KB units;
-    # FETCH_SIZE doubled for 16-B/lane streaming reads on gfx950 as MI355X_MICROARCH.md prescribes).
-    traffic = None
+    # HBM-side bytes per launch of that kernel: PMC counters cannot be read in-process, so this is the committed rocprofv3
+    # measurement of this same step (tools/prof_r02.sh: separate FETCH_SIZE / WRITE_SIZE passes; KB units; FETCH_SIZE doubled for
+    # 16-B/lane streaming reads on gfx950 as MI355X_MICROARCH.md prescribes).  The file names the kernels it was taken with: if the
+    # dominant kernel of THIS run is not in it, the entry is stale and traffic stays null with the reason spelt out.
+    traffic, traffic_source = None, None
+    src = os.path.join("profiles", "r02_pmc_traffic.json")
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        e = pm.get("%s<%d, %d, %d, %d>" % (kname, nfn, prec, am, bm))
+        pm = json.load(open(os.path.join(ROOT, src)))
+        e = pm.get("kernels", {}).get(kname)
         if e:
             traffic = round((2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0)
-    except Exception:  # noqa
-        pass
+            traffic_source = "static: %s (rocprofv3 PMC passes of `%s`), average over %d launches" % (src, pm.get("command", "bench.py"), e["launches"])
+        else:
+            traffic_source = "STALE: %s holds no entry for %s -- re-run tools/prof_r02.sh" % (src, kname)
+    except Exception as ex:  # noqa
+        traffic_source = "unavailable: %s" % str(ex)[:120]
+    per_kernel = {}
+    for key, (c_, f_, m_) in sorted(by.items(), key=lambda kv: -kv[1][2]):
+        per_kernel.setdefault(kernel_name(key[0], key[1], key[2], key[3], len(key) > 4), [0, 0.0, 0.0])
+        d = per_kernel[kernel_name(key[0], key[1], key[2], key[3], len(key) > 4)]
+        d[0] += c_
+        d[1] += f_
+        d[2] += m_
     return {
         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-        "traffic_unit": "HBM-side bytes per launch (profiles/r01_pmc_traffic.json)",
-        "kernel": "%s<NFN=%d,NPASS=%d,A=%d,B=%d>" % (kname, nfn, prec, am, bm),
+        "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_source,
+        "kernel": kname,
         "launches_per_step": cnt, "avg_launch_us": round(ms * 1e3 / cnt, 2), "alg_gflop_per_launch": round(fl / cnt / 1e9, 3),
         "all_gemm": {"launches_per_step": sum(d[0] for d in by.values()), "ms_per_step": round(tot_ms, 3),
                      "achieved": round(tot_f / (tot_ms * 1e-3) / 1e12, 2), "alg_gflop_per_step": round(tot_f / 1e9, 1)},
-        "note": "algorithmic FLOPs = 2*M*N*K per launch; NPASS=3 issues 3 bf16 MFMA passes per algorithmic FLOP "
-                "(split-bf16, fp32-class accuracy), so its ceiling is peak/3",
+        "per_kernel": {k: {"launches": d[0], "ms_per_step": round(d[2], 3), "achieved": round(d[1] / (d[2] * 1e-3) / 1e12, 1)}
+                       for k, d in per_kernel.items()},
+        "hbm": hbm_roofline(),
+        "note": "algorithmic FLOPs = 2*M*N*K per launch (HIP events on the launch stream around every GEMM launch of one instrumented "
+                "step); the split-bf16 kernels issue 3 bf16 MFMA passes per algorithmic FLOP (fp32-class accuracy), so their ceiling "
+                "is peak/3 = 833 TFLOP/s, and ~480 TFLOP/s under the MFMA power envelope (DESIGN.md section 4)",
     }
+
+
+HBM_PEAK_GBS = 8000.0
+
+
+def hbm_roofline():
+    """achieved GB/s of the largest HBM-bound pass of the step, timed with HIP events on its own (20 launches): the LayerNorm((F,H,W))
+    + GELU normalisation of a conv-FFN hidden tensor [10 240 x 2112] fp32: algorithmic bytes = read x + write y = 2 x 86.5 MB."""
+    import vptr_amd.ops as ops
+    try:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        rows, F, HW = PER_GPU_BATCH * TF * 64, 2112, 64
+        x = torch.randn(rows, F, device=dev)
+        w, b = torch.randn(HW, F, device=dev), torch.randn(HW, F, device=dev)
+        with torch.no_grad():
+            for _ in range(3):
+                ops.norm_act(x, w, b, "ln", HW, True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            # statistics pass + normalise pass per call; time the pair
+            e0.record()
+            for _ in range(20):
+                ops.norm_act(x, w, b, "ln", HW, True)
+            e1.record()
+            torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 20
+        nbytes = 3.0 * rows * F * 4      # statistics pass reads x; normalise pass reads x and writes y
+        return {"kernels": "vptr_groupstats + vptr_norm_act_fwd (LayerNorm((2112,8,8)) + GELU on [10240 x 2112] fp32)", "us_per_call": round(us, 2),
+                "alg_bytes": int(nbytes), "achieved": round(nbytes / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
+                "note": "the 86.5 MB tensor fits the 256 MB Infinity Cache: re-reads are served on-die, so this is an L2/MALL-side rate"}
+    except Exception as ex:  # noqa
+        return {"error": str(ex)[:160]}
 
 
 def _time_steps(step, warm=2, timed=3):
