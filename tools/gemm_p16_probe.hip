@@ -174,6 +174,107 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 4) void gemm_nt(const unsign
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// nt64: 64 x 176 tiles, 4 waves (2 x 2 of 32 x 96), 32 KB stages: twice the tiles of the 128-row kernel for the N = 528 outputs
+// (240 tiles on 256 CUs = one lone workgroup per CU) so that two workgroups share a CU and cover each other's barrier phases
+__global__ __launch_bounds__(256, 2) void gemm_nt64(const unsigned char* __restrict__ A, const unsigned char* __restrict__ B, float* __restrict__ D, int M, int N,
+                                                    int K, int64_t strideA, int64_t strideB, int64_t strideD) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr int ST = 32 * 1024;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1, lr = lane & 15, lq = lane >> 4;
+  const int tiles_n = (N + BN - 1) / BN, tiles = tiles_n * ((M + 63) / 64);
+  const int lg = xcd_logical();
+  const int prob = lg / tiles, tile = lg - prob * tiles;
+  A += prob * strideA; B += prob * strideB; D += prob * strideD;
+  const int m0 = (tile / tiles_n) * 64, n0 = (tile % tiles_n) * BN;
+  const int nk = (K + BK - 1) / BK;
+  const bool ktail = (K & 31) != 0;
+  const int64_t pitch = (int64_t)K * 4;
+  const unsigned char* src[8];
+  int tail_adj[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int u = wave + 4 * i;
+    const bool isA = u < 8;
+    const int prow = (isA ? u : u - 8) * 8 + (lane >> 3), pch = lane & 7;
+    const int c = pch ^ ((prow >> 1) & 7);
+    const int grow = isA ? min(m0 + prow, M - 1) : min(n0 + prow, N - 1);
+    src[i] = (isA ? A : B) + grow * pitch + c * 16;
+    tail_adj[i] = c >= 4 ? -64 : 0;
+  }
+  auto issue = [&](const int kt, const int stage) {
+    const bool last = ktail && kt == nk - 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned char* g = src[i] + (int64_t)kt * 128 + (last ? tail_adj[i] : 0);
+      const uint32_t laddr = (uint32_t)(stage * ST + (wave + 4 * i) * 1024);
+      GLDS(laddr, g);
+    }
+  };
+  f32x4 acc[2][6];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int offAh[2], offBh[6];
+  const int ch = (lq >> 1) * 4 + (lq & 1);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int r = wm * 32 + mi * 16 + lr, f = (r >> 1) & 7;
+    offAh[mi] = r * 128 + ((ch ^ f) << 4);
+  }
+#pragma unroll
+  for (int ni = 0; ni < 6; ++ni) {
+    const int r = (wn * 6 + ni) * 16 + lr, f = (r >> 1) & 7;
+    offBh[ni] = 8192 + r * 128 + ((ch ^ f) << 4);
+  }
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    const unsigned char* st = smem + (kt & 1) * ST;
+    bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      ah[mi] = *reinterpret_cast<const bf16x8*>(st + offAh[mi]);
+      al[mi] = *reinterpret_cast<const bf16x8*>(st + (offAh[mi] ^ 32));
+    }
+    if (ktail && kt == nk - 1 && lq >= 2) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        ah[mi] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        al[mi] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) {
+      if (ni == 5 && wn == 1) break;
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(st + offBh[ni]);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(st + (offBh[ni] ^ 32));
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int ni = 0; ni < 6; ++ni) {
+    const int nf = wn * 6 + ni, col = n0 + nf * 16 + lr;
+    if (nf >= 11 || col >= N) continue;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 32 + mi * 16 + lq * 4 + r;
+        if (row < M) D[(int64_t)row * N + col] = acc[mi][ni][r];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // tn: D[NG][KX] = sum_t G[t][ng] X[t][kx];  T % 32 == 0 in the probe.
 // Stage = 40 pieces of [8 t][128 B]; a piece holds, for one pair of granules, 4 mini-subtiles [8 t][16 ch] (g0 hi, g0 lo, g1 hi,
 // g1 lo) of 256 bytes each: lane L of the DMA fetches chunk (L >> 4) * 2 + (L & 1) of row (L & 15) >> 1 -- whole 128-byte lines
@@ -317,12 +418,14 @@ static int run_nt(int M, int N, int K, int P) {
   CK(hipDeviceSynchronize());
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   std::vector<float> hD((size_t)M * N);
-  for (int var = 0; var < 4; ++var) {
-    const int nw = var == 0 ? 4 : 8;
-    auto kern = var == 0 ? gemm_nt<4, 0> : (var == 1 ? gemm_nt<8, 0> : (var == 2 ? gemm_nt<8, 1> : gemm_nt<8, 2>));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B));
+  for (int var = 1; var < 5; ++var) {
+    const int nw = var == 0 || var == 4 ? 4 : 8;
+    auto kern = var == 0 ? gemm_nt<4, 0> : (var == 1 ? gemm_nt<8, 0> : (var == 2 ? gemm_nt<8, 1> : (var == 3 ? gemm_nt<8, 2> : gemm_nt64)));
+    const int lds = var == 4 ? 64 * 1024 : 2 * STAGE_B;
+    const int ntile = var == 4 ? ((M + 63) / 64) * ((N + BN - 1) / BN) : tiles;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     CK(hipMemset(D, 0, sd * P));
-    auto launch = [&]() { kern<<<tiles * P, nw * 64, 2 * STAGE_B>>>(pA, pB, D, M, N, K, (int64_t)sa, (int64_t)sb, (int64_t)M * N); };
+    auto launch = [&]() { kern<<<ntile * P, nw * 64, lds>>>(pA, pB, D, M, N, K, (int64_t)sa, (int64_t)sb, (int64_t)M * N); };
     launch();
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(hD.data(), D + (size_t)(P - 1) * M * N, sd, hipMemcpyDeviceToHost));
@@ -335,7 +438,7 @@ static int run_nt(int M, int N, int K, int P) {
       den += ref * ref;
     }
     const float us = time_us(launch, 20);
-    printf("nt %dw map%d  M %d N %d K %d x%d  tiles %d  %8.1f us  %7.1f TFLOP/s  rel-L2 %.2e\n", nw, var > 1 ? var - 1 : 0, M, N, K, P, tiles * P, us,
+    printf("nt %dw map%d  M %d N %d K %d x%d  tiles %d  %8.1f us  %7.1f TFLOP/s  rel-L2 %.2e\n", nw, var > 1 ? var - 1 : 0, M, N, K, P, ntile * P, us,
            2.0 * M * N * K * P / us / 1e6, sqrt(num / den));
   }
   hipFree(dA); hipFree(dB); hipFree(D); hipFree(pA); hipFree(pB);
