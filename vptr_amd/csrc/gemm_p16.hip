@@ -446,6 +446,12 @@ int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* des
     }
     attr_set = true;
   }
-  vptr_wgrad_p16_kernel<<<total_tiles, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count);
+  static int pad = -1;   // VPTR_WGRAD_LDS_PAD (bytes): experiments on the number of co-resident workgroups (> 0 forces one per CU)
+  if (pad < 0) {
+    const char* e = getenv("VPTR_WGRAD_LDS_PAD");
+    pad = e ? atoi(e) : 0;
+    if (pad > 0) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE + pad);
+  }
+  vptr_wgrad_p16_kernel<<<total_tiles, GNT, 2 * P16_STAGE + pad, st>>>(descs_dev, tile_start_dev, count);
   return 0;
 }
