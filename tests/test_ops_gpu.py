@@ -291,9 +291,12 @@ def test_rowtab_colsum(ops, dev):
 
 
 # ----------------------------------------------------------------------------------------------------------- attention
-@pytest.mark.parametrize("ws,H,W", [(4, 8, 8), (8, 16, 8)])
-def test_window_attention(ops, dev, ws, H, W):
-    B, C, nh = 3, 48, 8
+TOLA = 5e-5   # attention cores: split-bf16 MFMA products (forward; gradients 1e-4)
+
+
+@pytest.mark.parametrize("ws,H,W,C", [(4, 8, 8, 48), (8, 16, 8, 48), (4, 8, 8, 528), (8, 16, 16, 528), (2, 4, 6, 64)])
+def test_window_attention(ops, dev, ws, H, W, C):
+    B, nh = 3, 8
     L = ws * ws
     q, k, v = rn((B * H * W, C), 50, 0.5), rn((B * H * W, C), 51, 0.5), rn((B * H * W, C), 52)
     table = rn(((2 * ws - 1) ** 2, nh), 53, 0.5)
@@ -310,20 +313,23 @@ def test_window_attention(ops, dev, ws, H, W):
     ds = [t.to(dev).requires_grad_(True) for t in (q, k, v, table)]
     od = ops.window_attention(ds[0], ds[1], ds[2], ds[3], idx.to(dev), B, H, W, nh, ws)
     (od * go.to(dev)).sum().backward()
-    assert rel(od, o) < TOLV
+    assert rel(od, o) < TOLA
     for a, c in zip(ds, ins):
-        assert rel(a.grad, c.grad) < 5e-5
+        assert rel(a.grad, c.grad) < 1e-4
     # without a bias table (rpe=False path)
     od2 = ops.window_attention(ds[0].detach(), ds[1].detach(), ds[2].detach(), None, None, B, H, W, nh, ws)
     o2 = O._attend(O._heads(part(q.double()), nh), O._heads(part(k.double()), nh), O._heads(part(v.double()), nh), None)
-    assert rel(od2, O.win_reverse(o2, B, H, W, ws).reshape(B * H * W, C)) < TOLV
+    assert rel(od2, O.win_reverse(o2, B, H, W, ws).reshape(B * H * W, C)) < TOLA
 
 
-@pytest.mark.parametrize("Tq,Tk,causal,N,HW", [(5, 5, False, 2, 6), (5, 5, True, 2, 6), (3, 7, False, 2, 6), (29, 29, True, 2, 6),
-                                               # >= 256 pixel problems: the variant with 4 pixels per wave + register prefetch
-                                               (5, 5, True, 3, 90), (3, 7, False, 3, 90), (10, 10, False, 2, 129)])
-def test_temporal_attention(ops, dev, Tq, Tk, causal, N, HW):
-    C, nh = 48, 8
+@pytest.mark.parametrize("Tq,Tk,causal,N,HW,C", [(5, 5, False, 2, 6, 48), (5, 5, True, 2, 6, 48), (3, 7, False, 2, 6, 48), (29, 29, True, 2, 6, 48),
+                                                 # >= 256 pixel problems: the variant with 4 pixels per wave + register prefetch
+                                                 (5, 5, True, 3, 90, 48), (3, 7, False, 3, 90, 48), (10, 10, False, 2, 129, 48),
+                                                 # head dim 66 (the model's), the long sequences of BASELINE configs 4 / 5
+                                                 (10, 10, False, 2, 64, 528), (29, 29, True, 1, 16, 528), (40, 10, False, 1, 20, 528),
+                                                 (50, 50, False, 1, 9, 528), (64, 33, False, 1, 5, 128)])
+def test_temporal_attention(ops, dev, Tq, Tk, causal, N, HW, C):
+    nh = 8
     q, k, v = rn((N * Tq * HW, C), 60, 0.5), rn((N * Tk * HW, C), 61, 0.5), rn((N * Tk * HW, C), 62)
     go = rn((N * Tq * HW, C), 63)
     ins = [t.double().clone().requires_grad_(True) for t in (q, k, v)]
@@ -336,9 +342,9 @@ def test_temporal_attention(ops, dev, Tq, Tk, causal, N, HW):
     ds = [t.to(dev).requires_grad_(True) for t in (q, k, v)]
     od = ops.temporal_attention(ds[0], ds[1], ds[2], N, Tq, Tk, HW, nh, causal)
     (od * go.to(dev)).sum().backward()
-    assert rel(od, o) < TOLV
+    assert rel(od, o) < TOLA
     for a, c in zip(ds, ins):
-        assert rel(a.grad, c.grad) < 5e-5
+        assert rel(a.grad, c.grad) < 1e-4
 
 
 def _proj_ref(ops, xq, xk, xv, Ws, bs, nh, attend):

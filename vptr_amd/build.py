@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libvptr_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_p16.hip", "norm.hip", "attn.hip", "elementwise.hip", "conv7.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_p16.hip", "norm.hip", "attn.hip", "attn_mfma.hip", "elementwise.hip", "conv7.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast", "-fno-slp-vectorize",
          "-Wno-unused-result"]
 
@@ -40,7 +40,7 @@ def _digest(paths):
 def _compile(src, force):
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
     stamp = obj + ".sha"
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_shared.h"),
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_shared.h"), os.path.join(CSRC, "attn_mfma.h"),
             os.path.join(HERE, "..", "include", "vptr_hip.h")]
     dig = _digest(deps)
     if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:

@@ -2,7 +2,7 @@
 // per-pixel temporal attention.  Problems are tiny (16x16 or 64x64 windows, T<=50 time steps, head_dim 66), i.e.
 // 0.4 % of the model FLOPs, so they run in exact fp32 on the vector ALUs with every tile staged once through LDS;
 // the window partition / (T, N*HW, C) permutes of the reference are pure index arithmetic here.
-#include "common.h"
+#include "attn_mfma.h"
 
 #define ATT_MAXL 64   // max tokens per window (ws <= 8)
 #define ATT_MAXT 64   // max time steps
@@ -305,6 +305,13 @@ extern "C" int vptr_winattn_fwd(const float* q, const float* k, const float* v, 
   if (bias_table) VPTR_CHECK(rel_index != nullptr, "winattn_fwd: bias table needs rel_index");
   if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "winattn_fwd: dropout needs seed_dev");
   const int L = ws * ws, hd = C / nh;
+  if (vptr_attn_mfma_ok(L, L, C, nh, 0)) {
+    AmGeom gm = {0, H, W, ws, 0, 0, 0, L, L, C, nh, hd, B * (H / ws) * (W / ws)};
+    const int rc = vptr_attn_mfma_fwd(q, k, v, bias_table, rel_index, o, gm, 0, dropout_p, seed_dev, site, p16, (hipStream_t)stream);
+    if (rc) return rc;
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
   if (ws == 4 && hd % 2 == 0 && C % 2 == 0) {
     const int nwin = B * (H / 4) * (W / 4);
     const int wpb = nwin >= 64 ? 2 : 1;   // two windows per workgroup: the second one's loads overlap the first one's math
@@ -434,6 +441,14 @@ extern "C" int vptr_winattn_bwd(const float* q, const float* k, const float* v, 
   if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "winattn_bwd: dropout needs seed_dev");
   const int L = ws * ws, hd = C / nh, ntab = (2 * ws - 1) * (2 * ws - 1);
   const int nwin = B * (H / ws) * (W / ws);
+  if (vptr_attn_mfma_ok(L, L, C, nh, 0)) {
+    AmGeom gm = {0, H, W, ws, 0, 0, 0, L, L, C, nh, hd, nwin};
+    const int rc = vptr_attn_mfma_bwd(q, k, v, bias_table, rel_index, dout, dq, dk, dv, dbias_table, gm, 0, dropout_p, seed_dev, site, dq_scale, p16,
+                                      (hipStream_t)stream);
+    if (rc) return rc;
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
   if (ws == 4 && hd % 2 == 0 && C % 2 == 0) {
     // many windows per workgroup: the 49 bias-table atomics per workgroup hit the same 49*nh addresses from every workgroup
     // with a bias-table gradient, fewer and longer workgroups (their 49 atomics per head all hit the same 392 words)
@@ -725,6 +740,13 @@ extern "C" int vptr_tattn_fwd(const float* q, const float* k, const float* v, fl
   if (causal) VPTR_CHECK(Tq == Tk, "tattn_fwd: causal mask needs Tq == Tk");
   if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "tattn_fwd: dropout needs seed_dev");
   const int hd = C / nh;
+  if (vptr_attn_mfma_ok(Tq, Tk, C, nh, causal)) {
+    AmGeom gm = {1, 0, 0, 0, Tq, Tk, HW, Tq, Tk, C, nh, hd, Nb * HW};
+    const int rc = vptr_attn_mfma_fwd(q, k, v, nullptr, nullptr, o, gm, causal, dropout_p, seed_dev, site, p16, (hipStream_t)stream);
+    if (rc) return rc;
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
   if (Tq <= 16 && Tk <= 16 && hd % 2 == 0 && C % 2 == 0) {
     const size_t lds16 = sizeof(float) * ((Tq + 2 * Tk) * att_pitch(hd) + 16 * 20);
     const int items = (Tq > Tk ? Tq : Tk) * (att_pitch(hd) / 2);
@@ -840,6 +862,14 @@ extern "C" int vptr_tattn_bwd(const float* q, const float* k, const float* v, co
   if (causal) VPTR_CHECK(Tq == Tk, "tattn_bwd: causal mask needs Tq == Tk");
   if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "tattn_bwd: dropout needs seed_dev");
   const int hd = C / nh;
+  if (vptr_attn_mfma_ok(Tq, Tk, C, nh, causal)) {
+    AmGeom gm = {1, 0, 0, 0, Tq, Tk, HW, Tq, Tk, C, nh, hd, Nb * HW};
+    const int rc = vptr_attn_mfma_bwd(q, k, v, nullptr, nullptr, dout, dq, dk, dv, nullptr, gm, causal, dropout_p, seed_dev, site, dq_scale, p16,
+                                      (hipStream_t)stream);
+    if (rc) return rc;
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
   if (Tq <= 16 && Tk <= 16 && hd % 2 == 0 && C % 2 == 0) {
     const size_t lds16 = sizeof(float) * (2 * (Tq + Tk) * att_pitch(hd) + 2 * 16 * 20);
     const int items = (Tq > Tk ? Tq : Tk) * (att_pitch(hd) / 2);
