@@ -27,8 +27,23 @@ def _scale(ops, dev, seed, site, shape, p=P_DROP):
     return out.reshape(shape).cpu()
 
 
+@pytest.fixture(params=["default", "mfma"])
+def attn_kernels(request):
+    """the attention-probability masks through both kernel families (16-token problems default to the fp32 vector kernels;
+    VPTR_ATTN_MFMA=2 sends them through the matrix-core kernels, which must hash the same element indices)"""
+    import os
+    old = os.environ.get("VPTR_ATTN_MFMA")
+    if request.param == "mfma":
+        os.environ["VPTR_ATTN_MFMA"] = "2"
+    yield request.param
+    if old is None:
+        os.environ.pop("VPTR_ATTN_MFMA", None)
+    else:
+        os.environ["VPTR_ATTN_MFMA"] = old
+
+
 @pytest.mark.parametrize("far", [False, True])
-def test_dropout_and_droppath_masks_match_reference_semantics(dev, far):
+def test_dropout_and_droppath_masks_match_reference_semantics(dev, far, attn_kernels):
     import vptr_amd.model as pkg
     import vptr_amd.model.vidhrformer as V
     from vptr_amd import ops
@@ -95,8 +110,8 @@ def test_dropout_and_droppath_masks_match_reference_semantics(dev, far):
             block("transformer.decoder.layers.%d." % i, site, T, True, Tmem=T)
             site += 16
     assert next(it, None) is None, "the model drew more DropPath vectors than the reference has sites"
-    dropped = sum(float((v == 0).float().mean()) for v in masks.values()) / len(masks)
-    assert 0.05 < dropped < 0.15, dropped          # the masks really are ~10 % zeros
+    dropped = sum(float((v == 0).sum()) for v in masks.values()) / sum(v.numel() for v in masks.values())
+    assert 0.08 < dropped < 0.12, dropped          # the masks really are ~10 % zeros (element-weighted: DropPath vectors are tiny)
 
     # ---- oracle with the injected masks
     Pt = {k: v.clone() for k, v in P.items()}

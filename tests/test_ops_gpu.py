@@ -294,8 +294,22 @@ def test_rowtab_colsum(ops, dev):
 TOLA = 5e-5   # attention cores: split-bf16 MFMA products (forward; gradients 1e-4)
 
 
+@pytest.fixture(params=["mfma", "vector"])
+def attn_mode(request):
+    """every attention geometry through both families of kernels: VPTR_ATTN_MFMA=2 forces the matrix-core kernels wherever they
+    cover the geometry, 0 the fp32 vector kernels (the default mixes them by problem size)"""
+    import os
+    old = os.environ.get("VPTR_ATTN_MFMA")
+    os.environ["VPTR_ATTN_MFMA"] = "2" if request.param == "mfma" else "0"
+    yield request.param
+    if old is None:
+        os.environ.pop("VPTR_ATTN_MFMA", None)
+    else:
+        os.environ["VPTR_ATTN_MFMA"] = old
+
+
 @pytest.mark.parametrize("ws,H,W,C", [(4, 8, 8, 48), (8, 16, 8, 48), (4, 8, 8, 528), (8, 16, 16, 528), (2, 4, 6, 64)])
-def test_window_attention(ops, dev, ws, H, W, C):
+def test_window_attention(ops, dev, attn_mode, ws, H, W, C):
     B, nh = 3, 8
     L = ws * ws
     q, k, v = rn((B * H * W, C), 50, 0.5), rn((B * H * W, C), 51, 0.5), rn((B * H * W, C), 52)
@@ -328,7 +342,7 @@ def test_window_attention(ops, dev, ws, H, W, C):
                                                  # head dim 66 (the model's), the long sequences of BASELINE configs 4 / 5
                                                  (10, 10, False, 2, 64, 528), (29, 29, True, 1, 16, 528), (40, 10, False, 1, 20, 528),
                                                  (50, 50, False, 1, 9, 528), (64, 33, False, 1, 5, 128)])
-def test_temporal_attention(ops, dev, Tq, Tk, causal, N, HW, C):
+def test_temporal_attention(ops, dev, attn_mode, Tq, Tk, causal, N, HW, C):
     nh = 8
     q, k, v = rn((N * Tq * HW, C), 60, 0.5), rn((N * Tk * HW, C), 61, 0.5), rn((N * Tk * HW, C), 62)
     go = rn((N * Tq * HW, C), 63)

@@ -493,19 +493,19 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const float* __restr
   }
 }
 
-static int am_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("VPTR_ATTN_MFMA");
-    v = e ? atoi(e) : 1;
-  }
-  return v;
+static int am_enabled() {   // read per call: tests switch the mode inside one process
+  const char* e = getenv("VPTR_ATTN_MFMA");
+  return e ? atoi(e) : 1;
 }
 
 // true when the MFMA kernels cover the geometry (otherwise the fp32 vector kernels of attn.hip run)
 bool vptr_attn_mfma_ok(int Lq, int Lk, int C, int nh, int causal) {
   const int hd = C / nh;
-  return am_enabled() && Lq >= 1 && Lk >= 1 && Lq <= AM_MAXL && Lk <= AM_MAXL && hd % 2 == 0 && C % 2 == 0 && hd <= 96 && (!causal || Lq == Lk);
+  // VPTR_ATTN_MFMA: 0 = never, 1 (default) = problems with more than 16 rows (the 16-token fp32 vector kernels of attn.hip are
+  // faster on 16 x 16 problems: K64 step 56.9 vs 61.0 ms), 2 = every covered geometry
+  const int mode = am_enabled();
+  if (mode == 0 || (mode == 1 && Lq <= 16 && Lk <= 16)) return false;
+  return Lq >= 1 && Lk >= 1 && Lq <= AM_MAXL && Lk <= AM_MAXL && hd % 2 == 0 && C % 2 == 0 && hd <= 96 && (!causal || Lq == Lk);
 }
 
 template <int NKS, int NDF>
