@@ -1,0 +1,77 @@
+"""Whole-step hipGraph (`NARTrainer.capture`): replays must equal eager steps.  The step is deterministic up to the order of fp32
+atomics -- also with dropout 0.1, because the dropout masks come from the device-resident counter seed that eager steps and replays
+advance identically; only the DropPath vectors come from torch's generator (whose offsets differ under capture), so they are
+switched off here.  Losses, gradient norms and post-step parameters of 10 replays (5 with a device -> host read after each, 5
+back-to-back) are compared with 10 eager steps from the same initial state."""
+import pytest
+import torch
+
+from helpers import build_transformer, jload, load
+from oracle import fill
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(pkg, cfg, meta, dev, dropout):
+    enc = pkg.VPTREnc(1, meta["feat"], 3, "reflect")
+    dec = pkg.VPTRDec(1, meta["feat"], 3, "Tanh", "reflect")
+    T = build_transformer(pkg, cfg, False, dropout=dropout)
+    fill.apply_fill(enc, meta["seed"])
+    fill.apply_fill(dec, meta["seed"] + 10)
+    fill.apply_fill(T, meta["seed"] + 20)
+    return enc.to(dev), dec.to(dev), T.to(dev)
+
+
+def _batch(meta, cfg, s, dev):
+    past = ((fill.rand_input((meta["N"], cfg["Tp"], 1, meta["HW"], meta["HW"]), meta["seed"] + 100 + s) - 0.6013795) / 2.7570653).to(dev)
+    fut = ((fill.rand_input((meta["N"], cfg["Tf"], 1, meta["HW"], meta["HW"]), meta["seed"] + 200 + s) - 0.6013795) / 2.7570653).to(dev)
+    return past, fut
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_graph_replays_match_eager_steps(dev, dropout, monkeypatch):
+    import vptr_amd.model as pkg
+    import vptr_amd.model.vidhrformer as V
+    from vptr_amd import ops
+    from vptr_amd.train import NARTrainer
+    monkeypatch.setattr(V, "_droppath_scale", lambda p, training, count, device: None)
+    z = load("step_tiny")
+    cfg, meta = jload(z, "cfg"), jload(z, "meta")
+    nstep = 5
+    runs = {}
+    for mode in ("eager", "graph"):
+        ops.unregister_flat_slabs()
+        ops.manual_seed(dev, 1234)
+        torch.manual_seed(7)
+        enc, dec, T = _make(pkg, cfg, meta, dev, dropout)
+        tr = NARTrainer(enc, dec, T, batch_size=meta["N"], lr=1e-4, max_grad_norm=1.0, lam_pc=0.1)
+        start = {k: v.detach().clone() for k, v in T.state_dict().items()}
+        if mode == "graph":
+            tr.capture(*_batch(meta, cfg, 0, dev), warmup=2)
+            T.load_state_dict(start)                                   # the warm-up and capture passes stepped the model
+            tr.opt.m.zero_(); tr.opt.v.zero_(); tr.opt.step_dev.zero_()
+            if tr.opt.planes is not None:
+                tr.opt.planes.refresh()
+            ops.manual_seed(dev, 1234)
+        recs = []
+        for s in range(nstep):
+            out = tr.step(*_batch(meta, cfg, s, dev))
+            recs.append({k: float(v) for k, v in out.items()})       # a device -> host read per step ...
+        for s in range(nstep, 2 * nstep):                               # ... and a run of replays with no read in between
+            out = tr.step(*_batch(meta, cfg, s, dev))
+        torch.cuda.synchronize()
+        recs.append({k: float(v) for k, v in out.items()})
+        runs[mode] = (recs, {k: v.detach().clone() for k, v in T.state_dict().items()})
+    e, g = runs["eager"], runs["graph"]
+    for re_, rg in zip(e[0], g[0]):
+        for k in re_:
+            assert rg[k] == rg[k] and abs(rg[k]) < 1e6, ("graph replay produced a non-finite / absurd value", k, rg[k])
+            # identical masks; residual differences come from the order of fp32 atomics, amplified over the AdamW steps
+            assert abs(re_[k] - rg[k]) <= (2e-4 if dropout == 0.0 else 2e-3) * abs(re_[k]) + 1e-6, (k, re_[k], rg[k])
+    if True:
+        num = den = 0.0
+        for k, v in e[1].items():
+            if v.is_floating_point() and "running" not in k:
+                num += float((g[1][k].double() - v.double()).pow(2).sum())
+                den += float(v.double().pow(2).sum())
+        assert (num / den) ** 0.5 < 1e-5, (num / den) ** 0.5

@@ -415,6 +415,14 @@ def _auto_flush_wgrads():
 
 
 _pin_pool = {"slots": [], "next": 0}
+_graph_keepalive = []   # pinned upload sources of captured launches (must outlive every replay)
+_graph_reserve = []     # pinned buffers set aside for the next capture
+
+
+def reserve_graph_staging(count=8, nbytes=1 << 18):
+    """set `count` pinned staging buffers aside for the host-built tables of a whole-step graph capture"""
+    while len(_graph_reserve) < count:
+        _graph_reserve.append(torch.empty(nbytes, dtype=torch.uint8).pin_memory())
 
 
 def _to_device_async(host_bytes, dev):
@@ -424,6 +432,19 @@ def _to_device_async(host_bytes, dev):
     n = len(host_bytes)
     if os.environ.get("VPTR_SYNC_UPLOAD") == "1":
         return torch.frombuffer(bytearray(host_bytes), dtype=torch.uint8).to(dev)
+    if torch.cuda.is_current_stream_capturing():
+        # the copy becomes a memcpy node that reads the HOST buffer at every replay: it gets a pinned buffer of its own that is
+        # never reused (the rotating pool below is rewritten by later eager launches -- replays would upload stale descriptors)
+        # (pinned memory cannot be allocated while capturing: reserve_graph_staging() set buffers aside beforehand)
+        for i, cand in enumerate(_graph_reserve):
+            if cand.numel() >= n:
+                buf = _graph_reserve.pop(i)
+                break
+        else:
+            raise RuntimeError("graph capture: no reserved pinned staging buffer of %d bytes (ops.reserve_graph_staging)" % n)
+        buf[:n].copy_(torch.frombuffer(bytearray(host_bytes), dtype=torch.uint8))
+        _graph_keepalive.append(buf)
+        return buf[:n].to(dev, non_blocking=True)
     pool = _pin_pool
     i = pool["next"] % 16
     pool["next"] += 1

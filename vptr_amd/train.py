@@ -331,6 +331,7 @@ class NARTrainer:
         if self.pg is not None and self.world > 1:
             raise RuntimeError("graph capture of the data-parallel step is not enabled (RCCL calls stay eager)")
         self._static_past, self._static_future = past.clone(), future.clone()
+        ops.reserve_graph_staging()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
