@@ -314,8 +314,9 @@ def main():
     ap.add_argument("--precision", type=int, default=int(os.environ.get("VPTR_GEMM_PRECISION", "3")), choices=[1, 3],
                     help="3 = split-bf16 MFMA (meets the 1e-3 parity bar, default); 1 = single-pass bf16")
     ap.add_argument("--dropout", type=float, default=0.1)
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("VPTR_GRAPH", "0")),
-                    help="1: capture the step in a hipGraph (1 GPU). Default 0: the step is GPU-bound, eager == graph speed")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("VPTR_GRAPH", "1")),
+                    help="1 (default): capture the whole step in one hipGraph on a single GPU (same kernels, no host launch cost: "
+                         "57.2 vs 61.3 ms on one box); 0: eager.  Multi-rank runs are always eager (RCCL calls stay outside graphs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the ms/step lines of BASELINE configs 2 / 4 / 5")

@@ -39,6 +39,12 @@ class _Config:
 
 config = _Config()
 
+
+def _direct_apply(fn_cls):
+    """torch.autograd.Function.apply without its Python prologue (functorch dead-wrapper scan, setup_context binding: ~10 us of
+    the ~20 us a call costs on the host; ~290 custom nodes per model forward).  These ops are never used under functorch transforms."""
+    return super(torch.autograd.Function, fn_cls).apply
+
 _seed_state = {}
 _seed_scope = {}
 
@@ -197,9 +203,12 @@ class _AsP16Fn(torch.autograd.Function):
         return dy
 
 
+_AsP16Fn_apply = _direct_apply(_AsP16Fn)
+
+
 def as_p16(x):
     """autograd-aware fp32 -> P16 conversion: the gradient of the P16 tensor (an ordinary fp32 tensor) passes through"""
-    return _AsP16Fn.apply(x)
+    return _AsP16Fn_apply(x)
 
 
 def p16_decode(t):
@@ -704,9 +713,12 @@ class _LinearFn(torch.autograd.Function):
         return (dx, dW, db, dres) + (None,) * 10
 
 
+_LinearFn_apply = _direct_apply(_LinearFn)
+
+
 def linear(x, W, b=None, residual=None, alpha=1.0, act=ACT_NONE, rowscale=None, rs_div=1, rs_mod=1, dropout_p=0.0, site=0,
            x_p16=False, out_p16=False, dy_p16=False):
-    return _LinearFn.apply(x, W, b, residual, rowscale, float(alpha), int(act), int(rs_div), int(rs_mod), float(dropout_p),
+    return _LinearFn_apply(x, W, b, residual, rowscale, float(alpha), int(act), int(rs_div), int(rs_mod), float(dropout_p),
                            int(site), bool(x_p16), bool(out_p16), bool(dy_p16))
 
 
@@ -774,11 +786,14 @@ class _LayerNormFn(torch.autograd.Function):
         return dx, dgamma, dbeta, dtab, None, None, None, None, None
 
 
+_LayerNormFn_apply = _direct_apply(_LayerNormFn)
+
+
 def layernorm(x, gamma, beta, tab=None, tab_div=1, tab_mod=1, eps=1e-5, passthrough=False, out_p16=False):
     """y = LN(x) [, y2 = y + tab[(row // tab_div) % tab_mod]] [, xr]; x [rows, C]; tab [tab_mod, C].
     passthrough=True appends xr (= x, for use as the residual of the sub-layer this LayerNorm feeds; see _LayerNormFn).
     out_p16: y and y2 are written as P16 tensors (they only feed GEMMs; their gradients arrive as ordinary fp32)."""
-    return _LayerNormFn.apply(x, gamma, beta, tab, int(tab_div), int(tab_mod), float(eps), bool(passthrough), bool(out_p16))
+    return _LayerNormFn_apply(x, gamma, beta, tab, int(tab_div), int(tab_mod), float(eps), bool(passthrough), bool(out_p16))
 
 
 class _AddRowTabFn(torch.autograd.Function):
@@ -803,8 +818,11 @@ class _AddRowTabFn(torch.autograd.Function):
         return dy, dtab, None, None
 
 
+_AddRowTabFn_apply = _direct_apply(_AddRowTabFn)
+
+
 def add_rowtab(x, tab, div, mod):
-    return _AddRowTabFn.apply(x, tab, int(div), int(mod))
+    return _AddRowTabFn_apply(x, tab, int(div), int(mod))
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -839,9 +857,12 @@ class _WinAttnFn(torch.autograd.Function):
         return dq, dk, dv, dtable, None, None, None, None, None, None, None, None
 
 
+_WinAttnFn_apply = _direct_apply(_WinAttnFn)
+
+
 def window_attention(q, k, v, table, rel_index, B, H, W, nh, ws, dropout_p=0.0, site=0):
     """q (pre-scaled), k, v: [B*H*W, C]; table [(2ws-1)^2, nh] or None; returns [B*H*W, C] (before out_proj)."""
-    return _WinAttnFn.apply(q, k, v, table, rel_index, int(B), int(H), int(W), int(nh), int(ws), float(dropout_p), int(site))
+    return _WinAttnFn_apply(q, k, v, table, rel_index, int(B), int(H), int(W), int(nh), int(ws), float(dropout_p), int(site))
 
 
 class _TAttnFn(torch.autograd.Function):
@@ -868,9 +889,12 @@ class _TAttnFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, None, None, None, None
 
 
+_TAttnFn_apply = _direct_apply(_TAttnFn)
+
+
 def temporal_attention(q, k, v, Nb, Tq, Tk, HW, nh, causal=False, dropout_p=0.0, site=0):
     """q [(n,tq,p), C] pre-scaled; k, v [(n,tk,p), C]; attends over time for every (n, pixel, head)."""
-    return _TAttnFn.apply(q, k, v, int(Nb), int(Tq), int(Tk), int(HW), int(nh), int(bool(causal)), float(dropout_p), int(site))
+    return _TAttnFn_apply(q, k, v, int(Nb), int(Tq), int(Tk), int(HW), int(nh), int(bool(causal)), float(dropout_p), int(site))
 
 
 class _ProjAttnFn(torch.autograd.Function):
@@ -1004,10 +1028,13 @@ class _ProjAttnFn(torch.autograd.Function):
         return (dxq, dxk, dxv, dWq, dbq, dWk, dbk, dWv, dbv, dtable) + (None,) * 11
 
 
+_ProjAttnFn_apply = _direct_apply(_ProjAttnFn)
+
+
 def _proj_attention(xq, xk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, kind, geom, nh, p, site, merge_v_grad, x_p16=False, o_p16=False):
     same_qk = xk is xq
     same_v = same_qk and xv is xq
-    return _ProjAttnFn.apply(xq, xk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, kind, geom, int(nh), float(p), int(site),
+    return _ProjAttnFn_apply(xq, xk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, kind, geom, int(nh), float(p), int(site),
                              same_qk, same_v, bool(merge_v_grad) and same_qk, bool(x_p16), bool(o_p16))
 
 
@@ -1128,12 +1155,15 @@ class _NormActFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None, dres, None, None
 
 
+_NormActFn_apply = _direct_apply(_NormActFn)
+
+
 def norm_act(x, w, b, mode, HW, training, running_mean=None, running_var=None, act=ACT_GELU, eps=1e-5, dropout_p=0.0, site=0,
              momentum=0.1, rowscale=None, rs_div=1, rs_mod=1, residual=None, out_p16=False, dx_p16=False):
     """y = rowscale * dropout(act(norm(x)*w + b)) + residual  (one elementwise pass; see _NormActFn).
     out_p16: y is written as a P16 tensor (it only feeds a GEMM); dx_p16: the gradient w.r.t. x is returned as a P16 tensor (x is
     the output of a linear(..., dy_p16=True) and nothing else)."""
-    return _NormActFn.apply(x, w, b, running_mean, running_var, mode, int(HW), bool(training), int(act), float(eps),
+    return _NormActFn_apply(x, w, b, running_mean, running_var, mode, int(HW), bool(training), int(act), float(eps),
                             float(dropout_p), int(site), float(momentum), rowscale, int(rs_div), int(rs_mod), residual,
                             bool(out_p16), bool(dx_p16))
 
@@ -1168,11 +1198,14 @@ class _DWConvFn(torch.autograd.Function):
         return dx, dw9, db, None, None, None
 
 
+_DWConvFn_apply = _direct_apply(_DWConvFn)
+
+
 def dwconv3x3(x, weight, bias, frames, H, W):
     """Depthwise 3x3 (pad 1) on channel-last x [frames*H*W, F]; weight is the PyTorch parameter [F,1,3,3]."""
     F = x.shape[1]
     w9 = weight.reshape(F, 9).t().contiguous()  # tap-major [9, F] for coalesced reads
-    return _DWConvFn.apply(x, w9, bias, int(frames), int(H), int(W))
+    return _DWConvFn_apply(x, w9, bias, int(frames), int(H), int(W))
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -1198,15 +1231,18 @@ class _WindowCopyFn(torch.autograd.Function):
         return dx, None, None, None, None, None, None, None
 
 
+_WindowCopyFn_apply = _direct_apply(_WindowCopyFn)
+
+
 def pad_tokens(x, frames, H, W, ws):
     """[frames*H*W, C] -> ([frames*Hp*Wp, C], Hp, Wp): zero centre padding up to multiples of the window size"""
     Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
-    return _WindowCopyFn.apply(x, frames, H, W, Hp, Wp, (Hp - H) // 2, (Wp - W) // 2), Hp, Wp
+    return _WindowCopyFn_apply(x, frames, H, W, Hp, Wp, (Hp - H) // 2, (Wp - W) // 2), Hp, Wp
 
 
 def crop_tokens(x, frames, Hp, Wp, H, W):
     """inverse selection of pad_tokens"""
-    return _WindowCopyFn.apply(x, frames, Hp, Wp, H, W, -((Hp - H) // 2), -((Wp - W) // 2))
+    return _WindowCopyFn_apply(x, frames, Hp, Wp, H, W, -((Hp - H) // 2), -((Wp - W) // 2))
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -1230,6 +1266,9 @@ class _ToTokensFn(torch.autograd.Function):
         dx = torch.empty((B, C, H, W), device=dy.device, dtype=torch.float32)
         check(lib.vptr_tokens_to_nchw(ptr(dy), ptr(dx), B, C, H * W, 0, stream()), "vptr_tokens_to_nchw")
         return dx
+
+
+_ToTokensFn_apply = _direct_apply(_ToTokensFn)
 
 
 class _FromTokensFn(torch.autograd.Function):
@@ -1256,12 +1295,15 @@ class _FromTokensFn(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+_FromTokensFn_apply = _direct_apply(_FromTokensFn)
+
+
 def nchw_to_tokens(x):
-    return _ToTokensFn.apply(x)
+    return _ToTokensFn_apply(x)
 
 
 def tokens_to_nchw(x, B, C, H, W, relu=False):
-    return _FromTokensFn.apply(x, int(B), int(C), int(H), int(W), bool(relu))
+    return _FromTokensFn_apply(x, int(B), int(C), int(H), int(W), bool(relu))
 
 
 # ------------------------------------------------------------------------------------------------------------------
