@@ -140,6 +140,13 @@ def test_library_exports_every_declared_symbol():
     assert ctypes.sizeof(_lib.GemmDesc) % 8 == 0
 
 
+def test_graft_entry_build_runs():
+    """the driver's build check (`__graft_entry__.build()`): compiles what changed, imports the package, checks the ABI version"""
+    import importlib
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
+
+
 def test_product_path_has_no_cpu_fallback():
     import vptr_amd.ops as ops
     x = torch.randn(8, 16)
