@@ -102,21 +102,22 @@ __device__ __forceinline__ bf16x8 am_tile_frag(const unsigned char* tile, const 
 // stage rows of `src` (keys of problem g, head h) as the transposable image; `nthr` threads of the slot cooperate (tid 0 .. nthr-1).
 // Rows >= Lk and channels >= hd are zero-filled without loads (P is zero there, but 0 x stale-NaN would poison the product).
 __device__ __forceinline__ void am_stage_img(unsigned char* img, const float* __restrict__ src, const AmGeom& gm, const int g, const int h, const int LKP,
-                                             const int NDF, const int tid, const int nthr) {
+                                             const int NDF, const int tid, const int nthr, const bool query_rows = false) {
   const int NP = NDF * 8;   // channel pairs per row including the zero padding up to 16 NDF
-  for (int idx = tid; idx < gm.Lk * NP; idx += nthr) {
+  const int L = query_rows ? gm.Lq : gm.Lk;
+  for (int idx = tid; idx < L * NP; idx += nthr) {
     const int j = idx / NP, dp = idx - j * NP, d = 2 * dp;
     const bool ok = d < gm.hd;
-    const float2 v = *reinterpret_cast<const float2*>(src + am_krow(gm, g, j) * gm.C + h * gm.hd + min(d, gm.hd - 2));
+    const float2 v = *reinterpret_cast<const float2*>(src + (query_rows ? am_qrow(gm, g, j) : am_krow(gm, g, j)) * gm.C + h * gm.hd + min(d, gm.hd - 2));
     uint32_t hi, lo;
     vptr_split2(ok ? v.x : 0.f, ok ? v.y : 0.f, hi, lo);
     *reinterpret_cast<uint32_t*>(img + am_img_off(LKP, d >> 4, 0, j, d & 15)) = hi;
     *reinterpret_cast<uint32_t*>(img + am_img_off(LKP, d >> 4, 1, j, d & 15)) = lo;
   }
-  const int ppb = (LKP - gm.Lk) * 2;   // 16-byte pieces of the pad rows of one (df, plane) block (32 B per row)
+  const int ppb = (LKP - L) * 2;   // 16-byte pieces of the pad rows of one (df, plane) block (32 B per row)
   for (int idx = tid; idx < 2 * NDF * ppb; idx += nthr) {
     const int blk = idx / ppb, rem = idx - blk * ppb;
-    *reinterpret_cast<uint4*>(img + (blk * LKP + gm.Lk) * 32 + rem * 16) = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(img + (blk * LKP + L) * 32 + rem * 16) = make_uint4(0u, 0u, 0u, 0u);
   }
 }
 
@@ -493,6 +494,208 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// backward for problems with more than 16 query rows (64-token windows, T = 29 ... 50): the waves of a problem first act as
+// QUERY-block owners (P, dP, dS of 16 query rows; dQ block), leave dS and the dropped P as bf16 hi / lo tiles in LDS, and then as
+// KEY-block owners: dV[16 keys] = P_drop^T . dO and dK[16 keys] = dS^T . Q over ALL query rows -- A = a transposing read down the
+// tiles of every query block, B = the transposable image of dO / Q, full-depth v_mfma_f32_16x16x32_bf16, results stored once.
+// No scalar operand loads, no LDS atomics, no accumulator round trip (the single-block kernel above keeps those for 16-row
+// problems, where one wave owns everything).  One image region is reused for K (dQ), dO (dV) and Q (dK).
+// LDS: [slots][image: 2 NDF planes x max(LKP, LQ32) x 32 B | bias-table gradient]  then  [4 waves][dS hi, dS lo, Pd hi, Pd lo tiles]
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 am_tileT_frag(const unsigned char* tiles, const int tile_stride, const int plane_off, const int pitch, const int jb,
+                                                const int kq, const int NQB, const int lr, const int lq) {
+  const int rowoff = plane_off + (4 * lq + (lr >> 2)) * pitch + (jb * 16 + (lr & 3) * 4) * 2;
+  am_s16x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+  if (2 * kq < NQB) a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) am_s16x4*)(tiles + (2 * kq) * tile_stride + rowoff));
+  if (2 * kq + 1 < NQB) b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) am_s16x4*)(tiles + (2 * kq + 1) * tile_stride + rowoff));
+  const am_s16x8 c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, c);
+}
+
+template <int NKS, int NDF>
+__global__ __launch_bounds__(256) void attn_mfma_bwd_shared_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                                   const float* __restrict__ table, const int64_t* __restrict__ rel_index,
+                                                                   const float* __restrict__ dout, float* __restrict__ dq, float* __restrict__ dk,
+                                                                   float* __restrict__ dv, float* __restrict__ dtable, const AmGeom gm, const int nqbr,
+                                                                   const int causal, const float p, const uint64_t* seed_dev, const uint32_t site,
+                                                                   const float dq_scale, const int p16, const int ntab) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char am_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int NQB = (gm.Lq + 15) >> 4, njf = (gm.Lk + 15) >> 4, nkj = (gm.Lk + 31) >> 5, LKP = nkj * 32;
+  const int nkq = (gm.Lq + 31) >> 5, LQ32 = nkq * 32, IMR = LKP > LQ32 ? LKP : LQ32;
+  const int slots = 4 / nqbr, slot = wave / nqbr, qb = wave - slot * nqbr;
+  const int prob = blockIdx.x * slots + slot;
+  const bool pvalid = prob < gm.groups * gm.nh;
+  const int g = pvalid ? prob / gm.nh : 0, h = pvalid ? prob - g * gm.nh : 0;
+  const bool active = pvalid && qb < NQB;
+  const int img_bytes = 2 * NDF * IMR * 32, tab_bytes = dtable ? ((ntab * 4 + 15) & ~15) : 0;
+  const int slot_bytes = img_bytes + tab_bytes, pitch = LKP * 2 + 16, tile_stride = 4 * 16 * pitch;
+  unsigned char* img = am_smem + slot * slot_bytes;
+  float* stab = reinterpret_cast<float*>(img + img_bytes);
+  unsigned char* tiles = am_smem + slots * slot_bytes + slot * nqbr * tile_stride;   // tiles of this problem's query blocks
+  unsigned char* mytile = tiles + qb * tile_stride;                                  // [dS hi][dS lo][Pd hi][Pd lo]
+  const int stid = tid - slot * nqbr * 64, snthr = nqbr * 64;
+
+  if (pvalid) am_stage_img(img, k, gm, g, h, IMR, NDF, stid, snthr);   // the image region has IMR rows in every phase
+  for (int e = stid; e < tab_bytes / 4; e += snthr) stab[e] = 0.f;
+  float ds[4][4];
+#pragma unroll
+  for (int jf = 0; jf < 4; ++jf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ds[jf][r] = 0.f;
+  if (active) {
+    float pr[4][4];
+    am_scores<NKS>(gm, q, k, table, rel_index, g, h, qb, njf, causal, lr, lq, pr);
+    bf16x8 gh[NKS], gl[NKS];
+    {
+      const int i = qb * 16 + lr;
+      const float* row = dout + am_qrow(gm, g, min(i, gm.Lq - 1)) * gm.C + h * gm.hd;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) am_load_frag(row, 32 * ks + 8 * lq, gm.hd, i < gm.Lq, gh[ks], gl[ks]);
+    }
+    uint64_t seed = 0;
+    if (p > 0.f) seed = *seed_dev;
+    float delta[4] = {0.f, 0.f, 0.f, 0.f}, pd[4][4];
+#pragma unroll
+    for (int jf = 0; jf < 4; ++jf) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pd[jf][r] = 0.f;
+      if (jf < njf) {
+        const int j = jf * 16 + lr;
+        const float* row = v + am_krow(gm, g, min(j, gm.Lk - 1)) * gm.C + h * gm.hd;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          bf16x8 vh, vl;
+          am_load_frag(row, 32 * ks + 8 * lq, gm.hd, j < gm.Lk, vh, vl);
+          acc = am_mfma3(gh[ks], gl[ks], vh, vl, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = qb * 16 + 4 * lq + r;
+          float sc = 1.f;
+          if (p > 0.f && i < gm.Lq && j < gm.Lk) sc = vptr_drop_scale(seed, site, ((uint64_t)prob * gm.Lq + i) * gm.Lk + j, p);
+          pd[jf][r] = i < gm.Lq ? pr[jf][r] * sc : 0.f;
+          ds[jf][r] = acc[r] * sc;
+          delta[r] += pr[jf][r] * ds[jf][r];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) delta[r] = am_row16_sum(delta[r]);
+#pragma unroll
+    for (int jf = 0; jf < 4; ++jf) {
+      const int j = jf * 16 + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ds[jf][r] = pr[jf][r] * (ds[jf][r] - delta[r]);
+        if (jf * 16 < LKP) {
+          const int il = 4 * lq + r;
+          uint32_t hi, lo;
+          vptr_split2(ds[jf][r], pd[jf][r], hi, lo);   // low halves: dS, high halves: dropped P
+          *reinterpret_cast<uint16_t*>(mytile + il * pitch + j * 2) = (uint16_t)hi;
+          *reinterpret_cast<uint16_t*>(mytile + 16 * pitch + il * pitch + j * 2) = (uint16_t)lo;
+          *reinterpret_cast<uint16_t*>(mytile + 32 * pitch + il * pitch + j * 2) = (uint16_t)(hi >> 16);
+          *reinterpret_cast<uint16_t*>(mytile + 48 * pitch + il * pitch + j * 2) = (uint16_t)(lo >> 16);
+        }
+      }
+    }
+  }
+  __syncthreads();   // K image, zeroed table gradient, tiles of every query block
+  if (active && dtable) {
+#pragma unroll
+    for (int jf = 0; jf < 4; ++jf) {
+      const int j = jf * 16 + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = qb * 16 + 4 * lq + r;
+        if (jf < njf && j < gm.Lk && i < gm.Lq) atomicAdd(&stab[rel_index[i * gm.Lk + j]], ds[jf][r]);
+      }
+    }
+  }
+  if (active) {   // dQ block = dS . K
+    f32x4 qacc[NDF];
+#pragma unroll
+    for (int df = 0; df < NDF; ++df) qacc[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kj = 0; kj < 2; ++kj) {
+      if (kj < nkj) {
+        const bf16x8 sh = am_tile_frag(mytile, pitch, kj, lr, lq), sl = am_tile_frag(mytile + 16 * pitch, pitch, kj, lr, lq);
+#pragma unroll
+        for (int df = 0; df < NDF; ++df) {
+          const bf16x8 kh = am_tr_frag(img, IMR, df, 0, kj, lr, lq), kl = am_tr_frag(img, IMR, df, 1, kj, lr, lq);
+          qacc[df] = am_mfma3(sh, sl, kh, kl, qacc[df]);
+        }
+      }
+    }
+#pragma unroll
+    for (int df = 0; df < NDF; ++df) {
+      const int d = df * 16 + lr;
+      if (d < gm.hd) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = qb * 16 + 4 * lq + r;
+          if (i < gm.Lq) {
+            const int64_t e = am_qrow(gm, g, i) * gm.C + h * gm.hd + d;
+            if (p16) vptr_p16_store1(reinterpret_cast<unsigned char*>(dq), e, qacc[df][r] * dq_scale);
+            else dq[e] = qacc[df][r] * dq_scale;
+          }
+        }
+      }
+    }
+  }
+  // key-block ownership: dV (A = dropped P tiles, B = dO image) then dK (A = dS tiles, B = Q image)
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();   // everyone is done with the previous image
+    if (pvalid) am_stage_img(img, pass == 0 ? dout : q, gm, g, h, IMR, NDF, stid, snthr, true);
+    __syncthreads();
+    float* dst = pass == 0 ? dv : dk;
+    const int plane_off = pass == 0 ? 32 * pitch : 0;
+    if (pvalid) {
+      for (int jb = qb; jb < njf; jb += nqbr) {   // wave-uniform
+        f32x4 acc[NDF];
+#pragma unroll
+        for (int df = 0; df < NDF; ++df) acc[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+          if (kq < nkq) {
+            const bf16x8 ah = am_tileT_frag(tiles, tile_stride, plane_off, pitch, jb, kq, NQB, lr, lq);
+            const bf16x8 al = am_tileT_frag(tiles, tile_stride, plane_off + 16 * pitch, pitch, jb, kq, NQB, lr, lq);
+#pragma unroll
+            for (int df = 0; df < NDF; ++df) {
+              const bf16x8 bh = am_tr_frag(img, IMR, df, 0, kq, lr, lq), bl = am_tr_frag(img, IMR, df, 1, kq, lr, lq);
+              acc[df] = am_mfma3(ah, al, bh, bl, acc[df]);
+            }
+          }
+        }
+#pragma unroll
+        for (int df = 0; df < NDF; ++df) {
+          const int d = df * 16 + lr;
+          if (d < gm.hd) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int j = jb * 16 + 4 * lq + r;
+              if (j < gm.Lk) {
+                const int64_t e = am_krow(gm, g, j) * gm.C + h * gm.hd + d;
+                if (p16) vptr_p16_store1(reinterpret_cast<unsigned char*>(dst), e, acc[df][r]);
+                else dst[e] = acc[df][r];
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (dtable && pvalid) {   // the table atomics precede two barriers
+    for (int t = stid; t < ntab; t += snthr) {
+      const float val = stab[t];
+      if (val != 0.f) unsafeAtomicAdd(dtable + (int64_t)t * gm.nh + h, val);
+    }
+  }
+}
+
 static int am_enabled() {   // read per call: tests switch the mode inside one process
   const char* e = getenv("VPTR_ATTN_MFMA");
   return e ? atoi(e) : 1;
@@ -541,6 +744,16 @@ static int am_launch_bwd(const float* q, const float* k, const float* v, const f
   const size_t slot_bytes = (size_t)2 * NDF * LKP * 32 + (nqbr > 1 ? (size_t)LKP * NDF * 64 : 0) + (dtable ? ((ntab * 4 + 15) & ~15) : 0);
   const size_t lds = slots * slot_bytes + 4 * 2 * 16 * pitch;
   const int nprob = gm.groups * gm.nh;
+  if (nqbr > 1) {   // several query blocks per problem: the tile-sharing kernel
+    const int LQ32 = (gm.Lq + 31) / 32 * 32, IMR = LKP > LQ32 ? LKP : LQ32;
+    const size_t sb = (size_t)2 * NDF * IMR * 32 + (dtable ? ((ntab * 4 + 15) & ~15) : 0);
+    const size_t lds2 = slots * sb + 4 * 4 * 16 * pitch;
+    auto kern2 = attn_mfma_bwd_shared_kernel<NKS, NDF>;
+    if (lds2 > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    kern2<<<(nprob + slots - 1) / slots, 256, lds2, st>>>(q, k, v, table, rel_index, dout, dq, dk, dv, dtable, gm, nqbr, causal, p, seed_dev, site, dq_scale, p16,
+                                                          ntab);
+    return 0;
+  }
   auto kern = attn_mfma_bwd_kernel<NKS, NDF>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   kern<<<(nprob + slots - 1) / slots, 256, lds, st>>>(q, k, v, table, rel_index, dout, dq, dk, dv, dtable, gm, nqbr, causal, p, seed_dev, site, dq_scale, p16, ntab);
