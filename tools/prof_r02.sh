@@ -5,8 +5,8 @@
 # Writes gpurun_out/r02/*; copy the summaries into profiles/.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r02; rm -rf $OUT; mkdir -p $OUT
-BENCH="python bench.py --no-cpu-baseline --no-other-configs"
-SHORT="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs"
+BENCH="python bench.py --graph 0 --no-cpu-baseline --no-other-configs"   # eager launches: one traced kernel per launch
+SHORT="python bench.py --graph 0 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o b --output-format csv -- $BENCH > $OUT/bench_stdout.log 2>&1
 tail -1 $OUT/bench_stdout.log > $OUT/bench_line.json
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc -o f --output-format csv -- $SHORT > /dev/null 2>&1
@@ -24,7 +24,7 @@ steps = 26.0   # 5 warm-up + 20 timed + 1 instrumented
 tot = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6 / steps
 gemm = sum(float(r["TotalDurationNs"]) for r in rows if "gemm" in r["Name"] or "conv_planes" in r["Name"] or "wgrad" in r["Name"]) / 1e6 / steps
 with open(OUT + "/r02_bench_kernel_stats.md", "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-other-configs   (eager, N=16, bf16x3, dropout 0.1;\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --graph 0 --no-cpu-baseline --no-other-configs   (eager, N=16, bf16x3, dropout 0.1;\n")
     f.write("# 5 warm-up + 20 timed + 1 instrumented step = 26 steps; per-step figures = totals / 26)\n")
     f.write("# kernel time %.1f ms/step: MFMA GEMM kernels %.1f, everything else %.1f\n\n" % (tot, gemm, tot - gemm))
     f.write("| kernel | calls/step | ms/step | avg us | % |\n|---|---|---|---|---|\n")
@@ -44,7 +44,7 @@ for tag, cname in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
 out = {k: v for k, v in sorted(res.items(), key=lambda kv: -(kv[1].get("FETCH_SIZE", 0) * kv[1].get("launches", 0)))
        if "gemm" in k or "wgrad" in k or "conv_planes" in k or v.get("FETCH_SIZE", 0) * v.get("launches", 0) > 1e5}
 json.dump({"unit": "KB per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE, separate passes); HBM-side bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
-           "command": "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs", "kernels": out},
+           "command": "python bench.py --graph 0 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs", "kernels": out},
           open(OUT + "/r02_pmc_traffic.json", "w"), indent=1)
 for k, v in list(out.items())[:12]:
     print("%-46s launches %5d  FETCH_SIZE %12.1f KB  WRITE_SIZE %12.1f KB per launch" % (k[:46], v.get("launches", 0), v.get("FETCH_SIZE", 0), v.get("WRITE_SIZE", 0)))
