@@ -6,9 +6,11 @@ indices hold the same parameterised leaves (nn.Conv2d / nn.BatchNorm2d / nn.Conv
 parameter containers.  The forward pass runs NHWC implicit-GEMM convolutions on the matrix cores with BatchNorm
 folded into the GEMM epilogue (eval mode), ReLU / residual fused, and direct 7x7 kernels at the image ends.
 
-Scope of the HIP path: eval-mode BatchNorm (stage-2 training and inference, train_NAR.py:190-191): encoder forward,
-decoder forward and decoder backward w.r.t. its input (and optionally its weights).  Train-mode BatchNorm of the
-stage-1 script is a 'next' row and raises NotImplementedError.
+Two modes on the HIP path.  Eval-mode BatchNorm (stage-2 training and inference, train_NAR.py:190-191): BatchNorm folded into
+the GEMM epilogues; encoder forward (the frozen encoder's ResnetBlock convolutions on plane operands), decoder forward and
+decoder backward w.r.t. its input and -- as the reference computes them -- its weights.  Train-mode BatchNorm (stage 1,
+train_AutoEncoder.py:44-86): raw convolution -> batch statistics -> normalise + ReLU with full autograd through encoder and
+decoder (`ops.conv2d_nhwc`, `ops.norm_act`), used by `vptr_amd.train.AETrainer`.
 """
 import functools
 
