@@ -49,6 +49,17 @@ def _worker(rank, world, port, q):
     model.zero_grad()
     ((model(xs) - ys) ** 2).mean().backward()
     full = torch.cat([p.grad.reshape(-1) for p in params])
+    # DDP's per-forward buffer broadcast as one flat collective: rank 0's BatchNorm statistics replace everybody's
+    from vptr_amd.parallel import BufferSync
+    bn = model[1]
+    with torch.no_grad():
+        bn.running_mean.fill_(float(rank + 1))
+        bn.running_var.fill_(float(10 * (rank + 1)))
+        bn.num_batches_tracked.fill_(7 + rank)
+    bs = BufferSync(model, 0, None)
+    assert bool(bs)
+    bs.sync()
+    assert float(bn.running_mean[0]) == 1.0 and float(bn.running_var[-1]) == 10.0 and int(bn.num_batches_tracked) == 7
     q.put((rank, sd, float((flat - expect).abs().max()), float((flat - full).abs().max())))
     dist.barrier()
     dist.destroy_process_group()

@@ -24,8 +24,9 @@ def hooked(dref, st):
     e0.record()
     rc = real(dref, st)
     e1.record()
-    recs.append(((d.M, d.N, d.K * max(d.ksegs, 1), d.a_mode, d.b_mode, max(d.batch, 1), d.conv_KH if d.a_mode == 2 else 0, d.conv_stride if d.a_mode == 2 else 0,
-                  d.conv_transposed if d.a_mode == 2 else 0), e0, e1))
+    epi = ("g" if d.act == 1 else "") + ("P" if d.Dpre else "") + ("d" if d.dropout_p > 0 else "") + ("r" if d.residual else "") + ("s" if d.rowscale else "") + ("o" if d.d_p16 else "")
+    recs.append(((d.M, d.N, d.K * max(d.ksegs, 1), d.a_mode, d.b_mode, max(d.batch, 1), d.conv_KH if d.a_mode in (2, 3) else 0, d.conv_stride if d.a_mode in (2, 3) else 0,
+                  d.conv_transposed if d.a_mode == 2 else 0, epi), e0, e1))
     return rc
 lib.vptr_gemm = hooked
 trainer.step(past, fut)
@@ -37,8 +38,8 @@ for k, e0, e1 in recs:
     d[0] += 1
     d[1] += e0.elapsed_time(e1)
 tot = sum(v[1] for v in by.values())
-print("%-52s %5s %9s %8s %8s" % ("M N K am bm batch kh stride transposed", "n", "ms", "us/call", "TF/s"))
+print("%-60s %5s %9s %8s %8s" % ("M N K am bm batch kh stride transposed epilogue(g=GELU P=Dpre d=dropout r=residual s=rowscale o=P16 out)", "n", "ms", "us/call", "TF/s"))
 for k, (n, ms) in sorted(by.items(), key=lambda kv: -kv[1][1]):
     M, N, K = k[:3]
-    print("%-52s %5d %9.3f %8.1f %8.1f" % (" ".join(str(x) for x in k), n, ms, ms * 1e3 / n, 2.0 * M * N * K * k[5] * n / ms / 1e9))
+    print("%-60s %5d %9.3f %8.1f %8.1f" % (" ".join(str(x) for x in k), n, ms, ms * 1e3 / n, 2.0 * M * N * K * k[5] * n / ms / 1e9))
 print("total non-grouped GEMM ms: %.3f" % tot)
