@@ -255,6 +255,10 @@ class WeightPlanes:
         check(lib.vptr_weight_planes(ptr(self.table), ptr(self.starts), len(self.weights), self.tiles, stream()), "vptr_weight_planes")
         self.versions = [t[5]._version for t in self.index]
 
+    def stale(self):
+        """True when a registered weight changed through torch (load_state_dict, an external optimizer) since the last refresh"""
+        return any(v != t[5]._version for v, t in zip(self.versions, self.index))
+
     def lookup(self, W):
         """(Wp, ld, WT, ld) for W = a registered weight or a whole-row slice of one, or None; stale planes (the weight changed
         through torch since the last refresh) are rebuilt first"""

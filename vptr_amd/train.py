@@ -11,7 +11,7 @@ MI355X-first differences in *how* (not *what*):
   * losses are returned as device tensors (the reference's 8 `.item()` syncs per step are left to the caller);
   * the weight (and bias) gradients of every nn.Linear of a backward pass run as ONE grouped MFMA launch at its end
     (ops.defer_wgrad / vptr_gemm_grouped);
-  * `capture()` (whole step as one hipGraph) is experimental and not used by bench.py.
+  * `capture()` turns the whole step into one hipGraph (single GPU; bench.py's default launch mode).
 
 `FARTrainer` is the same for `single_iter` of train_FAR.py:48-101, `AETrainer` for the stage-1 auto-encoder + PatchGAN step of
 train_AutoEncoder.py:44-78; both NAR and FAR trainers take the optional adversarial branch (`disc=`, `lam_gan=`).
@@ -314,11 +314,10 @@ class NARTrainer:
 
     def step(self, past, future):
         if self._graph is not None:
-            # EXPERIMENTAL (round 1): with dropout > 0, replays that are not followed by a device->host read showed a
-            # corrupted GDL term / gradient norm on ROCm 7.2 (tools/loss_trace*.py); replays whose losses are
-            # read back every step, and dropout = 0, are correct.  Unresolved -> bench.py runs the eager step (same speed:
-            # the step is GPU-bound).  The sync below keeps replays from overlapping.
-            torch.cuda.current_stream().synchronize()
+            # replays are stream-ordered like any other launch; tests/test_graph_gpu.py compares them with eager steps (the
+            # round-1 corruption was a captured table upload reading a recycled pinned buffer: ops._to_device_async)
+            if self.opt.planes is not None and self.opt.planes.stale():
+                self.opt.planes.refresh()   # parameters were changed from outside (load_state_dict) since the last replay
             self._static_past.copy_(past)
             self._static_future.copy_(future)
             self._graph.replay()
