@@ -410,6 +410,8 @@ def main():
             try:
                 trainer._graph = None  # instrumented eager pass
                 trainer.world = 1      # rank 0 alone runs it: no collective may be issued (the other ranks are at the final barrier)
+                trainer.pg = None
+                trainer._bufsync = None   # ... including the per-forward BatchNorm-buffer broadcast
                 res["roofline"] = gemm_roofline(trainer, past, fut, args.precision)
             except Exception as e:  # noqa
                 res["roofline"] = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,

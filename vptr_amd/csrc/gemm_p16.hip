@@ -226,7 +226,8 @@ __device__ __forceinline__ bf16x8 p16_tr_frag(const unsigned char* st, const int
   return __builtin_bit_cast(bf16x8, c);
 }
 
-__global__ __launch_bounds__(GNT, 4) void vptr_wgrad_p16_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
+template <int NSTAGE>   // 2: two workgroups per CU; 3: one workgroup per CU with the DMA two K-steps ahead (experiment, VPTR_WGRAD_STAGES=3)
+__global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
                                                                 const int count) {
   constexpr int BN = 176;
   extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
@@ -306,11 +307,17 @@ __global__ __launch_bounds__(GNT, 4) void vptr_wgrad_p16_kernel(const vptr_gemm_
   const bool ttail = (T & 31) != 0;
 
   issue(0, 0);
+  if (NSTAGE == 3 && nk > 1) issue(1, 1);
   for (int kt = 0; kt < nk; ++kt) {
-    __builtin_amdgcn_s_waitcnt(0x0f70);
+    if (NSTAGE == 3 && kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | 5);   // vmcnt(5): step kt landed, step kt + 1 may still fly
+    else __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
-    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-    const unsigned char* st = p16_smem + (kt & 1) * P16_STAGE;
+    if (NSTAGE == 3) {
+      if (kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
+    } else if (kt + 1 < nk) {
+      issue(kt + 1, (kt + 1) & 1);
+    }
+    const unsigned char* st = p16_smem + (NSTAGE == 3 ? kt % 3 : (kt & 1)) * P16_STAGE;
     bf16x8 ah[2], al[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -438,20 +445,18 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
 int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* descs_dev, const int* tile_start_dev, int count, int total_tiles,
                           hipStream_t st) {
   VPTR_CHECK(proto->b_mode == VPTR_B_P16T && proto->precision == 3, "vptr_gemm_grouped(p16): both operands token-major P16, precision 3");
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess) {
-      vptr_set_error("vptr_gemm_grouped(p16): cannot reserve %d bytes of LDS", 2 * P16_STAGE);
+  static int stages = -1;
+  if (stages < 0) {
+    const char* e = getenv("VPTR_WGRAD_STAGES");
+    stages = (e && atoi(e) == 3) ? 3 : 2;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess) {
+      vptr_set_error("vptr_gemm_grouped(p16): cannot reserve LDS");
+      stages = -1;
       return -1;
     }
-    attr_set = true;
   }
-  static int pad = -1;   // VPTR_WGRAD_LDS_PAD (bytes): experiments on the number of co-resident workgroups (> 0 forces one per CU)
-  if (pad < 0) {
-    const char* e = getenv("VPTR_WGRAD_LDS_PAD");
-    pad = e ? atoi(e) : 0;
-    if (pad > 0) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE + pad);
-  }
-  vptr_wgrad_p16_kernel<<<total_tiles, GNT, 2 * P16_STAGE + pad, st>>>(descs_dev, tile_start_dev, count);
+  if (stages == 3) vptr_wgrad_p16_kernel<3><<<total_tiles, GNT, 3 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count);
+  else vptr_wgrad_p16_kernel<2><<<total_tiles, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count);
   return 0;
 }
