@@ -68,16 +68,16 @@ __global__ void tr_test(const int* __restrict__ addr_el, short* __restrict__ out
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-template <int NW, int PROB>  // NW waves: 8 -> 4x2 waves of 32x96, 4 -> 2x2 waves of 64x96
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 4) void gemm_nt(const unsigned char* __restrict__ A, const unsigned char* __restrict__ B,
+template <int NW, int PROB, int NST = 2>  // NW waves: 8 -> 4x2 waves of 32x96, 4 -> 2x2 waves of 64x96; NST stages (3: DMA two K-steps ahead, one workgroup per CU)
+__global__ __launch_bounds__(NW * 64, NST == 3 ? 2 : (NW == 4 ? 2 : 4)) void gemm_nt(const unsigned char* __restrict__ A, const unsigned char* __restrict__ B,
                                                                      float* __restrict__ D, int M, int N, int K, int64_t strideA, int64_t strideB,
-                                                                     int64_t strideD) {
+                                                                     int64_t strideD, int elim) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   constexpr int MI = 128 / (NW / 2) / 16, PPW = 40 / NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // PROB = wave map variant: 0: wm = wave >> 1, wn = wave & 1;  1, 2: wm = wave & (NW/2 - 1), wn = wave / (NW/2) (waves w and w + 4 share
   // a SIMD, so every SIMD then hosts one wave of each column half); 2: the 12th (padding) fragment of the odd half is skipped
-  const int wm = PROB ? (wave & (NW / 2 - 1)) : (wave >> 1), wn = PROB ? (wave / (NW / 2)) : (wave & 1), lr = lane & 15, lq = lane >> 4;
+  const int wm = PROB ? (wave & (NW / 2 - 1)) : (wave >> 1), wn = PROB ? (wave / (NW / 2)) : (wave & 1), lr = lane & 15, lq = lane >> 4;   // PROB 3 = 2 + B fragment prefetch
   const int tiles_n = (N + BN - 1) / BN, tiles = tiles_n * ((M + BM - 1) / BM);
   const int lg = xcd_logical();
   const int prob = lg / tiles, tile = lg - prob * tiles;
@@ -99,14 +99,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 4) void gemm_nt(const unsign
     src[i] = (isA ? A : B) + grow * pitch + c * 16;
     tail_adj[i] = c >= 4 ? -64 : 0;
   }
-  auto issue = [&](const int kt, const int stage) {
+  auto issue1 = [&](const int kt, const int stage, const int i) {
     const bool last = ktail && kt == nk - 1;
+    // elim 2 / 3: only the A / B pieces after step 1; elim 4: every piece re-reads K-step 0 (cache-resident source)
+    if (kt > 1 && ((elim == 2 && wave + NW * i >= 16) || (elim == 3 && wave + NW * i < 16))) return;
+    const unsigned char* g = src[i] + (int64_t)(elim == 4 ? 0 : kt) * 128 + (last ? tail_adj[i] : 0);
+    const uint32_t laddr = (uint32_t)(stage * STAGE_B + (wave + NW * i) * 1024);
+    GLDS(laddr, g);
+  };
+  auto issue = [&](const int kt, const int stage) {
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const unsigned char* g = src[i] + (int64_t)kt * 128 + (last ? tail_adj[i] : 0);
-      const uint32_t laddr = (uint32_t)(stage * STAGE_B + (wave + NW * i) * 1024);
-      GLDS(laddr, g);
-    }
+    for (int i = 0; i < PPW; ++i) issue1(kt, stage, i);
   };
   f32x4 acc[MI][6];
 #pragma unroll
@@ -128,11 +131,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 4) void gemm_nt(const unsign
     offBl[ni] = 16384 + r * 128 + (((ch + 2) ^ f) << 4);
   }
   issue(0, 0);
+  if (NST == 3 && nk > 1) issue(1, 1);
   for (int kt = 0; kt < nk; ++kt) {
-    __builtin_amdgcn_s_waitcnt(0x0f70);
+    if (NST == 3 && kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | PPW);   // vmcnt(PPW): step kt landed, step kt + 1 may still fly
+    else __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
-    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-    const unsigned char* st = smem + (kt & 1) * STAGE_B;
+    if (NST == 3) {
+      if (PROB != 4 && kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
+    } else if (PROB != 4 && kt + 1 < nk && !(elim == 1 && kt > 0)) issue(kt + 1, (kt + 1) & 1);   // elim 1: no DMA after the second step
+    const unsigned char* st = smem + (NST == 3 ? kt % 3 : (kt & 1)) * STAGE_B;
     bf16x8 ah[MI], al[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -146,6 +153,28 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 4) void gemm_nt(const unsign
         al[mi] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
       }
     }
+    if (PROB == 3 || PROB == 4) {   // map 2 + the next B fragment pair requested before the MFMAs of the current one; 4: DMA pieces between the MFMA groups
+      bf16x8 bh[2], bl[2];
+      bh[0] = *reinterpret_cast<const bf16x8*>(st + offBh[0]);
+      bl[0] = *reinterpret_cast<const bf16x8*>(st + offBl[0]);
+#pragma unroll
+      for (int ni = 0; ni < 6; ++ni) {
+        if (ni == 5 && wn == 1) break;
+        if (ni + 1 < 6 && !(ni + 1 == 5 && wn == 1)) {
+          bh[(ni + 1) & 1] = *reinterpret_cast<const bf16x8*>(st + offBh[ni + 1]);
+          bl[(ni + 1) & 1] = *reinterpret_cast<const bf16x8*>(st + offBl[ni + 1]);
+        }
+        if (PROB == 4 && NW == 8 && ni < PPW && kt + NST - 1 < nk) issue1(kt + NST - 1, NST == 3 ? (kt + 2) % 3 : (kt + 1) & 1, ni);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl[ni & 1], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int ni = 0; ni < 6; ++ni) {
       if (PROB == 2 && ni == 5 && wn == 1) break;   // wave-uniform
@@ -157,6 +186,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 4) void gemm_nt(const unsign
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
       }
+    }
     }
   }
 #pragma unroll
@@ -177,7 +207,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 4) void gemm_nt(const unsign
 // nt64: 64 x 176 tiles, 4 waves (2 x 2 of 32 x 96), 32 KB stages: twice the tiles of the 128-row kernel for the N = 528 outputs
 // (240 tiles on 256 CUs = one lone workgroup per CU) so that two workgroups share a CU and cover each other's barrier phases
 __global__ __launch_bounds__(256, 2) void gemm_nt64(const unsigned char* __restrict__ A, const unsigned char* __restrict__ B, float* __restrict__ D, int M, int N,
-                                                    int K, int64_t strideA, int64_t strideB, int64_t strideD) {
+                                                    int K, int64_t strideA, int64_t strideB, int64_t strideD, int elim) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   constexpr int ST = 32 * 1024;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -279,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt64(const unsigned char* __restr
 // Stage = 40 pieces of [8 t][128 B]; a piece holds, for one pair of granules, 4 mini-subtiles [8 t][16 ch] (g0 hi, g0 lo, g1 hi,
 // g1 lo) of 256 bytes each: lane L of the DMA fetches chunk (L >> 4) * 2 + (L & 1) of row (L & 15) >> 1 -- whole 128-byte lines
 // per row on the global side, 32-byte channel rows on the LDS side, which is what ds_read_b64_tr_b16 wants.
-template <int NW>
+template <int NW, int LAY>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 4) void gemm_tn(const unsigned char* __restrict__ G, const unsigned char* __restrict__ X,
                                                                      float* __restrict__ D, int T, int NG, int KX, int64_t strideG, int64_t strideX,
                                                                      int64_t strideD, int elim) {
@@ -303,7 +333,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 4) void gemm_tn(const unsign
     const bool isA = u < 16;
     const int v = isA ? u : u - 16;
     const int gp = v >> 2, tp = v & 3;
-    const int ms = lane >> 4, t = (lane & 15) >> 1, half = lane & 1;
+    // LAY 1: 8 consecutive lanes fetch one token row's 128 bytes (2 granules x 2 planes), quarters XOR-swizzled by (row >> 1) & 3
+    const int ms = LAY ? (((lane & 7) >> 1) ^ ((lane >> 4) & 3)) : lane >> 4, t = LAY ? lane >> 3 : (lane & 15) >> 1, half = lane & 1;
     int gran = ((isA ? m0 : n0) >> 4) + gp * 2 + (ms >> 1);
     gran = min(gran, ((isA ? NG : KX) >> 4) - 1);
     src[i] = (isA ? G : X) + (int64_t)(tp * 8 + t) * (isA ? pg : px) + gran * 64 + (ms & 1) * 32 + half * 16;
@@ -312,7 +343,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 4) void gemm_tn(const unsign
   auto issue = [&](const int kt, const int stage) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-      const unsigned char* g = src[i] + kt * step_b[i];
+      // elim >= 32: the token index wraps at `elim` tokens -- every step re-reads the same few rows (L2-resident): the ceiling of a
+      // design whose tiles walk the tokens in lock-step
+      const unsigned char* g = src[i] + (elim >= 32 ? kt % (elim >> 5) : kt) * step_b[i];
       const uint32_t laddr = (uint32_t)(stage * STAGE_B + (wave + NW * i) * 1024);
       GLDS(laddr, g);
     }
@@ -324,22 +357,27 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 4) void gemm_tn(const unsign
     for (int ni = 0; ni < 6; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // tr-read addresses: fragment f (granule f of the operand's tile), plane p, read j: piece (f >> 1) * 4 + lq, mini-subtile
   // (f & 1) * 2 + p, row block j ^ (lq & 1)
-  const int lane_off = lq * 1024 + ((lr >> 2) * 32) + (lr & 3) * 8;
+  // LAY 1: row r = 4 rb + (lr >> 2) of piece lq at r * 128, logical quarter Q = (f & 1) * 2 + plane at position Q ^ ((r >> 1) & 3);
+  // read 0 takes row block rb = lq & 1, read 1 the other: address ^ (512 | 64); lo plane = address ^ 32
+  const int r0 = 4 * (lq & 1) + (lr >> 2);
+  const int lane_off = LAY ? lq * 1024 + r0 * 128 + (((r0 >> 1) & 3) * 32) + (lr & 3) * 8 : lq * 1024 + ((lr >> 2) * 32) + (lr & 3) * 8;
   int offA[MI], offB[6];   // hi plane, read 0; lo = + 256; read 1 = row block flipped
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int f = wm * MI + mi;
-    offA[mi] = (f >> 1) * 4096 + (f & 1) * 512 + lane_off;
+    offA[mi] = LAY ? ((f >> 1) * 4096 + lane_off) ^ ((f & 1) * 64) : (f >> 1) * 4096 + (f & 1) * 512 + lane_off;
   }
 #pragma unroll
   for (int ni = 0; ni < 6; ++ni) {
     const int f = wn * 6 + ni;
-    offB[ni] = 16384 + (f >> 1) * 4096 + (f & 1) * 512 + lane_off;
+    offB[ni] = LAY ? (16384 + (f >> 1) * 4096 + lane_off) ^ ((f & 1) * 64) : 16384 + (f >> 1) * 4096 + (f & 1) * 512 + lane_off;
   }
   const int rb0 = (lq & 1) * 128, rb1 = 128 - rb0;
-  auto frag = [&](const unsigned char* st, const int off) -> bf16x8 {
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + off + rb0));
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + off + rb1));
+  constexpr int LO = LAY ? 32 : 256;
+  auto frag = [&](const unsigned char* st, const int off, const int lo) -> bf16x8 {
+    const int o0 = LAY ? off ^ lo : off + lo + rb0, o1 = LAY ? off ^ lo ^ 576 : off + lo + rb1;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + o0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(st + o1));
     const s16x8 c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, c);
   };
@@ -352,13 +390,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 4) void gemm_tn(const unsign
     bf16x8 ah[MI], al[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      ah[mi] = frag(st, offA[mi]);
-      al[mi] = frag(st, offA[mi] + 256);
+      ah[mi] = frag(st, offA[mi], 0);
+      al[mi] = frag(st, offA[mi], LO);
     }
 #pragma unroll
     for (int ni = 0; ni < 6; ++ni) {
-      const bf16x8 bh = frag(st, offB[ni]);
-      const bf16x8 bl = frag(st, offB[ni] + 256);
+      const bf16x8 bh = frag(st, offB[ni], 0);
+      const bf16x8 bl = frag(st, offB[ni], LO);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
@@ -409,6 +447,9 @@ static int run_nt(int M, int N, int K, int P) {
   float *dA, *dB, *D;
   unsigned char *pA, *pB;
   const size_t sa = (size_t)M * K * 4, sb = (size_t)N * K * 4, sd = (size_t)M * N * 4;
+  // ROT > 1: successive launches rotate through ROT operand / output sets (cache-cold operands, as inside a train step)
+  const int ROT = getenv("ROT") ? atoi(getenv("ROT")) : 1, P1 = P;
+  P *= ROT;
   CK(hipMalloc(&dA, sa)); CK(hipMalloc(&dB, sb)); CK(hipMalloc(&D, sd * P)); CK(hipMalloc(&pA, sa * P + 256)); CK(hipMalloc(&pB, sb * P + 256));
   CK(hipMemcpy(dA, hA.data(), sa, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), sb, hipMemcpyHostToDevice));
   for (int p = 0; p < P; ++p) {
@@ -418,14 +459,19 @@ static int run_nt(int M, int N, int K, int P) {
   CK(hipDeviceSynchronize());
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   std::vector<float> hD((size_t)M * N);
-  for (int var = 1; var < 5; ++var) {
+  for (int var = 1; var < 8; ++var) {
     const int nw = var == 0 || var == 4 ? 4 : 8;
-    auto kern = var == 0 ? gemm_nt<4, 0> : (var == 1 ? gemm_nt<8, 0> : (var == 2 ? gemm_nt<8, 1> : (var == 3 ? gemm_nt<8, 2> : gemm_nt64)));
-    const int lds = var == 4 ? 64 * 1024 : 2 * STAGE_B;
+    auto kern = var == 0 ? gemm_nt<4, 0> : (var == 1 ? gemm_nt<8, 0> : (var == 2 ? gemm_nt<8, 1> : (var == 3 ? gemm_nt<8, 2> : (var == 4 ? gemm_nt64 : (var == 5 ? gemm_nt<8, 3> :
+                (var == 6 ? gemm_nt<8, 4, 3> : gemm_nt<8, 4>))))));   // map5 = map2 with 3 stages, map6 = map4 (prefetch) + DMA pieces between the MFMA groups
+    const int lds = var == 4 ? 64 * 1024 : (var == 6 ? 3 : 2) * STAGE_B;   // map5: interleaved DMA + 3 stages
     const int ntile = var == 4 ? ((M + 63) / 64) * ((N + BN - 1) / BN) : tiles;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     CK(hipMemset(D, 0, sd * P));
-    auto launch = [&]() { kern<<<ntile * P, nw * 64, lds>>>(pA, pB, D, M, N, K, (int64_t)sa, (int64_t)sb, (int64_t)M * N); };
+    int rot = ROT - 1;
+    auto launch = [&]() {
+      kern<<<ntile * P1, nw * 64, lds>>>(pA + (size_t)rot * P1 * sa, pB + (size_t)rot * P1 * sb, D + (size_t)rot * P1 * M * N, M, N, K, (int64_t)sa, (int64_t)sb, (int64_t)M * N, getenv("ELIM") ? atoi(getenv("ELIM")) : 0);
+      rot = (rot + 1) % ROT;
+    };
     launch();
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(hD.data(), D + (size_t)(P - 1) * M * N, sd, hipMemcpyDeviceToHost));
@@ -438,8 +484,8 @@ static int run_nt(int M, int N, int K, int P) {
       den += ref * ref;
     }
     const float us = time_us(launch, 20);
-    printf("nt %dw map%d  M %d N %d K %d x%d  tiles %d  %8.1f us  %7.1f TFLOP/s  rel-L2 %.2e\n", nw, var > 1 ? var - 1 : 0, M, N, K, P, ntile * P, us,
-           2.0 * M * N * K * P / us / 1e6, sqrt(num / den));
+    printf("nt %dw map%d  M %d N %d K %d x%d rot%d  tiles %d  %8.1f us  %7.1f TFLOP/s  rel-L2 %.2e\n", nw, var > 1 ? var - 1 : 0, M, N, K, P1, ROT, ntile * P1, us,
+           2.0 * M * N * K * P1 / us / 1e6, sqrt(num / den));
   }
   hipFree(dA); hipFree(dB); hipFree(D); hipFree(pA); hipFree(pB);
   return 0;
@@ -459,8 +505,9 @@ static int run_tn(int T, int NG, int KX, int P, int elim) {
   CK(hipDeviceSynchronize());
   const int tiles = ((NG + BM - 1) / BM) * ((KX + BN - 1) / BN);
   std::vector<float> hD((size_t)NG * KX);
+  for (int lay = 0; lay < 2; ++lay)
   for (int nw = 4; nw <= 8; nw += 4) {
-    auto kern = nw == 4 ? gemm_tn<4> : gemm_tn<8>;
+    auto kern = lay ? (nw == 4 ? gemm_tn<4, 1> : gemm_tn<8, 1>) : (nw == 4 ? gemm_tn<4, 0> : gemm_tn<8, 0>);
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B));
     CK(hipMemset(D, 0, sd * P));
     auto launch = [&]() { kern<<<tiles * P, nw * 64, 2 * STAGE_B>>>(pG, pX, D, T, NG, KX, (int64_t)sg, (int64_t)sx, (int64_t)NG * KX, elim); };
@@ -476,7 +523,7 @@ static int run_tn(int T, int NG, int KX, int P, int elim) {
       den += ref * ref;
     }
     const float us = time_us(launch, 10);
-    printf("tn %dw  T %d NG %d KX %d x%d  tiles %d  %8.1f us  %7.1f TFLOP/s  rel-L2 %.2e%s\n", nw, T, NG, KX, P, tiles * P, us,
+    printf("tn lay%d %dw  T %d NG %d KX %d x%d  tiles %d  %8.1f us  %7.1f TFLOP/s  rel-L2 %.2e%s\n", lay, nw, T, NG, KX, P, tiles * P, us,
            2.0 * T * NG * KX * P / us / 1e6, sqrt(num / den), elim ? " (elim)" : "");
   }
   hipFree(dG); hipFree(dX); hipFree(D); hipFree(pG); hipFree(pX);

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvptr_hip.so")
+LIB_PATH = os.environ.get("VPTR_HIP_LIB") or os.path.join(_HERE, "libvptr_hip.so")   # VPTR_HIP_LIB: an instrumented build of the same sources (tools/)
 
 c_void_p, c_int, c_float, c_int64, c_uint32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64, ctypes.c_uint32
 

@@ -92,10 +92,18 @@ extern "C" int vptr_weight_planes(const vptr_wplane_entry* table_dev, const int*
 // K % 32 == 16: the last step's second granule does not exist; its DMA lanes re-fetch the first one (always valid memory)
 // and the A fragments of lanes lq >= 2 are zeroed.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GNT, 4) void vptr_gemm_p16_kernel(const vptr_gemm_desc p, const int epi_rows) {
+// LEAN: plain epilogue only (gemm_shared.h).  NST = 3: the instantiation for grids of at most one workgroup per CU (nothing else on
+// the CU hides a stall): three stages with the DMA two K-steps ahead, its pieces issued between the MFMA groups instead of in a
+// burst after the barrier (cache-cold 10 240 x 528 x 2112: 79.7 -> 73.1 us in tools/gemm_p16_probe).  Both chosen by the launcher.
+template <bool LEAN, int NST>
+__global__ __launch_bounds__(GNT, NST == 3 ? 2 : 4) void vptr_gemm_p16_kernel(const vptr_gemm_desc p, const int epi_rows) {
   constexpr int NFN = 11, BN = 176;
   extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef VPTR_P16_TIMING   // debug build: p.Dpre is a [tiles][4] int64 buffer of wall-clock stamps (100 MHz) -- tools/nt_timing.py
+  const long long tm0 = wall_clock64();
+  long long tm1 = 0;
+#endif
   // waves w and w + 4 of a workgroup share a SIMD: with wn = wave >> 2 every SIMD hosts one wave of each column half, so skipping
   // the padding fragment of the odd half (176 = 11 fragments = 6 + 5) takes 1/12 off every SIMD's MFMA time (+4-5 % measured)
   const int wm = wave & 3, wn = wave >> 2, lr = lane & 15, lq = lane >> 4;
@@ -136,15 +144,16 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_p16_kernel(const vptr_gemm_d
     const int c = pch ^ (((lane >> 4) + 4 * wave) & 7);
     tadj = c >= 4 ? -64 : 0;
   }
-  auto issue = [&](const int kt, const int stage) {
+  auto issue1 = [&](const int kt, const int stage, const int i) {   // piece i of this wave: 0, 1 = A, 2 .. 4 = B
     const int sg = (int)(kt >= nk) + (int)(kt >= 2 * nk);
     const int kk = kt - sg * nk;
-    const int64_t oa = (sg == 0 ? (int64_t)0 : (sg == 1 ? sA1 : sA2)) + (int64_t)kk * 128 + ((ktail && kk == nk - 1) ? tadj : 0);
-    const int64_t ob = (sg == 0 ? (int64_t)0 : (sg == 1 ? sB1 : sB2)) + (int64_t)kk * 128 + ((ktail && kk == nk - 1) ? tadj : 0);
+    const int64_t off = (int64_t)kk * 128 + ((ktail && kk == nk - 1) ? tadj : 0);
+    if (i < 2) P16_GLDS((uint32_t)(stage * P16_STAGE + (wave + 8 * i) * 1024), srcA[i] + ((sg == 0 ? (int64_t)0 : (sg == 1 ? sA1 : sA2)) + off));
+    else P16_GLDS((uint32_t)(stage * P16_STAGE + 16384 + (wave + 8 * (i - 2)) * 1024), srcB[i - 2] + ((sg == 0 ? (int64_t)0 : (sg == 1 ? sB1 : sB2)) + off));
+  };
+  auto issue = [&](const int kt, const int stage) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) P16_GLDS((uint32_t)(stage * P16_STAGE + (wave + 8 * i) * 1024), srcA[i] + oa);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) P16_GLDS((uint32_t)(stage * P16_STAGE + 16384 + (wave + 8 * i) * 1024), srcB[i] + ob);
+    for (int i = 0; i < 5; ++i) issue1(kt, stage, i);
   };
 
   f32x4 acc[2][6];
@@ -167,11 +176,18 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_p16_kernel(const vptr_gemm_d
   // lo chunk = hi chunk + 2 under the XOR swizzle: (ch + 2) ^ f = (ch ^ f) ^ 2 because bit 1 of ch is clear
   const int nkt = nk * nseg;
   issue(0, 0);
+  if (NST == 3 && nkt > 1) issue(1, 1);
+  int sc = 0, sn = 2;   // NST == 3: stage of step kt, stage that step kt + 2 goes to
   for (int kt = 0; kt < nkt; ++kt) {
-    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): step kt has landed (the only DMA in flight)
-    __syncthreads();                      // ... for every wave, and everyone is done reading the other stage
-    if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
-    const unsigned char* st = p16_smem + (kt & 1) * P16_STAGE;
+    // step kt has landed: with three stages step kt + 1 (5 pieces per wave) may still be in flight
+    if (NST == 3 && kt + 1 < nkt) __builtin_amdgcn_s_waitcnt(0x0f70 | 5);
+    else __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();                      // ... for every wave, and everyone is done reading the stage the next DMA overwrites
+#ifdef VPTR_P16_TIMING
+    if (kt == 0) tm1 = wall_clock64();
+#endif
+    if (NST == 2 && kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+    const unsigned char* st = p16_smem + (NST == 3 ? sc : (kt & 1)) * P16_STAGE;
     bf16x8 ah[2], al[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -188,25 +204,64 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_p16_kernel(const vptr_gemm_d
         }
       }
     }
+    // the next B fragment pair is requested before the MFMAs of the current one (an in-order wave otherwise waits out every
+    // LDS round trip with the matrix pipe idle)
+    bf16x8 bh[2], bl[2];
+    bh[0] = *reinterpret_cast<const bf16x8*>(st + offBh[0]);
+    bl[0] = *reinterpret_cast<const bf16x8*>(st + (offBh[0] ^ 32));
 #pragma unroll
     for (int ni = 0; ni < 6; ++ni) {
       if (ni == 5 && wn == 1) break;   // wave-uniform: fragment 11 of the tile does not exist
-      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(st + offBh[ni]);
-      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(st + (offBh[ni] ^ 32));
+      if (ni + 1 < 6 && !(ni + 1 == 5 && wn == 1)) {
+        bh[(ni + 1) & 1] = *reinterpret_cast<const bf16x8*>(st + offBh[ni + 1]);
+        bl[(ni + 1) & 1] = *reinterpret_cast<const bf16x8*>(st + (offBh[ni + 1] ^ 32));
+      }
+      if (NST == 3 && ni < 5 && kt + 2 < nkt) issue1(kt + 2, sn, ni);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl[ni & 1], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (NST == 3) {
+      sc = sc == 2 ? 0 : sc + 1;
+      sn = sn == 2 ? 0 : sn + 1;
     }
   }
-  if ((epi_rows || p.d_p16) && !p.atomic && epi_vec_ok(p)) {
+#ifdef VPTR_P16_TIMING
+  const long long tm2 = wall_clock64();
+  long long* const tbuf = reinterpret_cast<long long*>(p.Dpre);
+  long long tme[5] = {0, 0, 0, 0, 0};
+#endif
+  if (LEAN) {
     __syncthreads();  // the last stage is still being read by slower waves
+#ifdef VPTR_P16_TIMING
+    gemm_epilogue_rows_halves_batched<NFN, true>(p, mb, acc, reinterpret_cast<float*>(p16_smem), m0, n0, wm, wn, lr, lq, tid, true, false, tme);
+#else
+    gemm_epilogue_rows_halves_batched<NFN, true>(p, mb, acc, reinterpret_cast<float*>(p16_smem), m0, n0, wm, wn, lr, lq, tid, true, false);
+#endif
+  } else if (NST == 3 && (epi_rows || p.d_p16) && !p.atomic && epi_vec_ok(p)) {
+    // the full epilogue with its operand loads batched: affordable under this instantiation's 256-register budget
+    __syncthreads();
+    gemm_epilogue_rows_halves_batched<NFN, false>(p, mb, acc, reinterpret_cast<float*>(p16_smem), m0, n0, wm, wn, lr, lq, tid, true, false);
+  } else if ((epi_rows || p.d_p16) && !p.atomic && epi_vec_ok(p)) {
+    __syncthreads();
     gemm_epilogue_rows_halves<NFN>(p, mb, acc, reinterpret_cast<float*>(p16_smem), m0, n0, wm, wn, lr, lq, tid, true, false);
   } else {
     gemm_epilogue_serial<NFN>(p, mb, acc, m0, n0, wm, wn, lr, lq, true, p.atomic != 0);
   }
+#ifdef VPTR_P16_TIMING
+  if (LEAN && tbuf) {
+    __syncthreads();
+    if (tid == 0) {
+      tbuf[blockIdx.x * 16 + 0] = tm0; tbuf[blockIdx.x * 16 + 1] = tm1; tbuf[blockIdx.x * 16 + 2] = tm2; tbuf[blockIdx.x * 16 + 3] = wall_clock64();
+      for (int i = 0; i < 5; ++i) tbuf[blockIdx.x * 16 + 4 + i] = tme[i];
+    }
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -336,23 +391,30 @@ __global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kerne
         }
       }
     }
+    // the next B fragment pair is requested before the MFMAs of the current one (see vptr_gemm_p16_kernel)
+    bf16x8 bh[2], bl[2];
+    bh[0] = p16_tr_frag(st, offB[0], rb0);
+    bl[0] = p16_tr_frag(st, offB[0] + 256, rb0);
 #pragma unroll
     for (int ni = 0; ni < 6; ++ni) {
       if (ni == 5 && wn == 1 && !want_rowsum) break;   // wave-uniform: the padding fragment only works for the bias gradient
-      bf16x8 bh, bl;
-      if (ni == 5 && want_rowsum) {
-        bh = ones;
-        bl = zeros;
-      } else {
-        bh = p16_tr_frag(st, offB[ni], rb0);
-        bl = p16_tr_frag(st, offB[ni] + 256, rb0);
+      if (ni + 1 < 6) {
+        if (ni + 1 == 5 && wn == 1) {   // wave-uniform: fragment 11 does not exist; ones for the bias gradient (unused otherwise)
+          bh[(ni + 1) & 1] = ones;
+          bl[(ni + 1) & 1] = zeros;
+        } else {
+          bh[(ni + 1) & 1] = p16_tr_frag(st, offB[ni + 1], rb0);
+          bl[(ni + 1) & 1] = p16_tr_frag(st, offB[ni + 1] + 256, rb0);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl[ni & 1], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // epilogue: D += alpha * acc (fp32 atomics into the gradient slab: the same weight may receive several contributions)
@@ -388,6 +450,16 @@ __global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kerne
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
+static int vptr_cu_count() {   // compute units of the current device (256 on MI355X); 0 if the query fails (then no grid counts as "lone")
+  static int n = -1;
+  if (n < 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) n = v;
+    else n = 0;
+  }
+  return n;
+}
+
 static int p16_epi_rows_flag() {
   static int v = -1;
   if (v < 0) {
@@ -431,14 +503,32 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
                "vptr_gemm(p16): a P16 output needs N, ldd multiples of 16, 64-byte aligned D and 16-byte aligned epilogue operands, no atomics");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess) {
       vptr_set_error("vptr_gemm(p16): cannot reserve %d bytes of LDS", 2 * P16_STAGE);
       return -1;
     }
     attr_set = true;
   }
   const int tiles = ((d.M + GBM - 1) / GBM) * ((d.N + 175) / 176) * d.batch;
-  vptr_gemm_p16_kernel<<<tiles, GNT, 2 * P16_STAGE, st>>>(d, p16_epi_rows_flag() & 2);
+  // the plain launches (bias / alpha / residual, fp32 or P16 output, vector-aligned) take the lean instantiation
+  uintptr_t ebits = reinterpret_cast<uintptr_t>(d.D) | reinterpret_cast<uintptr_t>(d.residual) | reinterpret_cast<uintptr_t>(d.bias);
+  if (d.batch > 1) ebits |= reinterpret_cast<uintptr_t>(d.D_x1) | reinterpret_cast<uintptr_t>(d.D_x2) | reinterpret_cast<uintptr_t>(d.bias_x1) | reinterpret_cast<uintptr_t>(d.bias_x2);
+  #ifdef VPTR_P16_TIMING
+  const bool dpre_ok = true;
+#else
+  const bool dpre_ok = !d.Dpre;
+#endif
+  const bool lean = (p16_epi_rows_flag() & 4) == 0 && !d.colscale && dpre_ok && !d.rowscale && d.act == VPTR_ACT_NONE && d.dropout_p == 0.f && !d.act_after && !d.atomic &&
+                    (ebits & 15) == 0 && (d.N & 3) == 0 && (d.ldd & 3) == 0 && (d.ldr & 3) == 0;
+  const bool lone = tiles <= vptr_cu_count() && (p16_epi_rows_flag() & 16) == 0;   // at most one workgroup per CU
+  const int rows = lean ? 1 : (p16_epi_rows_flag() & 2);
+  if (lean && lone) vptr_gemm_p16_kernel<true, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, rows);
+  else if (lean) vptr_gemm_p16_kernel<true, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, rows);
+  else if (lone) vptr_gemm_p16_kernel<false, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, rows);
+  else vptr_gemm_p16_kernel<false, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, rows);
   return 0;
 }
 

@@ -316,6 +316,118 @@ __device__ __forceinline__ void gemm_epilogue_rows_halves(const vptr_gemm_desc& 
 }
 
 
+// LEAN: the instantiation for the plain launches (bias, alpha, residual, fp32 or P16 output only -- most launches of a step): the
+// other options are compiled out, which keeps the code a workgroup walks through after its K loop short (the full epilogue is
+// ~20 k instructions of mostly skipped branches; measured +9 us on a 25 us K = 528 GEMM).
+template <int NFN, bool LEAN>
+__device__ __forceinline__ void gemm_epilogue_rows_halves_batched(const vptr_gemm_desc& p, const Member& mb, f32x4 (&acc)[2][(NFN + 1) / 2], float* sE,
+                                                          const int m0, const int n0, const int wm, const int wn, const int lr, const int lq,
+                                                          const int tid, const bool first_split, const bool use_atomic_in, long long* tm = nullptr) {
+  constexpr int NFW = (NFN + 1) / 2, BN = 16 * NFN, PITCH = BN + 4, C4 = BN / 4, HR = GBM / 2, NPIECE = HR * C4;
+  const bool has_res = p.residual && first_split;
+  const bool has_bias = mb.bias && first_split;
+  const bool use_atomic = !LEAN && use_atomic_in;
+  const float* const colscale = LEAN ? nullptr : p.colscale;
+  float* const Dpre = LEAN ? nullptr : p.Dpre;
+  const float* const rowscale = LEAN ? nullptr : p.rowscale;
+  const auto D_planes = LEAN ? decltype(p.D_planes)(nullptr) : p.D_planes;
+  const int act = LEAN ? VPTR_ACT_NONE : p.act;
+  const float dropout_p = LEAN ? 0.f : p.dropout_p;
+  const bool act_after = !LEAN && p.act_after;
+  uint64_t seed = 0;
+  if (dropout_p > 0.f) seed = *p.seed_dev;
+  constexpr int NIT = (NPIECE + GNT - 1) / GNT;
+  // A lone workgroup has nobody to hide its latencies behind, and D may alias the residual (loads do not move across earlier
+  // stores): the per-column operands are applied when the fragments are spilled (one batch of loads per lane), and the
+  // residual / row-scale operands of a row half are all requested before its first store.
+  float bs[NFW], cs[NFW];
+#pragma unroll
+  for (int ni = 0; ni < NFW; ++ni) {
+    const int nf = wn * NFW + ni, col = n0 + nf * 16 + lr;
+    const bool ok = (nf < NFN) & (col < p.N);
+    bs[ni] = (has_bias && ok) ? mb.bias[col] : 0.f;
+    cs[ni] = (colscale && ok) ? colscale[col] : 1.f;
+  }
+#ifdef VPTR_P16_TIMING
+  if (tm) { float z = 0.f; for (int ni = 0; ni < NFW; ++ni) z += bs[ni]; if (z == 12345.678f) sE[0] = z; tm[0] = wall_clock64(); }
+#endif
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    f32x4 res[NIT];
+    float rsv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int piece = it * GNT + tid;
+      const int rl = piece / C4;
+      const int row = m0 + h * HR + rl, col = n0 + (piece - rl * C4) * 4;
+      const bool ok = piece < NPIECE && row < p.M && col < p.N;
+      res[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (has_res && ok) res[it] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)row * p.ldr + col);
+      rsv[it] = (rowscale && ok) ? rowscale[(row / p.rs_div) % p.rs_mod] : 1.f;
+    }
+    if ((wm >> 1) == h) {  // wave-uniform: the four waves of this row half spill their fragments
+#pragma unroll
+      for (int ni = 0; ni < NFW; ++ni) {
+        const int nf = wn * NFW + ni;
+        if (nf < NFN) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              sE[((wm & 1) * 32 + mi * 16 + lq * 4 + r) * PITCH + nf * 16 + lr] = (acc[mi][ni][r] * cs[ni] + bs[ni]) * mb.alpha;
+        }
+      }
+    }
+    __syncthreads();
+#ifdef VPTR_P16_TIMING
+    if (tm) tm[1 + 2 * h] = wall_clock64();
+#endif
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int piece = it * GNT + tid;
+      const int rl = piece / C4;
+      const int row = m0 + h * HR + rl, col = n0 + (piece - rl * C4) * 4;
+      if (piece < NPIECE && row < p.M && col < p.N) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&sE[rl * PITCH + (piece - rl * C4) * 4]);
+        if (Dpre) *reinterpret_cast<f32x4*>(Dpre + (int64_t)row * p.ldd + col) = v;
+        const float rs = rsv[it];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = vptr_act(v[e], act) * rs;
+          if (dropout_p > 0.f) t *= vptr_drop_scale(seed, p.site, (uint64_t)row * (uint64_t)p.N + col + e, dropout_p);
+          t += res[it][e];
+          if (act_after) t = t > 0.f ? t : 0.f;
+          v[e] = t;
+        }
+        if (D_planes) {  // the consumer's operand format straight from the producer: hi | lo of this row's 32-channel block
+          uint32_t hi[2], lo[2];
+          split2(v[0], v[1], hi[0], lo[0]);
+          split2(v[2], v[3], hi[1], lo[1]);
+          __bf16* o = reinterpret_cast<__bf16*>(D_planes) + ((int64_t)row * ((p.N + 31) >> 5) + (col >> 5)) * 64 + (col & 31);
+          *reinterpret_cast<uint2*>(o) = make_uint2(hi[0], hi[1]);
+          *reinterpret_cast<uint2*>(o + 32) = make_uint2(lo[0], lo[1]);
+        }
+        if (mb.D) {
+          float* dst = mb.D + (int64_t)row * p.ldd + col;
+          if (p.d_p16) {   // the consumer GEMM's operand format straight from this epilogue
+            vptr_p16_store4(reinterpret_cast<unsigned char*>(mb.D), (int64_t)row * p.ldd + col, make_float4(v[0], v[1], v[2], v[3]));
+          } else if (use_atomic) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e, v[e]);
+          } else {
+            *reinterpret_cast<f32x4*>(dst) = v;
+          }
+        }
+      }
+    }
+#ifdef VPTR_P16_TIMING
+    if (tm) tm[2 + 2 * h] = wall_clock64();
+#endif
+    if (h == 0) __syncthreads();
+  }
+}
+
+
 // ---- epilogue of the single-image loop: element by element (load -> compute -> store).  Two workgroups share the CU there and
 // cover each other's latencies, and under its 128-VGPR cap the batched-load form below spills (measured: fc1 156 -> 200 us).
 template <int NFN>
