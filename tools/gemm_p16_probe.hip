@@ -99,13 +99,42 @@ __global__ __launch_bounds__(NW * 64, NST == 3 ? 2 : (NW == 4 ? 2 : 4)) void gem
     src[i] = (isA ? A : B) + grow * pitch + c * 16;
     tail_adj[i] = c >= 4 ? -64 : 0;
   }
+  // PROB 5: scalar-base addressing: per piece one constant 32-bit lane offset; the K-step advances an SGPR base (no VALU per piece)
+  const int swave = __builtin_amdgcn_readfirstlane(wave);
+  uint32_t voff[PPW], voff_tail[PPW];
+  const unsigned char* const tileA = A + (int64_t)m0 * pitch;
+  const unsigned char* const tileB = B + (int64_t)n0 * pitch;
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int u = wave + NW * i;
+    const bool isA = u < 16;
+    const int prow = (isA ? u : u - 16) * 8 + (lane >> 3), pch = lane & 7;
+    const int c = pch ^ ((prow >> 1) & 7);
+    const int lrow = isA ? min(prow, M - 1 - m0) : min(prow, N - 1 - n0);
+    voff[i] = (uint32_t)(lrow * (int)pitch + c * 16);
+    voff_tail[i] = voff[i] + (c >= 4 ? -64 : 0);
+  }
   auto issue1 = [&](const int kt, const int stage, const int i) {
+    if (PROB == 5) {
+      const bool lastk = ktail && kt == nk - 1;
+      const bool isA = NW == 8 ? i < 2 : (swave + NW * i) < 16;
+      const unsigned char* base = (isA ? tileA : tileB) + (int64_t)kt * 128;
+      const uint32_t laddr = (uint32_t)(stage * STAGE_B + (swave + NW * i) * 1024);
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(laddr), "v"(lastk ? voff_tail[i] : voff[i]), "s"(base) : "memory");
+      return;
+    }
     const bool last = ktail && kt == nk - 1;
     // elim 2 / 3: only the A / B pieces after step 1; elim 4: every piece re-reads K-step 0 (cache-resident source)
     if (kt > 1 && ((elim == 2 && wave + NW * i >= 16) || (elim == 3 && wave + NW * i < 16))) return;
     const unsigned char* g = src[i] + (int64_t)(elim == 4 ? 0 : kt) * 128 + (last ? tail_adj[i] : 0);
     const uint32_t laddr = (uint32_t)(stage * STAGE_B + (wave + NW * i) * 1024);
-    GLDS(laddr, g);
+    // elim 5 / 6: every piece is issued, but (after step 1) with 1 / 16 active lanes: instruction count kept, bytes cut
+    if (kt > 1 && elim == 7) {   // M0 written for piece 0 only: the other pieces land on top of it (timing experiment)
+      if (i == 0) GLDS(laddr, g);
+      else asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(g) : "memory");
+    } else if (kt > 1 && elim == 5) { if (lane == 0) GLDS(laddr, g); }
+    else if (kt > 1 && elim == 6) { if (lane < 16) GLDS(laddr, g); }
+    else GLDS(laddr, g);
   };
   auto issue = [&](const int kt, const int stage) {
 #pragma unroll
@@ -153,7 +182,7 @@ __global__ __launch_bounds__(NW * 64, NST == 3 ? 2 : (NW == 4 ? 2 : 4)) void gem
         al[mi] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
       }
     }
-    if (PROB == 3 || PROB == 4) {   // map 2 + the next B fragment pair requested before the MFMAs of the current one; 4: DMA pieces between the MFMA groups
+    if (PROB == 3 || PROB == 4 || PROB == 5) {   // map 2 + the next B fragment pair requested before the MFMAs of the current one; 4: DMA pieces between the MFMA groups
       bf16x8 bh[2], bl[2];
       bh[0] = *reinterpret_cast<const bf16x8*>(st + offBh[0]);
       bl[0] = *reinterpret_cast<const bf16x8*>(st + offBl[0]);
@@ -177,7 +206,7 @@ __global__ __launch_bounds__(NW * 64, NST == 3 ? 2 : (NW == 4 ? 2 : 4)) void gem
     } else {
 #pragma unroll
     for (int ni = 0; ni < 6; ++ni) {
-      if (PROB == 2 && ni == 5 && wn == 1) break;   // wave-uniform
+      if ((PROB == 2) && ni == 5 && wn == 1) break;   // wave-uniform
       const bf16x8 bh = *reinterpret_cast<const bf16x8*>(st + offBh[ni]);
       const bf16x8 bl = *reinterpret_cast<const bf16x8*>(st + offBl[ni]);
 #pragma unroll
@@ -462,8 +491,8 @@ static int run_nt(int M, int N, int K, int P) {
   for (int var = 1; var < 8; ++var) {
     const int nw = var == 0 || var == 4 ? 4 : 8;
     auto kern = var == 0 ? gemm_nt<4, 0> : (var == 1 ? gemm_nt<8, 0> : (var == 2 ? gemm_nt<8, 1> : (var == 3 ? gemm_nt<8, 2> : (var == 4 ? gemm_nt64 : (var == 5 ? gemm_nt<8, 3> :
-                (var == 6 ? gemm_nt<8, 4, 3> : gemm_nt<8, 4>))))));   // map5 = map2 with 3 stages, map6 = map4 (prefetch) + DMA pieces between the MFMA groups
-    const int lds = var == 4 ? 64 * 1024 : (var == 6 ? 3 : 2) * STAGE_B;   // map5: interleaved DMA + 3 stages
+                (var == 6 ? gemm_nt<8, 5> : gemm_nt<8, 4>))))));   // map5: scalar-base DMA addressing   // map5 = map2 with 3 stages, map6 = map4 (prefetch) + DMA pieces between the MFMA groups
+    const int lds = var == 4 ? 64 * 1024 : 2 * STAGE_B;   // map5: interleaved DMA + 3 stages
     const int ntile = var == 4 ? ((M + 63) / 64) * ((N + BN - 1) / BN) : tiles;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     CK(hipMemset(D, 0, sd * P));
