@@ -39,3 +39,8 @@ for (M, N, K, flags) in [(10240, 528, 528, "b"), (10240, 528, 528, "br"), (10240
               M, N, K, flags, tiles, float(t[:, 3].max() - t0), start.median(), start.max(), first.median(), first.max(), loop.median(), loop.max(),
               float(loop.median()) / ((K + 31) // 32), epi.median(), epi.max(), (t[:, 3] - t[:, 0]).median(), (t[:, 3] - t[:, 0]).max(),
               *[float((t[:, 4 + i] - t[:, 2]).median()) for i in range(5)]))
+    raw = sets[-1][1].cpu().double()
+    epi_cyc = raw[:, 11]
+    ghz = float((epi_cyc / ((t[:, 3] - t[:, 2]) * 1e3)).median())     # shader-clock cycles per ns over the epilogue
+    print("    wave 0 of each workgroup, K loop: waiting for the step (waitcnt + barrier) %.1f us, issuing DMA %.1f us of %.1f us  (shader clock %.2f GHz)"
+          % (float(raw[:, 9].median()) / ghz / 1e3, float(raw[:, 10].median()) / ghz / 1e3, float(loop.median()), ghz))

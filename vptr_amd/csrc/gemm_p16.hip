@@ -178,15 +178,25 @@ __global__ __launch_bounds__(GNT, NST == 3 ? 2 : 4) void vptr_gemm_p16_kernel(co
   issue(0, 0);
   if (NST == 3 && nkt > 1) issue(1, 1);
   int sc = 0, sn = 2;   // NST == 3: stage of step kt, stage that step kt + 2 goes to
+#ifdef VPTR_P16_TIMING
+  long long cyc_wait = 0, cyc_issue = 0, cyc_t = 0;   // shader-clock cycles this wave spent waiting for the step / issuing its DMA
+#endif
   for (int kt = 0; kt < nkt; ++kt) {
+#ifdef VPTR_P16_TIMING
+    cyc_t = clock64();
+#endif
     // step kt has landed: with three stages step kt + 1 (5 pieces per wave) may still be in flight
     if (NST == 3 && kt + 1 < nkt) __builtin_amdgcn_s_waitcnt(0x0f70 | 5);
     else __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();                      // ... for every wave, and everyone is done reading the stage the next DMA overwrites
 #ifdef VPTR_P16_TIMING
     if (kt == 0) tm1 = wall_clock64();
+    { const long long c = clock64(); cyc_wait += c - cyc_t; cyc_t = c; }
 #endif
     if (NST == 2 && kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+#ifdef VPTR_P16_TIMING
+    cyc_issue += clock64() - cyc_t;
+#endif
     const unsigned char* st = p16_smem + (NST == 3 ? sc : (kt & 1)) * P16_STAGE;
     bf16x8 ah[2], al[2];
 #pragma unroll
@@ -233,6 +243,7 @@ __global__ __launch_bounds__(GNT, NST == 3 ? 2 : 4) void vptr_gemm_p16_kernel(co
   }
 #ifdef VPTR_P16_TIMING
   const long long tm2 = wall_clock64();
+  const long long cyc_end = clock64();
   long long* const tbuf = reinterpret_cast<long long*>(p.Dpre);
   long long tme[5] = {0, 0, 0, 0, 0};
 #endif
@@ -259,6 +270,7 @@ __global__ __launch_bounds__(GNT, NST == 3 ? 2 : 4) void vptr_gemm_p16_kernel(co
     if (tid == 0) {
       tbuf[blockIdx.x * 16 + 0] = tm0; tbuf[blockIdx.x * 16 + 1] = tm1; tbuf[blockIdx.x * 16 + 2] = tm2; tbuf[blockIdx.x * 16 + 3] = wall_clock64();
       for (int i = 0; i < 5; ++i) tbuf[blockIdx.x * 16 + 4 + i] = tme[i];
+      tbuf[blockIdx.x * 16 + 9] = cyc_wait; tbuf[blockIdx.x * 16 + 10] = cyc_issue; tbuf[blockIdx.x * 16 + 11] = clock64() - cyc_end;
     }
   }
 #endif
@@ -360,6 +372,7 @@ __global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kerne
   const bf16x8 ones = {one, one, one, one, one, one, one, one};
   const bf16x8 zeros = {zero, zero, zero, zero, zero, zero, zero, zero};
   const bool ttail = (T & 31) != 0;
+  const bool rows_live = m0 + wm * 32 < NG;
 
   issue(0, 0);
   if (NSTAGE == 3 && nk > 1) issue(1, 1);
@@ -372,6 +385,7 @@ __global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kerne
     } else if (kt + 1 < nk) {
       issue(kt + 1, (kt + 1) & 1);
     }
+    if (!rows_live) continue;   // wave-uniform: this wave's 32 rows lie beyond NG (the last row tile of a 528-row problem keeps 16 of 128)
     const unsigned char* st = p16_smem + (NSTAGE == 3 ? kt % 3 : (kt & 1)) * P16_STAGE;
     bf16x8 ah[2], al[2];
 #pragma unroll
