@@ -159,15 +159,27 @@ __global__ __launch_bounds__(NW * 64, NST == 3 ? 2 : (NW == 4 ? 2 : 4)) void gem
     offBh[ni] = 16384 + r * 128 + ((ch ^ f) << 4);
     offBl[ni] = 16384 + r * 128 + (((ch + 2) ^ f) << 4);
   }
+  // PROB 6: L2 warm-up -- after the DMA of step kt + 1 every wave touches one dword of the lines step kt + 2 will fetch (38 of the
+  // tile's 304 rows per wave); the load is never waited for (vmcnt(1) at the next barrier leaves it in flight)
+  const unsigned char* pf_ptr = nullptr;
+  int pf_sink = 0;
+  if (PROB == 6) {
+    const int r = wave * 38 + lane;
+    pf_ptr = r < 128 ? A + (int64_t)min(m0 + r, M - 1) * pitch : B + (int64_t)min(n0 + r - 128, N - 1) * pitch;
+  }
   issue(0, 0);
   if (NST == 3 && nk > 1) issue(1, 1);
   for (int kt = 0; kt < nk; ++kt) {
     if (NST == 3 && kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | PPW);   // vmcnt(PPW): step kt landed, step kt + 1 may still fly
+    else if (PROB == 6 && kt >= 1 && kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | 1);   // the warm-up load issued after this step's DMA may still fly
     else __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
     if (NST == 3) {
       if (PROB != 4 && kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
     } else if (PROB != 4 && kt + 1 < nk && !(elim == 1 && kt > 0)) issue(kt + 1, (kt + 1) & 1);   // elim 1: no DMA after the second step
+    if (PROB == 6 && kt + 2 < nk) {
+      if (lane < 38) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pf_ptr + (int64_t)(kt + 2) * 128) : "memory");
+    }
     const unsigned char* st = smem + (NST == 3 ? kt % 3 : (kt & 1)) * STAGE_B;
     bf16x8 ah[MI], al[MI];
 #pragma unroll
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(NW * 64, NST == 3 ? 2 : (NW == 4 ? 2 : 4)) void gem
         al[mi] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
       }
     }
-    if (PROB == 3 || PROB == 4 || PROB == 5) {   // map 2 + the next B fragment pair requested before the MFMAs of the current one; 4: DMA pieces between the MFMA groups
+    if (PROB >= 3) {   // map 2 + the next B fragment pair requested before the MFMAs of the current one; 4: DMA pieces between the MFMA groups
       bf16x8 bh[2], bl[2];
       bh[0] = *reinterpret_cast<const bf16x8*>(st + offBh[0]);
       bl[0] = *reinterpret_cast<const bf16x8*>(st + offBl[0]);
@@ -218,6 +230,7 @@ __global__ __launch_bounds__(NW * 64, NST == 3 ? 2 : (NW == 4 ? 2 : 4)) void gem
     }
     }
   }
+  if (PROB == 6) { __builtin_amdgcn_s_waitcnt(0x0f70); asm volatile("" ::"v"(pf_sink)); }
 #pragma unroll
   for (int ni = 0; ni < 6; ++ni) {
     const int nf = wn * 6 + ni, col = n0 + nf * 16 + lr;
@@ -491,7 +504,7 @@ static int run_nt(int M, int N, int K, int P) {
   for (int var = 1; var < 8; ++var) {
     const int nw = var == 0 || var == 4 ? 4 : 8;
     auto kern = var == 0 ? gemm_nt<4, 0> : (var == 1 ? gemm_nt<8, 0> : (var == 2 ? gemm_nt<8, 1> : (var == 3 ? gemm_nt<8, 2> : (var == 4 ? gemm_nt64 : (var == 5 ? gemm_nt<8, 3> :
-                (var == 6 ? gemm_nt<8, 5> : gemm_nt<8, 4>))))));   // map5: scalar-base DMA addressing   // map5 = map2 with 3 stages, map6 = map4 (prefetch) + DMA pieces between the MFMA groups
+                (var == 6 ? gemm_nt<8, 5> : gemm_nt<8, 6>))))));   // map5: scalar-base DMA addressing; map6: L2 warm-up loads   // map5 = map2 with 3 stages, map6 = map4 (prefetch) + DMA pieces between the MFMA groups
     const int lds = var == 4 ? 64 * 1024 : 2 * STAGE_B;   // map5: interleaved DMA + 3 stages
     const int ntile = var == 4 ? ((M + 63) / 64) * ((N + BN - 1) / BN) : tiles;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
