@@ -236,6 +236,12 @@ int vptr_tsattn_bwd(const float* q, const float* k, const float* v, const float*
 /* rstd (optional, may be NULL) = 1/sqrt(var + eps), written by the same launch */
 int vptr_colstats(const float* x, float* mean, float* var, float* rstd, float eps,
                   float* scratch /* >= 2*F*ceil(rows/256) floats */, int rows, int F, vptr_stream_t stream);
+/* the same plus BatchNorm2d's train-mode bookkeeping in the same launch (torch/nn/modules/batchnorm.py as used by
+ * VidHRFormer_modules.py:397-419): running_mean/var <- (1 - momentum) * running + momentum * (mean | var * rows / (rows - 1)),
+ * num_batches_tracked += 1; each of the three may be NULL */
+int vptr_colstats_running(const float* x, float* mean, float* var, float* rstd, float eps, float* scratch, int rows, int F,
+                          float* running_mean, float* running_var, float momentum, long long* num_batches_tracked,
+                          vptr_stream_t stream);
 int vptr_groupstats(const float* x, float* mean, float* var, float* rstd, float eps, int groups, int group_elems,
                     vptr_stream_t stream);
 /* y = rowscale[(row/rs_div)%rs_mod] * dropout(act( (x - mean)*rstd * w + b )) + residual

@@ -68,6 +68,7 @@ SIGNATURES = {
     "vptr_tsattn_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, F, P, U, I, P],
     "vptr_tsattn_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P, U, I, P],
     "vptr_colstats": [P, P, P, P, F, P, I, I, P],
+    "vptr_colstats_running": [P, P, P, P, F, P, I, I, P, P, F, P, P],
     "vptr_groupstats": [P, P, P, P, F, I, I, P],
     "vptr_norm_act_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, P, U, P, I, I, P, I, P],
     "vptr_norm_act_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, P, I, I, I, P],

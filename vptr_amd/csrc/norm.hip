@@ -56,6 +56,58 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
+// The same with the row held in registers between the three sweeps (NC4 float4 per lane; C <= 256 * NC4): one global read of x
+// instead of three dependent ones (a wave has nothing else to hide its round trips behind).
+template <int NC4>
+__global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ y,
+                                                         float* __restrict__ y2, const float* __restrict__ tab, int tab_div,
+                                                         int tab_mod, float* __restrict__ mean, float* __restrict__ rstd,
+                                                         int rows, int C, float eps, int p16) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * C);
+  const int C4 = C >> 2;
+  float4 v[NC4];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NC4; ++j) {
+    const int i = lane + 64 * j;
+    v[j] = i < C4 ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  }
+  const float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NC4; ++j) {
+    if (lane + 64 * j < C4) {
+      const float a = v[j].x - mu, b = v[j].y - mu, c = v[j].z - mu, d = v[j].w - mu;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  const float4* tr = tab ? reinterpret_cast<const float4*>(tab + (int64_t)((row / tab_div) % tab_mod) * C) : nullptr;
+#pragma unroll
+  for (int j = 0; j < NC4; ++j) {
+    const int i = lane + 64 * j;
+    if (i < C4) {
+      const float4 g = reinterpret_cast<const float4*>(gamma)[i];
+      const float4 b = reinterpret_cast<const float4*>(beta)[i];
+      float4 o;
+      o.x = (v[j].x - mu) * rs * g.x + b.x; o.y = (v[j].y - mu) * rs * g.y + b.y;
+      o.z = (v[j].z - mu) * rs * g.z + b.z; o.w = (v[j].w - mu) * rs * g.w + b.w;
+      vptr_store4_fmt(y, (int64_t)row * C + 4 * i, o, p16);
+      if (y2) {
+        const float4 t = tr[i];
+        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+        vptr_store4_fmt(y2, (int64_t)row * C + 4 * i, o, p16);
+      }
+    }
+  }
+}
+
 extern "C" int vptr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* y2,
                                   const float* tab, int tab_div, int tab_mod, float* mean, float* rstd, int rows, int C,
                                   float eps, int p16, vptr_stream_t stream) {
@@ -64,8 +116,14 @@ extern "C" int vptr_layernorm_fwd(const float* x, const float* gamma, const floa
   VPTR_CHECK(rows > 0 && C > 0, "layernorm_fwd: empty input");
   VPTR_CHECK(C % 4 == 0, "layernorm_fwd: C must be a multiple of 4 (got %d)", C);
   if (y2) VPTR_CHECK(tab && tab_div >= 1 && tab_mod >= 1, "layernorm_fwd: y2 needs tab, tab_div, tab_mod");
-  ln_fwd_kernel<<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(x, gamma, beta, y, y2, y2 ? tab : nullptr, tab_div, tab_mod,
-                                                                mean, rstd, rows, C, eps, p16);
+  const int C4 = C >> 2;
+  if (C4 <= 64)
+    ln_fwd_reg_kernel<1><<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(x, gamma, beta, y, y2, y2 ? tab : nullptr, tab_div, tab_mod, mean, rstd, rows, C, eps, p16);
+  else if (C4 <= 192)
+    ln_fwd_reg_kernel<3><<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(x, gamma, beta, y, y2, y2 ? tab : nullptr, tab_div, tab_mod, mean, rstd, rows, C, eps, p16);
+  else
+    ln_fwd_kernel<<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(x, gamma, beta, y, y2, y2 ? tab : nullptr, tab_div, tab_mod,
+                                                                  mean, rstd, rows, C, eps, p16);
   VPTR_LAUNCH_CHECK();
   return 0;
 }
@@ -356,7 +414,9 @@ __global__ __launch_bounds__(256) void colstats_partial_kernel(const float* __re
 }
 __global__ __launch_bounds__(256) void colstats_final_kernel(const float* __restrict__ scratch, float* __restrict__ mean,
                                                              float* __restrict__ var, float* __restrict__ rstd, float eps,
-                                                             int rows, int F, int nchunk) {
+                                                             int rows, int F, int nchunk, float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var, float momentum,
+                                                             long long* __restrict__ num_batches_tracked) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= F) return;
   float n = 0.f, mu = 0.f, m2 = 0.f;
@@ -371,6 +431,11 @@ __global__ __launch_bounds__(256) void colstats_final_kernel(const float* __rest
   mean[c] = mu;
   var[c] = m2 / n;
   if (rstd) rstd[c] = rsqrtf(m2 / n + eps);
+  if (running_mean) {   // BatchNorm2d's train-mode bookkeeping (momentum update, unbiased variance) in the same launch
+    running_mean[c] = running_mean[c] * (1.f - momentum) + mu * momentum;
+    running_var[c] = running_var[c] * (1.f - momentum) + (m2 / n) * (momentum * n / fmaxf(n - 1.f, 1.f));
+  }
+  if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
 }
 
 extern "C" int vptr_colstats(const float* x, float* mean, float* var, float* rstd, float eps, float* scratch, int rows, int F,
@@ -379,7 +444,21 @@ extern "C" int vptr_colstats(const float* x, float* mean, float* var, float* rst
   const int nchunk = cdiv(rows, 256);
   hipStream_t st = (hipStream_t)stream;
   colstats_partial_kernel<<<dim3(cdiv(F / 4, 32), nchunk), 256, 0, st>>>(x, scratch, rows, F / 4);
-  colstats_final_kernel<<<cdiv(F, 256), 256, 0, st>>>(scratch, mean, var, rstd, eps, rows, F, nchunk);
+  colstats_final_kernel<<<cdiv(F, 256), 256, 0, st>>>(scratch, mean, var, rstd, eps, rows, F, nchunk, nullptr, nullptr, 0.f, nullptr);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vptr_colstats_running(const float* x, float* mean, float* var, float* rstd, float eps, float* scratch, int rows, int F,
+                                     float* running_mean, float* running_var, float momentum, long long* num_batches_tracked,
+                                     vptr_stream_t stream) {
+  VPTR_CHECK(rows > 0 && F > 0 && F % 4 == 0 && scratch, "colstats: bad arguments (F must be a multiple of 4)");
+  VPTR_CHECK((running_mean == nullptr) == (running_var == nullptr), "colstats_running: running_mean and running_var go together");
+  const int nchunk = cdiv(rows, 256);
+  hipStream_t st = (hipStream_t)stream;
+  colstats_partial_kernel<<<dim3(cdiv(F / 4, 32), nchunk), 256, 0, st>>>(x, scratch, rows, F / 4);
+  colstats_final_kernel<<<cdiv(F, 256), 256, 0, st>>>(scratch, mean, var, rstd, eps, rows, F, nchunk, running_mean, running_var, momentum,
+                                                      num_batches_tracked);
   VPTR_LAUNCH_CHECK();
   return 0;
 }

@@ -83,11 +83,10 @@ def _bn_eval(bn):
 def _bn_act(y, bn, HW, act, residual=None):
     """BatchNorm2d (+ ReLU / LeakyReLU, + residual) on NHWC tokens [pixels, C]: batch statistics + running-stat update in
     train mode, running statistics in eval mode -- both with autograd (vptr_colstats + vptr_norm_act_fwd/bwd)."""
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        with torch.no_grad():
-            bn.num_batches_tracked.add_(1)
+    nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None   # incremented by the statistics launch
     return ops.norm_act(y, bn.weight, bn.bias, "bn", HW, bn.training, running_mean=bn.running_mean, running_var=bn.running_var,
-                        act=act, eps=bn.eps, momentum=bn.momentum if bn.momentum is not None else 0.1, residual=residual)
+                        act=act, eps=bn.eps, momentum=bn.momentum if bn.momentum is not None else 0.1, residual=residual,
+                        num_batches_tracked=nbt)
 
 
 class ResnetEncoder(nn.Module):

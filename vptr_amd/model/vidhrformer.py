@@ -237,10 +237,9 @@ class MlpDWBN(nn.Module):
             w = norm.weight.reshape(F, HW).t().contiguous()  # channel-last affine [HW, F]
             b = norm.bias.reshape(F, HW).t().contiguous()
             return ops.norm_act(h, w, b, "ln", HW, self.training, eps=norm.eps, **kw)
-        if self.training and norm.track_running_stats:
-            norm.num_batches_tracked.add_(1)
+        nbt = norm.num_batches_tracked if (self.training and norm.track_running_stats) else None   # incremented by the statistics launch
         return ops.norm_act(h, norm.weight, norm.bias, "bn", HW, self.training, norm.running_mean, norm.running_var,
-                            eps=norm.eps, momentum=norm.momentum, **kw)
+                            eps=norm.eps, momentum=norm.momentum, num_batches_tracked=nbt, **kw)
 
     def forward_tokens(self, u, residual, g, site, rowscale=None, rs_div=1, rs_mod=1, x_p16=False):
         """x_p16: u is a P16 tensor.  With P16-eligible widths the tensors that only connect a normalisation to a 1x1 convolution

@@ -1099,7 +1099,7 @@ class _NormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, running_mean, running_var, mode, HW, training, act, eps, p, site, momentum, rowscale, rs_div,
-                rs_mod, residual, out_p16, dx_p16):
+                rs_mod, residual, out_p16, dx_p16, num_batches_tracked):
         x, w, b = _c(x), _c(w), _c(b)
         residual = _c(residual) if residual is not None else None
         rows, F = x.shape
@@ -1113,11 +1113,9 @@ class _NormActFn(torch.autograd.Function):
                 nchunk = (rows + 255) // 256
                 scratch = torch.empty((2 * F * nchunk,), device=dev, dtype=torch.float32)
                 rstd = torch.empty_like(mean)
-                check(lib.vptr_colstats(ptr(x), ptr(mean), ptr(var), ptr(rstd), eps, ptr(scratch), rows, F, stream()), "vptr_colstats")
-                if running_mean is not None:
-                    with torch.no_grad():
-                        running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                        running_var.mul_(1 - momentum).add_(var, alpha=momentum * rows / max(rows - 1, 1))
+                # batch statistics + BatchNorm2d's running-statistics / num_batches_tracked bookkeeping in one launch pair
+                check(lib.vptr_colstats_running(ptr(x), ptr(mean), ptr(var), ptr(rstd), eps, ptr(scratch), rows, F, ptr(running_mean),
+                                                ptr(running_var), momentum, ptr(num_batches_tracked), stream()), "vptr_colstats_running")
             else:
                 mean, var = running_mean, running_var
                 rstd = torch.rsqrt(var + eps)
@@ -1156,20 +1154,20 @@ class _NormActFn(torch.autograd.Function):
         dres = dy if has_res else None
         if in_slab:
             dw = db = None
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None, dres, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None, dres, None, None, None
 
 
 _NormActFn_apply = _direct_apply(_NormActFn)
 
 
 def norm_act(x, w, b, mode, HW, training, running_mean=None, running_var=None, act=ACT_GELU, eps=1e-5, dropout_p=0.0, site=0,
-             momentum=0.1, rowscale=None, rs_div=1, rs_mod=1, residual=None, out_p16=False, dx_p16=False):
+             momentum=0.1, rowscale=None, rs_div=1, rs_mod=1, residual=None, out_p16=False, dx_p16=False, num_batches_tracked=None):
     """y = rowscale * dropout(act(norm(x)*w + b)) + residual  (one elementwise pass; see _NormActFn).
     out_p16: y is written as a P16 tensor (it only feeds a GEMM); dx_p16: the gradient w.r.t. x is returned as a P16 tensor (x is
     the output of a linear(..., dy_p16=True) and nothing else)."""
     return _NormActFn_apply(x, w, b, running_mean, running_var, mode, int(HW), bool(training), int(act), float(eps),
                             float(dropout_p), int(site), float(momentum), rowscale, int(rs_div), int(rs_mod), residual,
-                            bool(out_p16), bool(dx_p16))
+                            bool(out_p16), bool(dx_p16), num_batches_tracked)
 
 
 class _DWConvFn(torch.autograd.Function):
