@@ -111,6 +111,11 @@ typedef struct vptr_gemm_desc {
   /* a_mode = VPTR_A_P16 only: != 0 writes D (and D_x1 / D_x2) in the P16 plane format instead of fp32 (the operand format of the
      GEMM that consumes it; Dpre stays fp32).  Needs N and ldd multiples of 16 and 64-byte aligned outputs. */
   int d_p16;
+  /* a_mode = VPTR_A_P16 only: activation-GRADIENT epilogue.  Non-NULL: an [M, N] fp32 tensor (row pitch ldd) of saved
+     pre-activations h; D = alpha * acc * act'(h) * dropout(seed, site, row * N + col) -- the input gradient of a Linear whose
+     consumer was act(.) + dropout (linear2's dX fused with linear1's activation backward, VidHRFormer_modules.py:89,192), written
+     fp32 or P16.  Not combinable with bias / colscale / Dpre / rowscale / residual / act_after / atomic / batch / ksegs. */
+  const float* act_grad_src;
 } vptr_gemm_desc;
 
 int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream);

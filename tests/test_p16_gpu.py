@@ -131,3 +131,34 @@ def test_linear_autograd_p16(ops, dev):
     assert rel(y, yr) < TOL3
     for got, ref in ((x, xr), (W1, W1r), (b1, b1r), (W2, W2r), (b2, b2r), (r, rr)):
         assert rel(got.grad, ref.grad) < 2 * TOL3
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_mlp_autograd_p16(ops, dev, p):
+    """ops.mlp (one node: GELU' and the dropout mask applied by the epilogue of linear2's input-gradient GEMM, desc.act_grad_src) vs
+    fp64 torch autograd without dropout, and vs the two-node ops.linear chain (same sites -> same masks) with dropout"""
+    M, K, F_, N = 640, 528, 2112, 528
+    vals = [rn((M, K), 1), rn((F_, K), 2, K ** -0.5), rn((F_,), 3), rn((N, F_), 4, F_ ** -0.5), rn((N,), 5), rn((M, N), 6)]
+    g = rn((M, N), 7).to(dev)
+
+    def leaves():
+        return [t.clone().to(dev).requires_grad_(True) for t in vals]
+    x, W1, b1, W2, b2, r = leaves()
+    ops.manual_seed(dev, 77)
+    y = ops.mlp(x, W1, b1, W2, b2, residual=r, dropout_p=p, site1=11, site2=12)
+    (y * g).sum().backward()
+    if p == 0.0:
+        xr, W1r, b1r, W2r, b2r, rr = [t.double().requires_grad_(True) for t in vals]
+        yr = F.gelu(xr @ W1r.t() + b1r) @ W2r.t() + b2r + rr
+        (yr * g.double().cpu()).sum().backward()
+        refs = (xr, W1r, b1r, W2r, b2r, rr)
+    else:
+        refs = leaves()
+        ops.manual_seed(dev, 77)
+        h = ops.linear(refs[0], refs[1], refs[2], act=ops.ACT_GELU, dropout_p=p, site=11, out_p16=True)
+        yr = ops.linear(h, refs[3], refs[4], residual=refs[5], dropout_p=p, site=12, x_p16=True)
+        (yr * g).sum().backward()
+        assert float((y == 0).float().mean()) < 0.01 and rel(y, yr) < 1e-6       # identical masks, identical kernels in forward
+    assert rel(y, yr) < TOL3
+    for got, ref in zip((x, W1, b1, W2, b2, r), refs):
+        assert rel(got.grad, ref.grad) < 2 * TOL3

@@ -18,6 +18,11 @@ python - <<'PY'
 import csv, collections, json, glob, os
 OUT = "gpurun_out/r02"
 def short(n): return n.split("(")[0].replace("void ", "")
+def fam(n):   # PMC tables: the instantiations of the P16 kernels as one family (bench.py looks the dominant kernel up by this name)
+    s = short(n)
+    for base in ("vptr_gemm_p16_kernel", "vptr_wgrad_p16_kernel"):
+        if s.startswith(base): return base
+    return s
 # ---- (1) kernel stats
 rows = list(csv.DictReader(open(OUT + "/stats/b_kernel_stats.csv")))
 steps = 26.0   # 5 warm-up + 20 timed + 1 instrumented
@@ -38,7 +43,7 @@ for tag, cname in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(OUT + "/pmc/%s_counter_collection.csv" % tag)):
         if r["Counter_Name"] != cname: continue
-        k = short(r["Kernel_Name"]); agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
+        k = fam(r["Kernel_Name"]); agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
     for k, (n, v) in agg.items():
         res.setdefault(k, {})[cname] = v / n; res[k]["launches"] = n
 out = {k: v for k, v in sorted(res.items(), key=lambda kv: -(kv[1].get("FETCH_SIZE", 0) * kv[1].get("launches", 0)))
@@ -52,7 +57,7 @@ for k, v in list(out.items())[:12]:
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for f in sorted(glob.glob(OUT + "/pmc/m*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        k = short(r["Kernel_Name"]); agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+        k = fam(r["Kernel_Name"]); agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
 tops = sorted(agg, key=lambda k: -agg[k].get("SQ_BUSY_CYCLES", 0))[:8]
 with open(OUT + "/r02_mfma_util.md", "w") as f:
     f.write("# SQ counters per launch (rocprofv3 --pmc, own passes with --kernel-trace only), top kernels of the bench step by SQ_BUSY_CYCLES\n")

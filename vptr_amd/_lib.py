@@ -38,6 +38,7 @@ class GemmDesc(ctypes.Structure):
         ("bias_x1", c_void_p), ("bias_x2", c_void_p), ("alpha_x1", c_float), ("alpha_x2", c_float),
         ("D_planes", c_void_p),
         ("d_p16", c_int),
+        ("act_grad_src", c_void_p),
     ]
 
 
@@ -107,7 +108,7 @@ def _load():
         fn.restype = c_int
     lib.vptr_abi_version.restype = c_int
     lib.vptr_last_error.restype = ctypes.c_char_p
-    if lib.vptr_abi_version() != 3:
+    if lib.vptr_abi_version() != 4:
         raise ImportError("vptr_amd: ABI version mismatch in %s" % LIB_PATH)
     return lib
 

@@ -125,6 +125,13 @@ __device__ __forceinline__ float vptr_act(float v, int act) {
   if (act == VPTR_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
   return v;
 }
+// d act(h) / dh from the value the forward saved (GELU: the pre-activation; ReLU / LeakyReLU: pre-activation or output, same sign)
+__device__ __forceinline__ float vptr_act_grad(float h, int act) {
+  if (act == VPTR_ACT_GELU) return vptr_gelu_grad(h);
+  if (act == VPTR_ACT_RELU) return h > 0.f ? 1.f : 0.f;
+  if (act == VPTR_ACT_LRELU) return h > 0.f ? 1.f : 0.2f;
+  return 1.f;
+}
 
 // ---- wave / block reductions (wave = 64) ----------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

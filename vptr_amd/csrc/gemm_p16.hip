@@ -95,7 +95,7 @@ extern "C" int vptr_weight_planes(const vptr_wplane_entry* table_dev, const int*
 // LEAN: plain epilogue only (gemm_shared.h).  NST = 3: the instantiation for grids of at most one workgroup per CU (nothing else on
 // the CU hides a stall): three stages with the DMA two K-steps ahead, its pieces issued between the MFMA groups instead of in a
 // burst after the barrier (cache-cold 10 240 x 528 x 2112: 79.7 -> 73.1 us in tools/gemm_p16_probe).  Both chosen by the launcher.
-template <bool LEAN, int NST>
+template <int EPI, int NST>   // EPI: 0 every epilogue option, 1 lean, 2 activation gradient (gemm_shared.h)
 __global__ __launch_bounds__(GNT, NST == 3 ? 2 : 4) void vptr_gemm_p16_kernel(const vptr_gemm_desc p, const int epi_rows) {
   constexpr int NFN = 11, BN = 176;
   extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
@@ -247,17 +247,18 @@ __global__ __launch_bounds__(GNT, NST == 3 ? 2 : 4) void vptr_gemm_p16_kernel(co
   long long* const tbuf = reinterpret_cast<long long*>(p.Dpre);
   long long tme[5] = {0, 0, 0, 0, 0};
 #endif
+  constexpr bool LEAN = EPI != 0;
   if (LEAN) {
     __syncthreads();  // the last stage is still being read by slower waves
 #ifdef VPTR_P16_TIMING
-    gemm_epilogue_rows_halves_batched<NFN, true>(p, mb, acc, reinterpret_cast<float*>(p16_smem), m0, n0, wm, wn, lr, lq, tid, true, false, tme);
+    gemm_epilogue_rows_halves_batched<NFN, EPI>(p, mb, acc, reinterpret_cast<float*>(p16_smem), m0, n0, wm, wn, lr, lq, tid, true, false, tme);
 #else
-    gemm_epilogue_rows_halves_batched<NFN, true>(p, mb, acc, reinterpret_cast<float*>(p16_smem), m0, n0, wm, wn, lr, lq, tid, true, false);
+    gemm_epilogue_rows_halves_batched<NFN, EPI>(p, mb, acc, reinterpret_cast<float*>(p16_smem), m0, n0, wm, wn, lr, lq, tid, true, false);
 #endif
   } else if (NST == 3 && (epi_rows || p.d_p16) && !p.atomic && epi_vec_ok(p)) {
     // the full epilogue with its operand loads batched: affordable under this instantiation's 256-register budget
     __syncthreads();
-    gemm_epilogue_rows_halves_batched<NFN, false>(p, mb, acc, reinterpret_cast<float*>(p16_smem), m0, n0, wm, wn, lr, lq, tid, true, false);
+    gemm_epilogue_rows_halves_batched<NFN, 0>(p, mb, acc, reinterpret_cast<float*>(p16_smem), m0, n0, wm, wn, lr, lq, tid, true, false);
   } else if ((epi_rows || p.d_p16) && !p.atomic && epi_vec_ok(p)) {
     __syncthreads();
     gemm_epilogue_rows_halves<NFN>(p, mb, acc, reinterpret_cast<float*>(p16_smem), m0, n0, wm, wn, lr, lq, tid, true, false);
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(GNT, NST == 3 ? 2 : 4) void vptr_gemm_p16_kernel(co
     gemm_epilogue_serial<NFN>(p, mb, acc, m0, n0, wm, wn, lr, lq, true, p.atomic != 0);
   }
 #ifdef VPTR_P16_TIMING
-  if (LEAN && tbuf) {
+  if (EPI == 1 && tbuf) {
     __syncthreads();
     if (tid == 0) {
       tbuf[blockIdx.x * 16 + 0] = tm0; tbuf[blockIdx.x * 16 + 1] = tm1; tbuf[blockIdx.x * 16 + 2] = tm2; tbuf[blockIdx.x * 16 + 3] = wall_clock64();
@@ -517,10 +518,12 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
                "vptr_gemm(p16): a P16 output needs N, ldd multiples of 16, 64-byte aligned D and 16-byte aligned epilogue operands, no atomics");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess) {
       vptr_set_error("vptr_gemm(p16): cannot reserve %d bytes of LDS", 2 * P16_STAGE);
       return -1;
     }
@@ -539,10 +542,18 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
                     (ebits & 15) == 0 && (d.N & 3) == 0 && (d.ldd & 3) == 0 && (d.ldr & 3) == 0;
   const bool lone = tiles <= vptr_cu_count() && (p16_epi_rows_flag() & 16) == 0;   // at most one workgroup per CU
   const int rows = lean ? 1 : (p16_epi_rows_flag() & 2);
-  if (lean && lone) vptr_gemm_p16_kernel<true, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, rows);
-  else if (lean) vptr_gemm_p16_kernel<true, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, rows);
-  else if (lone) vptr_gemm_p16_kernel<false, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, rows);
-  else vptr_gemm_p16_kernel<false, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, rows);
+  if (d.act_grad_src) {   // activation-gradient epilogue: its own instantiation, no fallback
+    VPTR_CHECK(!d.colscale && !d.Dpre && !d.rowscale && !d.residual && !d.bias && !d.act_after && !d.atomic && d.batch == 1 && d.ksegs == 1 &&
+                   d.act != VPTR_ACT_NONE && ((ebits | reinterpret_cast<uintptr_t>(d.act_grad_src)) & 15) == 0 && (d.N & 3) == 0 && (d.ldd & 3) == 0,
+               "vptr_gemm(p16): act_grad_src combines with alpha / dropout / P16 output only and needs 16-byte aligned operands, N, ldd multiples of 4");
+    if (lone) vptr_gemm_p16_kernel<2, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, 1);
+    else vptr_gemm_p16_kernel<2, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, 1);
+    return 0;
+  }
+  if (lean && lone) vptr_gemm_p16_kernel<1, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, rows);
+  else if (lean) vptr_gemm_p16_kernel<1, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, rows);
+  else if (lone) vptr_gemm_p16_kernel<0, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, rows);
+  else vptr_gemm_p16_kernel<0, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, rows);
   return 0;
 }
 

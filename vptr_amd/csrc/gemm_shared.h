@@ -319,20 +319,21 @@ __device__ __forceinline__ void gemm_epilogue_rows_halves(const vptr_gemm_desc& 
 // LEAN: the instantiation for the plain launches (bias, alpha, residual, fp32 or P16 output only -- most launches of a step): the
 // other options are compiled out, which keeps the code a workgroup walks through after its K loop short (the full epilogue is
 // ~20 k instructions of mostly skipped branches; measured +9 us on a 25 us K = 528 GEMM).
-template <int NFN, bool LEAN>
+template <int NFN, int EPI>   // EPI: 0 every option, 1 lean (bias / alpha / residual), 2 activation gradient (desc.act_grad_src)
 __device__ __forceinline__ void gemm_epilogue_rows_halves_batched(const vptr_gemm_desc& p, const Member& mb, f32x4 (&acc)[2][(NFN + 1) / 2], float* sE,
                                                           const int m0, const int n0, const int wm, const int wn, const int lr, const int lq,
                                                           const int tid, const bool first_split, const bool use_atomic_in, long long* tm = nullptr) {
   constexpr int NFW = (NFN + 1) / 2, BN = 16 * NFN, PITCH = BN + 4, C4 = BN / 4, HR = GBM / 2, NPIECE = HR * C4;
-  const bool has_res = p.residual && first_split;
-  const bool has_bias = mb.bias && first_split;
+  constexpr bool LEAN = EPI != 0, GRAD = EPI == 2;
+  const bool has_res = !GRAD && p.residual && first_split;
+  const bool has_bias = !GRAD && mb.bias && first_split;
   const bool use_atomic = !LEAN && use_atomic_in;
   const float* const colscale = LEAN ? nullptr : p.colscale;
   float* const Dpre = LEAN ? nullptr : p.Dpre;
   const float* const rowscale = LEAN ? nullptr : p.rowscale;
   const auto D_planes = LEAN ? decltype(p.D_planes)(nullptr) : p.D_planes;
-  const int act = LEAN ? VPTR_ACT_NONE : p.act;
-  const float dropout_p = LEAN ? 0.f : p.dropout_p;
+  const int act = EPI == 1 ? VPTR_ACT_NONE : p.act;
+  const float dropout_p = EPI == 1 ? 0.f : p.dropout_p;
   const bool act_after = !LEAN && p.act_after;
   uint64_t seed = 0;
   if (dropout_p > 0.f) seed = *p.seed_dev;
@@ -363,6 +364,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_halves_batched(const vptr_gem
       const bool ok = piece < NPIECE && row < p.M && col < p.N;
       res[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (has_res && ok) res[it] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)row * p.ldr + col);
+      if (GRAD && ok) res[it] = *reinterpret_cast<const f32x4*>(p.act_grad_src + (int64_t)row * p.ldd + col);   // the saved pre-activations
       rsv[it] = (rowscale && ok) ? rowscale[(row / p.rs_div) % p.rs_mod] : 1.f;
     }
     if ((wm >> 1) == h) {  // wave-uniform: the four waves of this row half spill their fragments
@@ -393,9 +395,9 @@ __device__ __forceinline__ void gemm_epilogue_rows_halves_batched(const vptr_gem
         const float rs = rsv[it];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float t = vptr_act(v[e], act) * rs;
+          float t = GRAD ? v[e] * vptr_act_grad(res[it][e], act) : vptr_act(v[e], act) * rs;
           if (dropout_p > 0.f) t *= vptr_drop_scale(seed, p.site, (uint64_t)row * (uint64_t)p.N + col + e, dropout_p);
-          t += res[it][e];
+          if (!GRAD) t += res[it][e];
           if (act_after) t = t > 0.f ? t : 0.f;
           v[e] = t;
         }

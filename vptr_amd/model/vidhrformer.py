@@ -319,6 +319,9 @@ class VidHRFormerBlockEnc(nn.Module):
         x = _mha_tokens(self.temporal_MHSA, uq, uq, u, xr, g.N, g.T, g.T, HW, self.far, p, s + 3, out_dropout=p, out_site=s + 4,
                         merge_v_grad=not tpos.requires_grad, x_p16=P)
         u, xr = ops.layernorm(x, self.norm4.weight, self.norm4.bias, eps=self.norm4.eps, passthrough=True, out_p16=P)
+        if P and ops.config.fused_mlp:   # one autograd node; linear2's input gradient applies GELU' and the dropout mask in its epilogue
+            return ops.mlp(u, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, residual=xr, dropout_p=p,
+                           site1=s + 5, site2=s + 6, x_p16=True)
         h = ops.linear(u, self.linear1.weight, self.linear1.bias, act=ops.ACT_GELU, dropout_p=p, site=s + 5, x_p16=P, out_p16=P)
         return ops.linear(h, self.linear2.weight, self.linear2.bias, residual=xr, dropout_p=p, site=s + 6, x_p16=P)
 
@@ -397,8 +400,12 @@ class VidHRFormerBlockDecNAR(nn.Module):
         x = _mha_tokens(self.temporal_MHSA, uq, uq, u, xr, g.N, T2, T2, HW, False, p, s + 3, out_dropout=p, out_site=s + 4,
                         merge_v_grad=not tpos_f.requires_grad, x_p16=P)
         u, xr = ops.layernorm(x, self.norm4.weight, self.norm4.bias, eps=self.norm4.eps, passthrough=True, out_p16=P)
-        h = ops.linear(u, self.linear1.weight, self.linear1.bias, act=ops.ACT_GELU, dropout_p=p, site=s + 5, x_p16=P, out_p16=P)
-        x = ops.linear(h, self.linear2.weight, self.linear2.bias, residual=xr, dropout_p=p, site=s + 6, x_p16=P)
+        if P and ops.config.fused_mlp:   # as in VidHRFormerBlockEnc.forward_tokens
+            x = ops.mlp(u, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, residual=xr, dropout_p=p,
+                        site1=s + 5, site2=s + 6, x_p16=True)
+        else:
+            h = ops.linear(u, self.linear1.weight, self.linear1.bias, act=ops.ACT_GELU, dropout_p=p, site=s + 5, x_p16=P, out_p16=P)
+            x = ops.linear(h, self.linear2.weight, self.linear2.bias, residual=xr, dropout_p=p, site=s + 6, x_p16=P)
         # encoder-decoder attention; the reference applies drop_path1 to a (T2, N*HW, C) tensor, i.e. along TIME
         # (VidHRFormer_modules.py:204) -- reproduced: scale indexed by t = (row // HW) % T2
         if self.TSLMA_flag:

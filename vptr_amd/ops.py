@@ -35,6 +35,8 @@ class _Config:
     # weight-gradient chunks on a side stream during backward (see _flush_wgrads_side); 0 = one grouped launch at the end
     wgrad_async = os.environ.get("VPTR_WGRAD_ASYNC", "0") == "1"
     wgrad_chunk_tiles = int(os.environ.get("VPTR_WGRAD_CHUNK", "600"))
+    # the transformer MLP as one autograd node (ops.mlp) instead of two ops.linear nodes; 0 = A/B switch
+    fused_mlp = os.environ.get("VPTR_FUSED_MLP", "1") != "0"
 
 
 config = _Config()
@@ -103,7 +105,7 @@ def _c(t):
 def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None, colscale=None, alpha=1.0, act=ACT_NONE,
              Dpre=None, rowscale=None, rs_div=1, rs_mod=1, dropout_p=0.0, site=0, residual=None, act_after=False,
              atomic=False, split_k=1, conv=None, precision=None, seed=None, a_rowsum=None, batch_extra=None, kseg_extra=None,
-             planes_out=None, d_p16=False):
+             planes_out=None, d_p16=False, act_grad_src=None):
     """One vptr_gemm launch.  batch_extra = [(A, B, D, bias, alpha), ...] adds up to two same-shaped independent problems to
     the grid; kseg_extra = [(A, B), ...] adds up to two K-segments accumulated into the same D (include/vptr_hip.h)."""
     d = GemmDesc()
@@ -120,6 +122,7 @@ def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None
     d.a_rowsum = ptr(a_rowsum)
     d.D_planes = ptr(planes_out)
     d.d_p16 = int(bool(d_p16))
+    d.act_grad_src = ptr(act_grad_src)
     d.A, d.B, d.D, d.Dpre = ptr(A), ptr(B), ptr(D), ptr(Dpre)
     d.lda = lda if lda is not None else (A.stride(0) if a_mode != 2 else 0)
     d.ldb = ldb if ldb is not None else B.stride(0)
@@ -724,6 +727,74 @@ def linear(x, W, b=None, residual=None, alpha=1.0, act=ACT_NONE, rowscale=None, 
            x_p16=False, out_p16=False, dy_p16=False):
     return _LinearFn_apply(x, W, b, residual, rowscale, float(alpha), int(act), int(rs_div), int(rs_mod), float(dropout_p),
                            int(site), bool(x_p16), bool(out_p16), bool(dy_p16))
+
+
+class _MlpFn(torch.autograd.Function):
+    """y = dropout(linear2(dropout(GELU(linear1(x))))) + residual -- the transformer MLP (VidHRFormer_modules.py:87-89, 190-192) as ONE
+    autograd node on P16 operands.  Forward: two GEMM launches (GELU + saved pre-activation + dropout + P16 output in the first
+    epilogue; dropout + residual in the second).  Backward: g2 = dy * mask2 (one pass, P16); dh never exists: linear2's input-gradient
+    GEMM applies GELU'(pre) and mask1 in its epilogue (desc.act_grad_src) and writes g1 as P16; dx = g1 . W1; both weight (+ bias)
+    gradients go to the grouped end-of-backward launch."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, residual, p, site1, site2, x_p16):
+        _lib.require_cuda(x, W1, W2)
+        x, W1, W2 = _c(x), _c(W1), _c(W2)
+        M, C = x.shape
+        Fh, N = W1.shape[0], W2.shape[0]
+        if not p16_ok(C, Fh, N):
+            raise RuntimeError("mlp: P16 operands need every width to be a multiple of 16 and the split-bf16 precision")
+        dev = x.device
+        xs = x if x_p16 else to_p16(x)
+        ctx.seed = seed_tensor(dev) if p > 0 else None
+        h = torch.empty((M, Fh), device=dev, dtype=torch.float32)      # P16
+        pre = torch.empty((M, Fh), device=dev, dtype=torch.float32)
+        W1p, ld1, _, _ = weight_planes_for(W1)
+        gemm_raw(xs, W1p, h, M, Fh, C, A_P16, B_P16, lda=C, ldb=ld1, bias=b1, act=ACT_GELU, Dpre=pre, dropout_p=p, site=site1, seed=ctx.seed,
+                 d_p16=True)
+        y = torch.empty((M, N), device=dev, dtype=torch.float32)
+        res = _c(residual) if residual is not None else None
+        W2p, ld2, _, _ = weight_planes_for(W2)
+        gemm_raw(h, W2p, y, M, N, Fh, A_P16, B_P16, lda=Fh, ldb=ld2, bias=b2, dropout_p=p, site=site2, residual=res, seed=ctx.seed)
+        ctx.save_for_backward(xs, W1, W2, h, pre)
+        ctx.cfg = (p, site1, site2, residual is not None)
+        ctx.b1_ref, ctx.b2_ref = b1.detach(), b2.detach()   # only their addresses are used (flat gradient slab lookup)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, W1, W2, h, pre = ctx.saved_tensors
+        p, site1, site2, has_res = ctx.cfg
+        dy = _c(dy)
+        M, C = xs.shape
+        Fh, N = W1.shape[0], W2.shape[0]
+        if p > 0:
+            g2 = torch.empty_like(dy)
+            check(lib.vptr_act_bwd(ptr(dy), None, ptr(g2), M, N, ACT_NONE, 1.0, None, 1, 1, p, ptr(ctx.seed), site2, 1, stream()), "vptr_act_bwd")
+        else:
+            g2 = to_p16(dy)
+        g1 = torch.empty((M, Fh), device=dy.device, dtype=torch.float32)   # P16: dL/d(linear1 output), never materialised as fp32 dh
+        _, _, W2T, ld2t = weight_planes_for(W2)
+        gemm_raw(g2, W2T, g1, M, Fh, N, A_P16, B_P16, lda=N, ldb=ld2t, act=ACT_GELU, act_grad_src=pre, dropout_p=p, site=site1, seed=ctx.seed,
+                 d_p16=True)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, C), device=dy.device, dtype=torch.float32)
+            _, _, W1T, ld1t = weight_planes_for(W1)
+            gemm_raw(g1, W1T, dx, M, C, Fh, A_P16, B_P16, lda=Fh, ldb=ld1t)
+        dW2, db2 = _linear_param_grads(g2, h, W2, ctx.b2_ref, ctx.needs_input_grad[3], ctx.needs_input_grad[4], 1.0, p16=True)
+        dW1, db1 = _linear_param_grads(g1, xs, W1, ctx.b1_ref, ctx.needs_input_grad[1], ctx.needs_input_grad[2], 1.0, p16=True)
+        dres = dy if (has_res and ctx.needs_input_grad[5]) else None
+        return dx, dW1, db1, dW2, db2, dres, None, None, None, None
+
+
+_MlpFn_apply = _direct_apply(_MlpFn)
+
+
+def mlp(x, W1, b1, W2, b2, residual=None, dropout_p=0.0, site1=0, site2=0, x_p16=False):
+    """The transformer MLP linear2(dropout(GELU(linear1(x)))) (+ dropout, + residual) as one autograd node (see _MlpFn); needs
+    P16-eligible widths -- callers fall back to two `linear` calls otherwise."""
+    return _MlpFn_apply(x, W1, b1, W2, b2, residual, float(dropout_p), int(site1), int(site2), bool(x_p16))
 
 
 # ------------------------------------------------------------------------------------------------------------------
