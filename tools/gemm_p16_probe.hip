@@ -69,7 +69,7 @@ __global__ void tr_test(const int* __restrict__ addr_el, short* __restrict__ out
 
 // ------------------------------------------------------------------------------------------------------------------------
 template <int NW, int PROB, int NST = 2>  // NW waves: 8 -> 4x2 waves of 32x96, 4 -> 2x2 waves of 64x96; NST stages (3: DMA two K-steps ahead, one workgroup per CU)
-__global__ __launch_bounds__(NW * 64, NST == 3 ? 2 : (NW == 4 ? 2 : 4)) void gemm_nt(const unsigned char* __restrict__ A, const unsigned char* __restrict__ B,
+__global__ __launch_bounds__(NW * 64, NST >= 3 ? 2 : (NW == 4 ? 2 : 4)) void gemm_nt(const unsigned char* __restrict__ A, const unsigned char* __restrict__ B,
                                                                      float* __restrict__ D, int M, int N, int K, int64_t strideA, int64_t strideB,
                                                                      int64_t strideD, int elim) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -168,19 +168,21 @@ __global__ __launch_bounds__(NW * 64, NST == 3 ? 2 : (NW == 4 ? 2 : 4)) void gem
     pf_ptr = r < 128 ? A + (int64_t)min(m0 + r, M - 1) * pitch : B + (int64_t)min(n0 + r - 128, N - 1) * pitch;
   }
   issue(0, 0);
-  if (NST == 3 && nk > 1) issue(1, 1);
+  if (NST >= 3 && nk > 1) issue(1, 1);
+  if (NST >= 4 && nk > 2) issue(2, 2);
   for (int kt = 0; kt < nk; ++kt) {
-    if (NST == 3 && kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | PPW);   // vmcnt(PPW): step kt landed, step kt + 1 may still fly
+    if (NST == 4 && kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | (2 * PPW));   // steps kt + 1, kt + 2 may still fly
+    else if (NST >= 3 && kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | PPW);   // vmcnt(PPW): step kt landed, step kt + 1 may still fly
     else if (PROB == 6 && kt >= 1 && kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | 1);   // the warm-up load issued after this step's DMA may still fly
     else __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
-    if (NST == 3) {
-      if (PROB != 4 && kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
+    if (NST >= 3) {
+      if (PROB != 4 && kt + NST - 1 < nk) issue(kt + NST - 1, (kt + NST - 1) % NST);
     } else if (PROB != 4 && kt + 1 < nk && !(elim == 1 && kt > 0)) issue(kt + 1, (kt + 1) & 1);   // elim 1: no DMA after the second step
     if (PROB == 6 && kt + 2 < nk) {
       if (lane < 38) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pf_ptr + (int64_t)(kt + 2) * 128) : "memory");
     }
-    const unsigned char* st = smem + (NST == 3 ? kt % 3 : (kt & 1)) * STAGE_B;
+    const unsigned char* st = smem + (NST >= 3 ? kt % NST : (kt & 1)) * STAGE_B;
     bf16x8 ah[MI], al[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(NW * 64, NST == 3 ? 2 : (NW == 4 ? 2 : 4)) void gem
           bh[(ni + 1) & 1] = *reinterpret_cast<const bf16x8*>(st + offBh[ni + 1]);
           bl[(ni + 1) & 1] = *reinterpret_cast<const bf16x8*>(st + offBl[ni + 1]);
         }
-        if (PROB == 4 && NW == 8 && ni < PPW && kt + NST - 1 < nk) issue1(kt + NST - 1, NST == 3 ? (kt + 2) % 3 : (kt + 1) & 1, ni);
+        if (PROB == 4 && NW == 8 && ni < PPW && kt + NST - 1 < nk) issue1(kt + NST - 1, (kt + NST - 1) % NST, ni);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
@@ -504,8 +506,8 @@ static int run_nt(int M, int N, int K, int P) {
   for (int var = 1; var < 8; ++var) {
     const int nw = var == 0 || var == 4 ? 4 : 8;
     auto kern = var == 0 ? gemm_nt<4, 0> : (var == 1 ? gemm_nt<8, 0> : (var == 2 ? gemm_nt<8, 1> : (var == 3 ? gemm_nt<8, 2> : (var == 4 ? gemm_nt64 : (var == 5 ? gemm_nt<8, 3> :
-                (var == 6 ? gemm_nt<8, 5> : gemm_nt<8, 6>))))));   // map5: scalar-base DMA addressing; map6: L2 warm-up loads   // map5 = map2 with 3 stages, map6 = map4 (prefetch) + DMA pieces between the MFMA groups
-    const int lds = var == 4 ? 64 * 1024 : 2 * STAGE_B;   // map5: interleaved DMA + 3 stages
+                (var == 6 ? gemm_nt<8, 4, 3> : gemm_nt<8, 4, 4>))))));   // map5: interleaved DMA, 3 stages; map6: 4 stages   // map5 = map2 with 3 stages, map6 = map4 (prefetch) + DMA pieces between the MFMA groups
+    const int lds = var == 4 ? 64 * 1024 : (var == 6 ? 3 : (var == 7 ? 4 : 2)) * STAGE_B;   // map5: interleaved DMA + 3 stages
     const int ntile = var == 4 ? ((M + 63) / 64) * ((N + BN - 1) / BN) : tiles;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     CK(hipMemset(D, 0, sd * P));
