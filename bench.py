@@ -229,14 +229,19 @@ def hbm_roofline():
 
 
 def _time_steps(step, warm=2, timed=3):
+    """median of `timed` individually synchronised steps (a one-off allocator stall in a fresh configuration would otherwise
+    dominate a 3-step mean: one default run once reported 131 ms for a 54 ms step)"""
     for _ in range(warm):
         step()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(timed):
+        t0 = time.perf_counter()
         step()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / timed * 1e3
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
 
 
 def other_configs(dev, enc, T_k64, trainer, dropout):
