@@ -116,6 +116,12 @@ typedef struct vptr_gemm_desc {
      consumer was act(.) + dropout (linear2's dX fused with linear1's activation backward, VidHRFormer_modules.py:89,192), written
      fp32 or P16.  Not combinable with bias / colscale / Dpre / rowscale / residual / act_after / atomic / batch / ksegs. */
   const float* act_grad_src;
+  /* a_mode = VPTR_A_P16 only: per-frame statistics of the OUTPUT for the LayerNorm((F,H,W)) that consumes it (MlpDWBN,
+     VidHRFormer_modules.py:397-419): frame_stats[2 f] += sum, frame_stats[2 f + 1] += sum of squares of the rows
+     [f * frame_rows, (f + 1) * frame_rows) of D (fp32 atomics into a zeroed [M / frame_rows][2] buffer; frame_rows % 64 == 0).
+     vptr_norm_act_fwd(raw_stats = ...) turns them into mean / rstd -- no separate statistics pass over D. */
+  float* frame_stats;
+  int frame_rows;
 } vptr_gemm_desc;
 
 int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream);
@@ -253,10 +259,14 @@ int vptr_groupstats(const float* x, float* mean, float* var, float* rstd, float 
  * per_col != 0: stats indexed by column (BN), affine [F];
  * per_col == 0: stats indexed by row / HW (LN over (F,H,W)), affine given channel-last as [HW, F].
  * rowscale (DropPath, VidHRFormer_modules.py:563-575) and residual may be null. */
-int vptr_norm_act_fwd(const float* x, const float* mean, const float* rstd, const float* w, const float* b, float* y,
+/* raw_stats != NULL (per_col == 0 only): [frames][2] per-frame sum / sum of squares of x as accumulated by its producer
+ * (vptr_gemm_desc::frame_stats, vptr_dwconv3x3_fwd); the kernel derives mean / rstd from them (eps) and WRITES mean[], rstd[]
+ * for the backward pass -- otherwise mean[], rstd[] are inputs. */
+int vptr_norm_act_fwd(const float* x, float* mean, float* rstd, const float* w, const float* b, float* y,
                       int rows, int F, int HW, int per_col, int act, float dropout_p, const uint64_t* seed_dev,
                       uint32_t site, const float* rowscale, int rs_div, int rs_mod, const float* residual,
-                      int p16 /* != 0: y is written in the P16 plane format */, vptr_stream_t stream);
+                      int p16 /* != 0: y is written in the P16 plane format */, const float* raw_stats, float eps,
+                      vptr_stream_t stream);
 /* backward: dx written; dw/db ACCUMULATED (same layout as w/b).  scratch (initialised inside): per_col: >= 2*F floats;
  * per-frame: >= 2*frames*(1 + 4*ceil(HW*F/1024)) floats, frames = rows/HW (frame sums + per-wave partials).
  * const_stats != 0: mean/rstd are constants (BatchNorm in eval mode) -> no statistics terms in dx. */
@@ -265,8 +275,10 @@ int vptr_norm_act_bwd(const float* dy, const float* x, const float* mean, const 
                       int const_stats, float dropout_p, const uint64_t* seed_dev, uint32_t site, const float* rowscale,
                       int rs_div, int rs_mod, int p16 /* != 0: dx is written in the P16 plane format */, vptr_stream_t stream);
 /* depthwise 3x3, pad 1 (VidHRFormer_modules.py:404-409,433); w given tap-major [9, F]. */
+/* frame_stats (may be NULL): [frames][2] zeroed buffer that receives each frame's sum / sum of squares of y (see
+ * vptr_norm_act_fwd raw_stats); needs W even and (W/2)*(F/4) % 64 == 0 */
 int vptr_dwconv3x3_fwd(const float* x, const float* w9, const float* b, float* y, int frames, int H, int W, int F,
-                       vptr_stream_t stream);
+                       float* frame_stats, vptr_stream_t stream);
 int vptr_dwconv3x3_bwd(const float* dy, const float* x, const float* w9, float* dx, float* dw9, float* db, int frames,
                        int H, int W, int F, vptr_stream_t stream);
 

@@ -35,6 +35,8 @@ def test_graph_replays_match_eager_steps(dev, dropout, monkeypatch):
     from vptr_amd import ops
     from vptr_amd.train import NARTrainer
     monkeypatch.setattr(V, "_droppath_scale", lambda p, training, count, device: None)
+    if dropout == 0.0:   # the 2e-4 comparison needs a reproducible forward: conv-FFN statistics on the separate deterministic pass (the
+        monkeypatch.setattr(ops.config, "fused_frame_stats", False)   # atomics-accumulated default is covered by the dropout 0.1 case)
     z = load("step_tiny")
     cfg, meta = jload(z, "cfg"), jload(z, "meta")
     nstep = 5

@@ -162,3 +162,33 @@ def test_mlp_autograd_p16(ops, dev, p):
     assert rel(y, yr) < TOL3
     for got, ref in zip((x, W1, b1, W2, b2, r), refs):
         assert rel(got.grad, ref.grad) < 2 * TOL3
+
+
+def test_frame_stats_from_producers(ops, dev):
+    """LayerNorm((F,H,W)) statistics accumulated by the producers (GEMM epilogue: desc.frame_stats; depthwise kernel) == the separate
+    statistics pass: sums against fp64, and norm_act(raw_stats=...) against norm_act on its own statistics (forward and gradients)"""
+    frames, HW, C, F_ = 12, 64, 48, 192
+    rows = frames * HW
+    x, W, b = rn((rows, C), 1).to(dev), rn((F_, C), 2, C ** -0.5).to(dev), rn((F_,), 3).to(dev)
+    assert ops.frame_stats_ok(rows, HW, F_, 8)
+    st = ops.frame_stats_buffer(frames, dev)
+    y = ops.linear(x, W, b, frame_stats=st, frame_rows=HW)
+    yd = y.double().view(frames, -1)
+    assert float(((st[:, 1].double() - (yd ** 2).sum(1)).abs() / (yd ** 2).sum(1)).max()) < 1e-6
+    assert float((st[:, 0].double() - yd.sum(1)).abs().max()) < 1e-6 * float(yd.abs().sum(1).max())
+    st2 = ops.frame_stats_buffer(frames, dev)
+    dw = rn((F_, 1, 3, 3), 4).to(dev)
+    y2 = ops.dwconv3x3(y, dw, b, frames, 8, 8, frame_stats=st2)
+    y2d = y2.double().view(frames, -1)
+    assert float(((st2[:, 1].double() - (y2d ** 2).sum(1)).abs() / (y2d ** 2).sum(1)).max()) < 1e-6
+    w, bb = rn((HW, F_), 5).to(dev).requires_grad_(True), rn((HW, F_), 6).to(dev).requires_grad_(True)
+    outs = []
+    for raw in (st2, None):
+        xin = y2.detach().clone().requires_grad_(True)
+        o = ops.norm_act(xin, w, bb, "ln", HW, True, raw_stats=raw)
+        o.square().sum().backward()
+        outs.append((o.detach(), xin.grad.clone(), w.grad.clone()))
+        w.grad = None
+        bb.grad = None
+    for a, r in zip(outs[0], outs[1]):
+        assert rel(a, r) < 1e-5

@@ -39,6 +39,7 @@ class GemmDesc(ctypes.Structure):
         ("D_planes", c_void_p),
         ("d_p16", c_int),
         ("act_grad_src", c_void_p),
+        ("frame_stats", c_void_p), ("frame_rows", c_int),
     ]
 
 
@@ -71,9 +72,9 @@ SIGNATURES = {
     "vptr_colstats": [P, P, P, P, F, P, I, I, P],
     "vptr_colstats_running": [P, P, P, P, F, P, I, I, P, P, F, P, P],
     "vptr_groupstats": [P, P, P, P, F, I, I, P],
-    "vptr_norm_act_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, P, U, P, I, I, P, I, P],
+    "vptr_norm_act_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, P, U, P, I, I, P, I, P, F, P],
     "vptr_norm_act_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, P, I, I, I, P],
-    "vptr_dwconv3x3_fwd": [P, P, P, P, I, I, I, I, P],
+    "vptr_dwconv3x3_fwd": [P, P, P, P, I, I, I, I, P, P],
     "vptr_dwconv3x3_bwd": [P, P, P, P, P, P, I, I, I, I, P],
     "vptr_nchw_to_tokens": [P, P, I, I, I, P],
     "vptr_tokens_to_nchw": [P, P, I, I, I, I, P],
@@ -108,7 +109,7 @@ def _load():
         fn.restype = c_int
     lib.vptr_abi_version.restype = c_int
     lib.vptr_last_error.restype = ctypes.c_char_p
-    if lib.vptr_abi_version() != 4:
+    if lib.vptr_abi_version() != 5:
         raise ImportError("vptr_amd: ABI version mismatch in %s" % LIB_PATH)
     return lib
 

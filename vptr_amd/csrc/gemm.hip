@@ -865,7 +865,7 @@ extern "C" int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream) {
     return 0;
   }
   VPTR_CHECK(!d.d_p16, "vptr_gemm: d_p16 is an output format of the P16 kernels only");
-  VPTR_CHECK(!d.act_grad_src, "vptr_gemm: act_grad_src is an epilogue of the P16 kernels only");
+  VPTR_CHECK(!d.act_grad_src && !d.frame_stats, "vptr_gemm: act_grad_src / frame_stats are epilogues of the P16 kernels only");
   VPTR_CHECK(d.a_mode != 4, "vptr_gemm: a_mode 4 (k-contiguous 32-wide planes) was replaced by VPTR_A_P16");
   if (d.a_mode == VPTR_A_CONV_PLANES) {
     if (d.alpha == 0.f) d.alpha = 1.f;

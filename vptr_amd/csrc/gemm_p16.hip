@@ -542,6 +542,9 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
                     (ebits & 15) == 0 && (d.N & 3) == 0 && (d.ldd & 3) == 0 && (d.ldr & 3) == 0;
   const bool lone = tiles <= vptr_cu_count() && (p16_epi_rows_flag() & 16) == 0;   // at most one workgroup per CU
   const int rows = lean ? 1 : (p16_epi_rows_flag() & 2);
+  if (d.frame_stats)   // served by the lean epilogue only: no fallback
+    VPTR_CHECK(d.frame_rows >= 64 && d.frame_rows % 64 == 0 && d.M % 64 == 0 && !d.act_grad_src && lean && d.batch == 1,
+               "vptr_gemm(p16): frame_stats needs frame_rows %% 64 == 0, M %% 64 == 0 and a plain launch (bias / alpha / residual only)");
   if (d.act_grad_src) {   // activation-gradient epilogue: its own instantiation, no fallback
     VPTR_CHECK(!d.colscale && !d.Dpre && !d.rowscale && !d.residual && !d.bias && !d.act_after && !d.atomic && d.batch == 1 && d.ksegs == 1 &&
                    d.act != VPTR_ACT_NONE && ((ebits | reinterpret_cast<uintptr_t>(d.act_grad_src)) & 15) == 0 && (d.N & 3) == 0 && (d.ldd & 3) == 0,

@@ -356,6 +356,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_halves_batched(const vptr_gem
   for (int h = 0; h < 2; ++h) {
     f32x4 res[NIT];
     float rsv[NIT];
+    float ssum = 0.f, ssq = 0.f;   // desc.frame_stats: sum / sum of squares of this thread's outputs in this row half
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int piece = it * GNT + tid;
@@ -401,6 +402,10 @@ __device__ __forceinline__ void gemm_epilogue_rows_halves_batched(const vptr_gem
           if (act_after) t = t > 0.f ? t : 0.f;
           v[e] = t;
         }
+        if (!GRAD && p.frame_stats) {
+          ssum += (v[0] + v[1]) + (v[2] + v[3]);
+          ssq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
         if (D_planes) {  // the consumer's operand format straight from the producer: hi | lo of this row's 32-channel block
           uint32_t hi[2], lo[2];
           split2(v[0], v[1], hi[0], lo[0]);
@@ -420,6 +425,20 @@ __device__ __forceinline__ void gemm_epilogue_rows_halves_batched(const vptr_gem
             *reinterpret_cast<f32x4*>(dst) = v;
           }
         }
+      }
+    }
+    if (!GRAD && p.frame_stats) {   // kernel-uniform: the 64 rows of this half lie in one frame (frame_rows % 64 == 0)
+      const float S = wave_sum(ssum), Q = wave_sum(ssq);
+      float* red = sE + HR * PITCH;   // behind the half tile, inside the K loop's stages
+      if ((tid & 63) == 0) { red[2 * (tid >> 6)] = S; red[2 * (tid >> 6) + 1] = Q; }
+      __syncthreads();
+      if (tid == 0 && m0 + h * HR < p.M) {
+        float s8 = 0.f, q8 = 0.f;
+#pragma unroll
+        for (int w = 0; w < GNT / 64; ++w) { s8 += red[2 * w]; q8 += red[2 * w + 1]; }
+        const int fr = (m0 + h * HR) / p.frame_rows;
+        unsafeAtomicAdd(p.frame_stats + 2 * fr, s8);
+        unsafeAtomicAdd(p.frame_stats + 2 * fr + 1, q8);
       }
     }
 #ifdef VPTR_P16_TIMING

@@ -509,10 +509,13 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const float* __restri
                                                            const float* __restrict__ b, float* __restrict__ y, int rows,
                                                            int F4, int HW, int act, float p, const uint64_t* seed_dev,
                                                            uint32_t site, const float* __restrict__ rowscale, int rs_div,
-                                                           int rs_mod, const float* __restrict__ residual, int p16) {
+                                                           int rs_mod, const float* __restrict__ residual, int p16,
+                                                           const float* __restrict__ raw_stats, float* __restrict__ mean_out,
+                                                           float* __restrict__ rstd_out, float eps) {
   const int64_t total = (int64_t)rows * F4;
   uint64_t seed = 0;
   if (p > 0.f) seed = *seed_dev;
+  const float inv_n = 1.f / ((float)HW * (float)(F4 * 4));
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int row = (int)(i / F4), c4 = (int)(i - (int64_t)row * F4);
     const float4 v = reinterpret_cast<const float4*>(x)[i];
@@ -524,7 +527,15 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const float* __restri
       bb = reinterpret_cast<const float4*>(b)[c4];
     } else {
       const int f = row / HW, hw = row - f * HW;
-      const float m = mean[f], r = rstd[f];
+      float m, r;
+      if (raw_stats) {   // per-frame sum / sum of squares accumulated by the PRODUCER's epilogue (vptr_gemm frame_stats, vptr_dwconv3x3_fwd)
+        m = raw_stats[2 * f] * inv_n;
+        r = rsqrtf(fmaxf(raw_stats[2 * f + 1] * inv_n - m * m, 0.f) + eps);
+        if (hw == 0 && c4 == 0) { mean_out[f] = m; rstd_out[f] = r; }   // kept for the backward pass
+      } else {
+        m = mean[f];
+        r = rstd[f];
+      }
       mu = make_float4(m, m, m, m);
       rs = make_float4(r, r, r, r);
       ww = reinterpret_cast<const float4*>(w)[(int64_t)hw * F4 + c4];
@@ -553,10 +564,11 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const float* __restri
   }
 }
 
-extern "C" int vptr_norm_act_fwd(const float* x, const float* mean, const float* rstd, const float* w, const float* b,
+extern "C" int vptr_norm_act_fwd(const float* x, float* mean, float* rstd, const float* w, const float* b,
                                  float* y, int rows, int F, int HW, int per_col, int act, float dropout_p,
                                  const uint64_t* seed_dev, uint32_t site, const float* rowscale, int rs_div, int rs_mod,
-                                 const float* residual, int p16, vptr_stream_t stream) {
+                                 const float* residual, int p16, const float* raw_stats, float eps, vptr_stream_t stream) {
+  if (raw_stats) VPTR_CHECK(!per_col && mean && rstd, "norm_act_fwd: raw_stats (per-frame sums) belong to the LayerNorm((F,H,W)) mode and need mean / rstd outputs");
   VPTR_CHECK(rows > 0 && F > 0 && F % 4 == 0 && HW >= 1, "norm_act_fwd: bad arguments");
   if (p16) VPTR_CHECK(F % 16 == 0 && (reinterpret_cast<uintptr_t>(y) & 63) == 0, "norm_act_fwd: a P16 output needs F %% 16 == 0 and a 64-byte aligned y");
   if (!per_col) VPTR_CHECK(rows % HW == 0, "norm_act_fwd: rows must be a multiple of HW");
@@ -565,8 +577,8 @@ extern "C" int vptr_norm_act_fwd(const float* x, const float* mean, const float*
   const int blocks = (int)hmin64((total + 255) / 256, 8192);
   hipStream_t st = (hipStream_t)stream;
   if (rowscale) VPTR_CHECK(rs_div >= 1 && rs_mod >= 1, "norm_act_fwd: rowscale needs rs_div, rs_mod >= 1");
-  if (per_col) norm_act_fwd_kernel<true><<<blocks, 256, 0, st>>>(x, mean, rstd, w, b, y, rows, F / 4, HW, act, dropout_p, seed_dev, site, rowscale, rs_div, rs_mod, residual, p16);
-  else norm_act_fwd_kernel<false><<<blocks, 256, 0, st>>>(x, mean, rstd, w, b, y, rows, F / 4, HW, act, dropout_p, seed_dev, site, rowscale, rs_div, rs_mod, residual, p16);
+  if (per_col) norm_act_fwd_kernel<true><<<blocks, 256, 0, st>>>(x, mean, rstd, w, b, y, rows, F / 4, HW, act, dropout_p, seed_dev, site, rowscale, rs_div, rs_mod, residual, p16, nullptr, nullptr, nullptr, eps);
+  else norm_act_fwd_kernel<false><<<blocks, 256, 0, st>>>(x, raw_stats ? nullptr : mean, raw_stats ? nullptr : rstd, w, b, y, rows, F / 4, HW, act, dropout_p, seed_dev, site, rowscale, rs_div, rs_mod, residual, p16, raw_stats, mean, rstd, eps);
   VPTR_LAUNCH_CHECK();
   return 0;
 }
@@ -907,10 +919,10 @@ __device__ __forceinline__ DwRow2 dw_load_row2(const float4* __restrict__ x, int
 }
 __global__ __launch_bounds__(256) void dwconv_fwd2_kernel(const float* __restrict__ x_, const float* __restrict__ w9,
                                                           const float* __restrict__ b, float* __restrict__ y_, int frames, int H,
-                                                          int W, int F4, int flip) {
+                                                          int W, int F4, int flip, float* __restrict__ stats) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int W2 = W >> 1;
-  if (idx >= (int64_t)frames * W2 * F4) return;
+  if (idx >= (int64_t)frames * W2 * F4) return;   // (with stats the launcher guarantees whole waves: W2 * F4 % 64 == 0)
   const int c4 = (int)(idx % F4);
   const int xw0 = (int)((idx / F4) % W2) * 2;
   const int64_t f = idx / ((int64_t)F4 * W2);
@@ -921,6 +933,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd2_kernel(const float* __restric
   for (int t = 0; t < 9; ++t) w[t] = reinterpret_cast<const float4*>(w9)[(int64_t)(flip ? 8 - t : t) * F4 + c4];
   const float4 bias = b ? reinterpret_cast<const float4*>(b)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
   DwRow2 r0 = dw_load_row2(x, f * H, -1, H, xw0, W, F4, c4), r1 = dw_load_row2(x, f * H, 0, H, xw0, W, F4, c4);
+  float ssum = 0.f, ssq = 0.f;
   for (int yh = 0; yh < H; ++yh) {
     const DwRow2 r2 = dw_load_row2(x, f * H, yh + 1, H, xw0, W, F4, c4);
     float4 a = bias, a2 = bias;
@@ -932,8 +945,19 @@ __global__ __launch_bounds__(256) void dwconv_fwd2_kernel(const float* __restric
     fma4(a2, w[6], r2.c1); fma4(a2, w[7], r2.c2); fma4(a2, w[8], r2.c3);
     y[((f * H + yh) * W + xw0) * F4 + c4] = a;
     y[((f * H + yh) * W + xw0 + 1) * F4 + c4] = a2;
+    if (stats) {
+      ssum += ((a.x + a.y) + (a.z + a.w)) + ((a2.x + a2.y) + (a2.z + a2.w));
+      ssq += ((a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w)) + ((a2.x * a2.x + a2.y * a2.y) + (a2.z * a2.z + a2.w * a2.w));
+    }
     r0 = r1;
     r1 = r2;
+  }
+  if (stats) {   // the wave lies inside one frame (W2 * F4 % 64 == 0): per-frame sum / sum of squares for the LayerNorm((F,H,W)) that follows
+    const float S = wave_sum(ssum), Q = wave_sum(ssq);
+    if ((threadIdx.x & 63) == 0) {
+      unsafeAtomicAdd(stats + 2 * f, S);
+      unsafeAtomicAdd(stats + 2 * f + 1, Q);
+    }
   }
 }
 // dw9[tap, c] += sum_{f,y,x} dy[f,y,x,c] * x[f,y+ky-1,x+kx-1,c];  db[c] += sum dy.
@@ -1009,11 +1033,14 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restri
 }
 
 extern "C" int vptr_dwconv3x3_fwd(const float* x, const float* w9, const float* b, float* y, int frames, int H, int W, int F,
-                                  vptr_stream_t stream) {
+                                  float* frame_stats, vptr_stream_t stream) {
   VPTR_CHECK(frames > 0 && H > 0 && W > 0 && F > 0 && F % 4 == 0, "dwconv3x3_fwd: bad arguments");
   const int64_t total = (int64_t)frames * W * (F / 4);
-  if (W % 2 == 0 && total >= (1 << 16))
-    dwconv_fwd2_kernel<<<(unsigned)((total / 2 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, w9, b, y, frames, H, W, F / 4, 0);
+  if (frame_stats) {   // no silent fallback: the caller asks for statistics only where this kernel can give them (vptr_amd/ops.py)
+    VPTR_CHECK(W % 2 == 0 && ((W / 2) * (F / 4)) % 64 == 0, "dwconv3x3_fwd: frame_stats needs W even and (W/2)*(F/4) %% 64 == 0");
+    dwconv_fwd2_kernel<<<(unsigned)((total / 2 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, w9, b, y, frames, H, W, F / 4, 0, frame_stats);
+  } else if (W % 2 == 0 && total >= (1 << 16))
+    dwconv_fwd2_kernel<<<(unsigned)((total / 2 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, w9, b, y, frames, H, W, F / 4, 0, nullptr);
   else
     dwconv_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, w9, b, y, frames, H, W, F / 4, 0);
   VPTR_LAUNCH_CHECK();
@@ -1027,7 +1054,7 @@ extern "C" int vptr_dwconv3x3_bwd(const float* dy, const float* x, const float* 
   const int64_t total = (int64_t)frames * W * (F / 4);
   if (dx) {
     if (W % 2 == 0 && total >= (1 << 16))
-      dwconv_fwd2_kernel<<<(unsigned)((total / 2 + 255) / 256), 256, 0, st>>>(dy, w9, nullptr, dx, frames, H, W, F / 4, 1);
+      dwconv_fwd2_kernel<<<(unsigned)((total / 2 + 255) / 256), 256, 0, st>>>(dy, w9, nullptr, dx, frames, H, W, F / 4, 1, nullptr);
     else
       dwconv_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(dy, w9, nullptr, dx, frames, H, W, F / 4, 1);
   }

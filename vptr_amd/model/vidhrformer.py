@@ -248,13 +248,20 @@ class MlpDWBN(nn.Module):
         p = self.drop_p if self.training else 0.0
         F, C = self.fc1.weight.shape[0], self.fc1.weight.shape[1]
         P = ops.p16_ok(C, F, self.out_features)
-        h = ops.linear(u, self.fc1.weight.view(F, C), self.fc1.bias, x_p16=x_p16, dy_p16=P)
-        h = self._norm_act(h, self.norm1, g, dx_p16=P)
-        h = ops.dwconv3x3(h, self.dw3x3.weight, self.dw3x3.bias, g.N * g.T, g.H, g.W)
-        h = self._norm_act(h, self.norm2, g, dropout_p=p, site=site, out_p16=P)
-        h = ops.linear(h, self.fc2.weight.view(self.out_features, F), self.fc2.bias, x_p16=P, dy_p16=P)
+        # LayerNorm((ch,H,W)) statistics: where the producing kernel can deliver them (P16 GEMM epilogue halves / depthwise waves inside one
+        # frame), each normalisation reads per-frame sums its producer accumulated instead of running a statistics pass of its own
+        HW, frames, rows = g.H * g.W, g.N * g.T, u.shape[0]
+        S = self.layer_norm and P and ops.frame_stats_ok(rows, HW, F) and ops.frame_stats_ok(rows, HW, self.out_features)
+        Sd = S and ops.frame_stats_ok(rows, HW, F, g.W)
+        buf = ops.frame_stats_buffer(3 * frames, u.device).view(3, frames, 2) if S else None   # one fill for the three normalisations
+        st = [buf[i] if k else None for i, k in enumerate((S, Sd, S))]
+        h = ops.linear(u, self.fc1.weight.view(F, C), self.fc1.bias, x_p16=x_p16, dy_p16=P, frame_stats=st[0], frame_rows=HW)
+        h = self._norm_act(h, self.norm1, g, dx_p16=P, raw_stats=st[0])
+        h = ops.dwconv3x3(h, self.dw3x3.weight, self.dw3x3.bias, frames, g.H, g.W, frame_stats=st[1])
+        h = self._norm_act(h, self.norm2, g, dropout_p=p, site=site, out_p16=P, raw_stats=st[1])
+        h = ops.linear(h, self.fc2.weight.view(self.out_features, F), self.fc2.bias, x_p16=P, dy_p16=P, frame_stats=st[2], frame_rows=HW)
         return self._norm_act(h, self.norm3, g, dropout_p=p, site=site + 1, rowscale=rowscale, rs_div=rs_div, rs_mod=rs_mod,
-                              residual=residual, dx_p16=P)
+                              residual=residual, dx_p16=P, raw_stats=st[2])
 
 
 def _mha_tokens(mha, q_in, k_in, v_in, residual, Nb, Tq, Tk, HW, causal, p_attn, site, out_dropout=0.0, out_site=0,

@@ -37,6 +37,8 @@ class _Config:
     wgrad_chunk_tiles = int(os.environ.get("VPTR_WGRAD_CHUNK", "600"))
     # the transformer MLP as one autograd node (ops.mlp) instead of two ops.linear nodes; 0 = A/B switch
     fused_mlp = os.environ.get("VPTR_FUSED_MLP", "1") != "0"
+    # LayerNorm((F,H,W)) statistics accumulated by the epilogue of the producing GEMM / depthwise convolution; 0 = separate pass (A/B)
+    fused_frame_stats = os.environ.get("VPTR_FUSED_STATS", "1") != "0"
 
 
 config = _Config()
@@ -105,7 +107,7 @@ def _c(t):
 def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None, colscale=None, alpha=1.0, act=ACT_NONE,
              Dpre=None, rowscale=None, rs_div=1, rs_mod=1, dropout_p=0.0, site=0, residual=None, act_after=False,
              atomic=False, split_k=1, conv=None, precision=None, seed=None, a_rowsum=None, batch_extra=None, kseg_extra=None,
-             planes_out=None, d_p16=False, act_grad_src=None):
+             planes_out=None, d_p16=False, act_grad_src=None, frame_stats=None, frame_rows=0):
     """One vptr_gemm launch.  batch_extra = [(A, B, D, bias, alpha), ...] adds up to two same-shaped independent problems to
     the grid; kseg_extra = [(A, B), ...] adds up to two K-segments accumulated into the same D (include/vptr_hip.h)."""
     d = GemmDesc()
@@ -123,6 +125,7 @@ def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None
     d.D_planes = ptr(planes_out)
     d.d_p16 = int(bool(d_p16))
     d.act_grad_src = ptr(act_grad_src)
+    d.frame_stats, d.frame_rows = ptr(frame_stats), int(frame_rows)
     d.A, d.B, d.D, d.Dpre = ptr(A), ptr(B), ptr(D), ptr(Dpre)
     d.lda = lda if lda is not None else (A.stride(0) if a_mode != 2 else 0)
     d.ldb = ldb if ldb is not None else B.stride(0)
@@ -656,7 +659,8 @@ class _LinearFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, W, b, residual, rowscale, alpha, act, rs_div, rs_mod, dropout_p, site, x_p16, out_p16, dy_p16):
+    def forward(ctx, x, W, b, residual, rowscale, alpha, act, rs_div, rs_mod, dropout_p, site, x_p16, out_p16, dy_p16, frame_stats=None,
+                frame_rows=0):
         _lib.require_cuda(x, W)
         if act == ACT_RELU and (residual is not None or rowscale is not None or dropout_p > 0):
             raise RuntimeError("linear: a ReLU epilogue cannot be combined with residual/rowscale/dropout")
@@ -674,8 +678,11 @@ class _LinearFn(torch.autograd.Function):
             xs = x if x_p16 else to_p16(x)
             Wp, ldw, _, _ = weight_planes_for(W)
             gemm_raw(xs, Wp, y, M, N, K, A_P16, B_P16, lda=K, ldb=ldw, bias=b, alpha=alpha, act=act, Dpre=pre, rowscale=rowscale,
-                     rs_div=rs_div, rs_mod=rs_mod, dropout_p=dropout_p, site=site, residual=res, seed=ctx.seed, d_p16=out_p16)
+                     rs_div=rs_div, rs_mod=rs_mod, dropout_p=dropout_p, site=site, residual=res, seed=ctx.seed, d_p16=out_p16,
+                     frame_stats=frame_stats, frame_rows=frame_rows)
         else:
+            if frame_stats is not None:
+                raise RuntimeError("linear: frame_stats is an epilogue of the P16 GEMMs only")
             xs = x
             gemm_raw(x, W, y, M, N, K, 0, 0, bias=b, alpha=alpha, act=act, Dpre=pre, rowscale=rowscale, rs_div=rs_div,
                      rs_mod=rs_mod, dropout_p=dropout_p, site=site, residual=res, seed=ctx.seed)
@@ -727,16 +734,31 @@ class _LinearFn(torch.autograd.Function):
             if dy_p16:
                 raise RuntimeError("linear: the residual branch needs the fp32 gradient")
             dres = dy
-        return (dx, dW, db, dres) + (None,) * 10
+        return (dx, dW, db, dres) + (None,) * 12
 
 
 _LinearFn_apply = _direct_apply(_LinearFn)
 
 
 def linear(x, W, b=None, residual=None, alpha=1.0, act=ACT_NONE, rowscale=None, rs_div=1, rs_mod=1, dropout_p=0.0, site=0,
-           x_p16=False, out_p16=False, dy_p16=False):
+           x_p16=False, out_p16=False, dy_p16=False, frame_stats=None, frame_rows=0):
+    """frame_stats / frame_rows: a zeroed [rows / frame_rows, 2] buffer (frame_stats_buffer) that the GEMM epilogue fills with each
+    frame's sum / sum of squares of y, for norm_act(..., raw_stats=...) -- the LayerNorm((F,H,W)) after a 1x1 convolution then needs no
+    statistics pass of its own."""
     return _LinearFn_apply(x, W, b, residual, rowscale, float(alpha), int(act), int(rs_div), int(rs_mod), float(dropout_p),
-                           int(site), bool(x_p16), bool(out_p16), bool(dy_p16))
+                           int(site), bool(x_p16), bool(out_p16), bool(dy_p16), frame_stats, int(frame_rows))
+
+
+def frame_stats_ok(rows, HW, F, W=None):
+    """can the producers of a conv-FFN tensor [rows, F] (frames of HW rows) deliver its LayerNorm((F,H,W)) statistics themselves?
+    (64-row epilogue halves inside one frame; the depthwise kernel's waves inside one frame)"""
+    return (config.fused_frame_stats and config.use_p16 and config.gemm_precision == 3 and HW % 64 == 0 and rows % HW == 0 and F % 16 == 0
+            and (W is None or (W % 2 == 0 and ((W // 2) * (F // 4)) % 64 == 0)))
+
+
+def frame_stats_buffer(frames, device):
+    """a zeroed [frames, 2] fp32 buffer for one producer / consumer pair (one tiny fill; inside a graph capture it is re-zeroed at every replay)"""
+    return torch.zeros((frames, 2), device=device, dtype=torch.float32)
 
 
 class _MlpFn(torch.autograd.Function):
@@ -1180,7 +1202,7 @@ class _NormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, running_mean, running_var, mode, HW, training, act, eps, p, site, momentum, rowscale, rs_div,
-                rs_mod, residual, out_p16, dx_p16, num_batches_tracked):
+                rs_mod, residual, out_p16, dx_p16, num_batches_tracked, raw_stats=None):
         x, w, b = _c(x), _c(w), _c(b)
         residual = _c(residual) if residual is not None else None
         rows, F = x.shape
@@ -1204,14 +1226,18 @@ class _NormActFn(torch.autograd.Function):
         else:
             frames = rows // HW
             mean = torch.empty((frames,), device=dev, dtype=torch.float32)
-            var = torch.empty_like(mean)
             rstd = torch.empty_like(mean)
-            check(lib.vptr_groupstats(ptr(x), ptr(mean), ptr(var), ptr(rstd), eps, frames, HW * F, stream()), "vptr_groupstats")
+            if raw_stats is None:
+                var = torch.empty_like(mean)
+                check(lib.vptr_groupstats(ptr(x), ptr(mean), ptr(var), ptr(rstd), eps, frames, HW * F, stream()), "vptr_groupstats")
+            # else: x's producer accumulated the per-frame sums; the normalise kernel derives mean / rstd and writes them for backward
+        if raw_stats is not None and per_col:
+            raise RuntimeError("norm_act: raw_stats belong to the LayerNorm((F,H,W)) mode")
         y = torch.empty_like(x)
         ctx.seed = seed_tensor(dev) if p > 0 else None
         check(lib.vptr_norm_act_fwd(ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(b), ptr(y), rows, F, HW, int(per_col), act, p,
                                     ptr(ctx.seed), site, ptr(rowscale), rs_div, rs_mod,
-                                    ptr(residual), int(out_p16), stream()), "vptr_norm_act_fwd")
+                                    ptr(residual), int(out_p16), ptr(raw_stats), eps, stream()), "vptr_norm_act_fwd")
         ctx.save_for_backward(x, w, b, mean, rstd, rowscale)
         ctx.cfg = (HW, per_col, act, const_stats, p, site, rs_div, rs_mod, residual is not None, dx_p16)
         return y
@@ -1235,29 +1261,30 @@ class _NormActFn(torch.autograd.Function):
         dres = dy if has_res else None
         if in_slab:
             dw = db = None
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None, dres, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None, dres, None, None, None, None
 
 
 _NormActFn_apply = _direct_apply(_NormActFn)
 
 
 def norm_act(x, w, b, mode, HW, training, running_mean=None, running_var=None, act=ACT_GELU, eps=1e-5, dropout_p=0.0, site=0,
-             momentum=0.1, rowscale=None, rs_div=1, rs_mod=1, residual=None, out_p16=False, dx_p16=False, num_batches_tracked=None):
+             momentum=0.1, rowscale=None, rs_div=1, rs_mod=1, residual=None, out_p16=False, dx_p16=False, num_batches_tracked=None,
+             raw_stats=None):
     """y = rowscale * dropout(act(norm(x)*w + b)) + residual  (one elementwise pass; see _NormActFn).
     out_p16: y is written as a P16 tensor (it only feeds a GEMM); dx_p16: the gradient w.r.t. x is returned as a P16 tensor (x is
     the output of a linear(..., dy_p16=True) and nothing else)."""
     return _NormActFn_apply(x, w, b, running_mean, running_var, mode, int(HW), bool(training), int(act), float(eps),
                             float(dropout_p), int(site), float(momentum), rowscale, int(rs_div), int(rs_mod), residual,
-                            bool(out_p16), bool(dx_p16), num_batches_tracked)
+                            bool(out_p16), bool(dx_p16), num_batches_tracked, raw_stats)
 
 
 class _DWConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w9, b, frames, H, W):
+    def forward(ctx, x, w9, b, frames, H, W, frame_stats=None):
         x, w9 = _c(x), _c(w9)
         F = x.shape[1]
         y = torch.empty_like(x)
-        check(lib.vptr_dwconv3x3_fwd(ptr(x), ptr(w9), ptr(b), ptr(y), frames, H, W, F, stream()), "vptr_dwconv3x3_fwd")
+        check(lib.vptr_dwconv3x3_fwd(ptr(x), ptr(w9), ptr(b), ptr(y), frames, H, W, F, ptr(frame_stats), stream()), "vptr_dwconv3x3_fwd")
         ctx.save_for_backward(x, w9)
         ctx.cfg = (frames, H, W)
         ctx.bias_ref = b.detach() if b is not None else None
@@ -1278,17 +1305,17 @@ class _DWConvFn(torch.autograd.Function):
               "vptr_dwconv3x3_bwd")
         if in_slab:
             dw9 = db = None
-        return dx, dw9, db, None, None, None
+        return dx, dw9, db, None, None, None, None
 
 
 _DWConvFn_apply = _direct_apply(_DWConvFn)
 
 
-def dwconv3x3(x, weight, bias, frames, H, W):
-    """Depthwise 3x3 (pad 1) on channel-last x [frames*H*W, F]; weight is the PyTorch parameter [F,1,3,3]."""
+def dwconv3x3(x, weight, bias, frames, H, W, frame_stats=None):
+    """Depthwise 3x3 (pad 1) on channel-last x [frames*H*W, F]; weight is the PyTorch parameter [F,1,3,3].  frame_stats: see linear."""
     F = x.shape[1]
     w9 = weight.reshape(F, 9).t().contiguous()  # tap-major [9, F] for coalesced reads
-    return _DWConvFn_apply(x, w9, bias, int(frames), int(H), int(W))
+    return _DWConvFn_apply(x, w9, bias, int(frames), int(H), int(W), frame_stats)
 
 
 # ------------------------------------------------------------------------------------------------------------------
