@@ -179,14 +179,14 @@ __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const float* __restri
 // dx + dgamma/dbeta in ONE pass: one wave per row, the row held in registers as NC4 float4 per lane between the two
 // reductions; the parameter gradients are accumulated per lane over the wave's rows, summed over the block's 4 waves in LDS,
 // and leave the block as one atomic per column.  C % 4 == 0 and C <= 256 * NC4.
-template <int NC4>
-__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restrict__ dy_, const float* __restrict__ dy2_,
+template <int NC4, int NW>   // NW waves per workgroup, each walking every NW-th row of the workgroup's rpb rows
+__global__ __launch_bounds__(64 * NW) void ln_bwd_fused_kernel(const float* __restrict__ dy_, const float* __restrict__ dy2_,
                                                            const float* __restrict__ x_, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            float* __restrict__ dx_, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int rows, int C, int rpb,
                                                            const float* __restrict__ dx_add_) {
-  __shared__ float4 red[4][2][NC4 * 64];
+  __shared__ float4 red[NW][2][NC4 * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int C4 = C >> 2;
   const int r0 = blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
     ab[k] = z;
   }
   const float inv_c = 1.f / (float)C;
-  for (int row = r0 + wv; row < r1; row += 4) {
+  for (int row = r0 + wv; row < r1; row += NW) {
     const float4* dy = reinterpret_cast<const float4*>(dy_) + (int64_t)row * C4;
     const float4* x = reinterpret_cast<const float4*>(x_) + (int64_t)row * C4;
     float4* dx = reinterpret_cast<float4*>(dx_) + (int64_t)row * C4;
@@ -246,9 +246,15 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
   __syncthreads();
   const float* rf = reinterpret_cast<const float*>(&red[0][0][0]);
   constexpr int WS = 2 * NC4 * 64 * 4, PS = NC4 * 64 * 4;  // floats per wave / per plane
-  for (int i = threadIdx.x; i < C; i += 256) {
-    unsafeAtomicAdd(dgamma + i, rf[i] + rf[WS + i] + rf[2 * WS + i] + rf[3 * WS + i]);
-    unsafeAtomicAdd(dbeta + i, rf[PS + i] + rf[WS + PS + i] + rf[2 * WS + PS + i] + rf[3 * WS + PS + i]);
+  for (int i = threadIdx.x; i < C; i += 64 * NW) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      sg += rf[w * WS + i];
+      sb += rf[w * WS + PS + i];
+    }
+    unsafeAtomicAdd(dgamma + i, sg);
+    unsafeAtomicAdd(dbeta + i, sb);
   }
 }
 
@@ -258,11 +264,15 @@ extern "C" int vptr_layernorm_bwd(const float* dy, const float* dy2, const float
   VPTR_CHECK(rows > 0 && C > 0, "layernorm_bwd: empty input");
   hipStream_t st = (hipStream_t)stream;
   if (dx && dgamma && dbeta && C % 4 == 0 && C <= 1024) {
-    const int rpb = rows >= 4096 ? 32 : 4;  // fewer, longer workgroups: the per-column atomics at the end contend across workgroups
+    // fewer, longer workgroups: the per-column atomics at the end contend across workgroups.  Big inputs: 8 waves x 8 rows each = 64 rows
+    // per workgroup (half the atomics of 4 waves x 8 rows at the same number of waves in flight: -0.25 ms per step; 16 waves or fewer rows lose)
+    const bool big = rows >= 4096;
+    const int rpb = big ? 64 : 4;
     const int nb = cdiv(rows, rpb);
-    if (C <= 256) ln_bwd_fused_kernel<1><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb, dx_add);
-    else if (C <= 768) ln_bwd_fused_kernel<3><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb, dx_add);
-    else ln_bwd_fused_kernel<4><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb, dx_add);
+    if (C <= 256) ln_bwd_fused_kernel<1, 4><<<cdiv(rows, big ? 32 : 4), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, big ? 32 : 4, dx_add);
+    else if (C <= 768 && big) ln_bwd_fused_kernel<3, 8><<<nb, 512, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb, dx_add);
+    else if (C <= 768) ln_bwd_fused_kernel<3, 4><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb, dx_add);
+    else ln_bwd_fused_kernel<4, 4><<<cdiv(rows, big ? 32 : 4), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, big ? 32 : 4, dx_add);
     VPTR_LAUNCH_CHECK();
     return 0;
   }
