@@ -25,12 +25,12 @@ def fam(n):   # PMC tables: the instantiations of the P16 kernels as one family 
     return s
 # ---- (1) kernel stats
 rows = list(csv.DictReader(open(OUT + "/stats/b_kernel_stats.csv")))
-steps = 26.0   # 5 warm-up + 20 timed + 1 instrumented
+steps = 28.0   # 5 warm-up + 20 timed + 3 instrumented
 tot = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6 / steps
 gemm = sum(float(r["TotalDurationNs"]) for r in rows if "gemm" in r["Name"] or "conv_planes" in r["Name"] or "wgrad" in r["Name"]) / 1e6 / steps
 with open(OUT + "/r02_bench_kernel_stats.md", "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --graph 0 --no-cpu-baseline --no-other-configs   (eager, N=16, bf16x3, dropout 0.1;\n")
-    f.write("# 5 warm-up + 20 timed + 1 instrumented step = 26 steps; per-step figures = totals / 26)\n")
+    f.write("# 5 warm-up + 20 timed + 3 instrumented steps = 28 steps; per-step figures = totals / 28)\n")
     f.write("# kernel time %.1f ms/step: MFMA GEMM kernels %.1f, everything else %.1f\n\n" % (tot, gemm, tot - gemm))
     f.write("| kernel | calls/step | ms/step | avg us | % |\n|---|---|---|---|---|\n")
     for r in rows[:60]:
