@@ -349,6 +349,118 @@ __global__ __launch_bounds__(256, 2) void gemm_nt64(const unsigned char* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Clean nt kernels for the tile-size question (no experiment switches): TM = 128: 8 waves (4 x 2), the product's loop (wave map
+// 2, B-fragment prefetch); TM = 256: 16 waves (8 x 2) share ONE B panel per stage -- 56 DMA pieces per 256 x 176 x 32 step instead
+// of 2 x 40, one workgroup per CU (2 stages of 56 KB).
+template <int TM>
+__global__ __launch_bounds__(TM * 4, TM == 256 ? 1 : 4) void gemm_nt_t(const unsigned char* __restrict__ A, const unsigned char* __restrict__ B,
+                                                                     float* __restrict__ D, int M, int N, int K, int64_t strideA, int64_t strideB,
+                                                                     int64_t strideD, int elim) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr int NWV = TM / 16, APC = TM / 8, NPC = APC + 24, PPW = (NPC + NWV - 1) / NWV, STG = NPC * 1024, BOFF = APC * 1024, WMN = NWV / 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & (WMN - 1), wn = wave / WMN, lr = lane & 15, lq = lane >> 4;
+  const int tiles_n = (N + BN - 1) / BN, tiles = tiles_n * ((M + TM - 1) / TM);
+  const int lg = xcd_logical();
+  const int prob = lg / tiles, tile = lg - prob * tiles;
+  A += prob * strideA; B += prob * strideB; D += prob * strideD;
+  const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * BN;
+  const int nk = (K + BK - 1) / BK;
+  const bool ktail = (K & 31) != 0;
+  const int64_t pitch = (int64_t)K * 4;
+  const unsigned char* src[PPW];
+  int tail_adj[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int u = min(wave + NWV * i, NPC - 1);
+    const bool isA = u < APC;
+    const int prow = (isA ? u : u - APC) * 8 + (lane >> 3), pch = lane & 7;
+    const int c = pch ^ ((prow >> 1) & 7);
+    const int grow = isA ? min(m0 + prow, M - 1) : min(n0 + prow, N - 1);
+    src[i] = (isA ? A : B) + grow * pitch + c * 16;
+    tail_adj[i] = c >= 4 ? -64 : 0;
+  }
+  auto issue = [&](const int kt, const int stage) {
+    const bool last = ktail && kt == nk - 1;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      if (wave + NWV * i < NPC) {   // wave-uniform
+        const unsigned char* g = src[i] + (int64_t)kt * 128 + (last ? tail_adj[i] : 0);
+        GLDS((uint32_t)(stage * STG + (wave + NWV * i) * 1024), g);
+      }
+    }
+  };
+  f32x4 acc[2][6];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int offAh[2], offBh[6];
+  const int ch = (lq >> 1) * 4 + (lq & 1);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int r = wm * 32 + mi * 16 + lr, f = (r >> 1) & 7;
+    offAh[mi] = r * 128 + ((ch ^ f) << 4);
+  }
+#pragma unroll
+  for (int ni = 0; ni < 6; ++ni) {
+    const int r = (wn * 6 + ni) * 16 + lr, f = (r >> 1) & 7;
+    offBh[ni] = BOFF + r * 128 + ((ch ^ f) << 4);
+  }
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    if (kt + 1 < nk && !(elim == 1 && kt > 0)) issue(kt + 1, (kt + 1) & 1);
+    const unsigned char* st = smem + (kt & 1) * STG;
+    bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      ah[mi] = *reinterpret_cast<const bf16x8*>(st + offAh[mi]);
+      al[mi] = *reinterpret_cast<const bf16x8*>(st + (offAh[mi] ^ 32));
+    }
+    if (ktail && kt == nk - 1 && lq >= 2) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        ah[mi] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        al[mi] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+    bf16x8 bh[2], bl[2];
+    bh[0] = *reinterpret_cast<const bf16x8*>(st + offBh[0]);
+    bl[0] = *reinterpret_cast<const bf16x8*>(st + (offBh[0] ^ 32));
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) {
+      if (ni == 5 && wn == 1) break;
+      if (ni + 1 < 6 && !(ni + 1 == 5 && wn == 1)) {
+        bh[(ni + 1) & 1] = *reinterpret_cast<const bf16x8*>(st + offBh[ni + 1]);
+        bl[(ni + 1) & 1] = *reinterpret_cast<const bf16x8*>(st + (offBh[ni + 1] ^ 32));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl[ni & 1], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int ni = 0; ni < 6; ++ni) {
+    const int nf = wn * 6 + ni, col = n0 + nf * 16 + lr;
+    if (nf >= 11 || col >= N) continue;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 32 + mi * 16 + lq * 4 + r;
+        if (row < M) D[(int64_t)row * N + col] = acc[mi][ni][r];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // tn: D[NG][KX] = sum_t G[t][ng] X[t][kx];  T % 32 == 0 in the probe.
 // Stage = 40 pieces of [8 t][128 B]; a piece holds, for one pair of granules, 4 mini-subtiles [8 t][16 ch] (g0 hi, g0 lo, g1 hi,
 // g1 lo) of 256 bytes each: lane L of the DMA fetches chunk (L >> 4) * 2 + (L & 1) of row (L & 15) >> 1 -- whole 128-byte lines
@@ -574,6 +686,50 @@ static int run_tn(int T, int NG, int KX, int P, int elim) {
   return 0;
 }
 
+static int run_tile(int M, int N, int K) {
+  std::vector<float> hA = rnd_vec((size_t)M * K, 1.f, 1), hB = rnd_vec((size_t)N * K, 0.05f, 2);
+  const int ROT = getenv("ROT") ? atoi(getenv("ROT")) : 1, elim = getenv("ELIM") ? atoi(getenv("ELIM")) : 0;
+  float *dA, *dB, *D;
+  unsigned char *pA, *pB;
+  const size_t sa = (size_t)M * K * 4, sb = (size_t)N * K * 4, sd = (size_t)M * N * 4;
+  CK(hipMalloc(&dA, sa)); CK(hipMalloc(&dB, sb)); CK(hipMalloc(&D, sd * ROT)); CK(hipMalloc(&pA, sa * ROT + 256)); CK(hipMalloc(&pB, sb * ROT + 256));
+  CK(hipMemcpy(dA, hA.data(), sa, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), sb, hipMemcpyHostToDevice));
+  for (int p = 0; p < ROT; ++p) {
+    to_p16_kernel<<<(unsigned)((sa / 16 + 255) / 256), 256>>>(dA, pA + p * sa, sa / 16);
+    to_p16_kernel<<<(unsigned)((sb / 16 + 255) / 256), 256>>>(dB, pB + p * sb, sb / 16);
+  }
+  CK(hipDeviceSynchronize());
+  std::vector<float> hD((size_t)M * N);
+  for (int tm = 128; tm <= 256; tm += 128) {
+    auto kern = tm == 128 ? gemm_nt_t<128> : gemm_nt_t<256>;
+    const int lds = tm == 128 ? 2 * 40 * 1024 : 2 * 56 * 1024;
+    const int ntile = ((M + tm - 1) / tm) * ((N + BN - 1) / BN);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CK(hipMemset(D, 0, sd * ROT));
+    int rot = ROT - 1;
+    auto launch = [&]() {
+      kern<<<ntile, tm * 4, lds>>>(pA + (size_t)rot * sa, pB + (size_t)rot * sb, D + (size_t)rot * M * N, M, N, K, 0, 0, 0, elim);
+      rot = (rot + 1) % ROT;
+    };
+    launch();
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(hD.data(), D + (size_t)(ROT - 1) * M * N, sd, hipMemcpyDeviceToHost));
+    double num = 0, den = 0;
+    for (int s = 0; s < 4000; ++s) {
+      const int i = (int)(((uint64_t)s * 2654435761u) % M), j = (int)(((uint64_t)s * 40503u + 17) % N);
+      double ref = 0;
+      for (int k = 0; k < K; ++k) ref += (double)hA[(size_t)i * K + k] * hB[(size_t)j * K + k];
+      num += (hD[(size_t)i * N + j] - ref) * (hD[(size_t)i * N + j] - ref);
+      den += ref * ref;
+    }
+    const float us = time_us(launch, 20);
+    printf("tile %dx176 (%d waves)  M %d N %d K %d rot%d  tiles %d  %8.1f us  %7.1f TFLOP/s  rel-L2 %.2e%s\n", tm, tm / 16, M, N, K, ROT, ntile, us,
+           2.0 * M * N * K / us / 1e6, sqrt(num / den), elim ? " (no DMA after step 1)" : "");
+  }
+  hipFree(dA); hipFree(dB); hipFree(D); hipFree(pA); hipFree(pB);
+  return 0;
+}
+
 static int run_tr_test() {
   int h_addr[64];
   short h_out[256];
@@ -611,6 +767,12 @@ int main(int argc, char** argv) {
     if (run_nt(10240, 528, 528, 3)) return 1;
     if (run_nt(20480, 2112, 2112, 1)) return 1;
     if (run_nt(1000, 528, 528, 1)) return 1;
+  }
+  if (!strcmp(mode, "tile")) {
+    if (run_tile(10240, 2112, 528)) return 1;
+    if (run_tile(20480, 2112, 2112)) return 1;
+    if (run_tile(10240, 528, 2112)) return 1;
+    if (run_tile(10240, 528, 528)) return 1;
   }
   if (!strcmp(mode, "tn") || !strcmp(mode, "all")) {
     const int elim = getenv("ELIM") ? atoi(getenv("ELIM")) : 0;
