@@ -460,6 +460,121 @@ __global__ __launch_bounds__(TM * 4, TM == 256 ? 1 : 4) void gemm_nt_t(const uns
   }
 }
 
+// 128 x 176 tile on 16 waves (4 x 4 of 32 x 48: 3 column fragments per wave, the last column group 2), NS stages, one workgroup per CU:
+// the occupancy of two 8-wave workgroups on ONE tile, for grids of <= one tile per CU
+template <int NS>
+__global__ __launch_bounds__(1024, 1) void gemm_nt_w16(const unsigned char* __restrict__ A, const unsigned char* __restrict__ B,
+                                                                     float* __restrict__ D, int M, int N, int K, int64_t strideA, int64_t strideB,
+                                                                     int64_t strideD, int elim) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr int TM = 128, NWV = 16, APC = TM / 8, NPC = APC + 24, PPW = (NPC + NWV - 1) / NWV, STG = NPC * 1024, BOFF = APC * 1024, WMN = 4, NF = 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & (WMN - 1), wn = wave / WMN, lr = lane & 15, lq = lane >> 4;
+  const int tiles_n = (N + BN - 1) / BN, tiles = tiles_n * ((M + TM - 1) / TM);
+  const int lg = xcd_logical();
+  const int prob = lg / tiles, tile = lg - prob * tiles;
+  A += prob * strideA; B += prob * strideB; D += prob * strideD;
+  const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * BN;
+  const int nk = (K + BK - 1) / BK;
+  const bool ktail = (K & 31) != 0;
+  const int64_t pitch = (int64_t)K * 4;
+  const unsigned char* src[PPW];
+  int tail_adj[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int u = min(wave + NWV * i, NPC - 1);
+    const bool isA = u < APC;
+    const int prow = (isA ? u : u - APC) * 8 + (lane >> 3), pch = lane & 7;
+    const int c = pch ^ ((prow >> 1) & 7);
+    const int grow = isA ? min(m0 + prow, M - 1) : min(n0 + prow, N - 1);
+    src[i] = (isA ? A : B) + grow * pitch + c * 16;
+    tail_adj[i] = c >= 4 ? -64 : 0;
+  }
+  auto issue = [&](const int kt, const int stage) {
+    const bool last = ktail && kt == nk - 1;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      if (wave + NWV * i < NPC) {   // wave-uniform
+        const unsigned char* g = src[i] + (int64_t)kt * 128 + (last ? tail_adj[i] : 0);
+        GLDS((uint32_t)(stage * STG + (wave + NWV * i) * 1024), g);
+      }
+    }
+  };
+  f32x4 acc[2][NF];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NF; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int offAh[2], offBh[NF];
+  const int ch = (lq >> 1) * 4 + (lq & 1);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int r = wm * 32 + mi * 16 + lr, f = (r >> 1) & 7;
+    offAh[mi] = r * 128 + ((ch ^ f) << 4);
+  }
+#pragma unroll
+  for (int ni = 0; ni < NF; ++ni) {
+    const int r = (wn * NF + ni) * 16 + lr, f = (r >> 1) & 7;
+    offBh[ni] = BOFF + r * 128 + ((ch ^ f) << 4);
+  }
+  issue(0, 0);
+  if (NS == 3 && nk > 1) issue(1, 1);
+  for (int kt = 0; kt < nk; ++kt) {
+    // pieces per wave: waves 0-7 own 3, waves 8-15 own 2 (40 pieces): vmcnt of the NEXT step's pieces may stay in flight
+    if (NS == 3 && kt + 1 < nk) { if (wave < 8) __builtin_amdgcn_s_waitcnt(0x0f70 | 3); else __builtin_amdgcn_s_waitcnt(0x0f70 | 2); }
+    else __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    if (NS == 3) { if (kt + 2 < nk && !(elim == 1 && kt > 0)) issue(kt + 2, (kt + 2) % 3); }
+    else if (kt + 1 < nk && !(elim == 1 && kt > 0)) issue(kt + 1, (kt + 1) & 1);
+    const unsigned char* st = smem + (NS == 3 ? kt % 3 : (kt & 1)) * STG;
+    bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      ah[mi] = *reinterpret_cast<const bf16x8*>(st + offAh[mi]);
+      al[mi] = *reinterpret_cast<const bf16x8*>(st + (offAh[mi] ^ 32));
+    }
+    if (ktail && kt == nk - 1 && lq >= 2) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        ah[mi] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        al[mi] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+    bf16x8 bh[2], bl[2];
+    bh[0] = *reinterpret_cast<const bf16x8*>(st + offBh[0]);
+    bl[0] = *reinterpret_cast<const bf16x8*>(st + (offBh[0] ^ 32));
+#pragma unroll
+    for (int ni = 0; ni < NF; ++ni) {
+      if (ni == 2 && wn == 3) break;
+      if (ni + 1 < NF && !(ni + 1 == 2 && wn == 3)) {
+        bh[(ni + 1) & 1] = *reinterpret_cast<const bf16x8*>(st + offBh[ni + 1]);
+        bl[(ni + 1) & 1] = *reinterpret_cast<const bf16x8*>(st + (offBh[ni + 1] ^ 32));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl[ni & 1], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int ni = 0; ni < NF; ++ni) {
+    const int nf = wn * NF + ni, col = n0 + nf * 16 + lr;
+    if (nf >= 11 || col >= N) continue;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 32 + mi * 16 + lq * 4 + r;
+        if (row < M) D[(int64_t)row * N + col] = acc[mi][ni][r];
+      }
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------------------------------------
 // tn: D[NG][KX] = sum_t G[t][ng] X[t][kx];  T % 32 == 0 in the probe.
 // Stage = 40 pieces of [8 t][128 B]; a piece holds, for one pair of granules, 4 mini-subtiles [8 t][16 ch] (g0 hi, g0 lo, g1 hi,
@@ -725,6 +840,32 @@ static int run_tile(int M, int N, int K) {
     const float us = time_us(launch, 20);
     printf("tile %dx176 (%d waves)  M %d N %d K %d rot%d  tiles %d  %8.1f us  %7.1f TFLOP/s  rel-L2 %.2e%s\n", tm, tm / 16, M, N, K, ROT, ntile, us,
            2.0 * M * N * K / us / 1e6, sqrt(num / den), elim ? " (no DMA after step 1)" : "");
+  }
+  for (int ns = 2; ns <= 3; ++ns) {
+    auto kern = ns == 2 ? gemm_nt_w16<2> : gemm_nt_w16<3>;
+    const int lds = ns * 40 * 1024;
+    const int ntile = ((M + 127) / 128) * ((N + BN - 1) / BN);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CK(hipMemset(D, 0, sd * ROT));
+    int rot = ROT - 1;
+    auto launch = [&]() {
+      kern<<<ntile, 1024, lds>>>(pA + (size_t)rot * sa, pB + (size_t)rot * sb, D + (size_t)rot * M * N, M, N, K, 0, 0, 0, elim);
+      rot = (rot + 1) % ROT;
+    };
+    launch();
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(hD.data(), D + (size_t)(ROT - 1) * M * N, sd, hipMemcpyDeviceToHost));
+    double num = 0, den = 0;
+    for (int s = 0; s < 4000; ++s) {
+      const int i = (int)(((uint64_t)s * 2654435761u) % M), j = (int)(((uint64_t)s * 40503u + 17) % N);
+      double ref = 0;
+      for (int k = 0; k < K; ++k) ref += (double)hA[(size_t)i * K + k] * hB[(size_t)j * K + k];
+      num += (hD[(size_t)i * N + j] - ref) * (hD[(size_t)i * N + j] - ref);
+      den += ref * ref;
+    }
+    const float us = time_us(launch, 20);
+    printf("tile 128x176 on 16 waves, %d stages  M %d N %d K %d rot%d  tiles %d  %8.1f us  %7.1f TFLOP/s  rel-L2 %.2e\n", ns, M, N, K, ROT, ntile, us,
+           2.0 * M * N * K / us / 1e6, sqrt(num / den));
   }
   hipFree(dA); hipFree(dB); hipFree(D); hipFree(pA); hipFree(pB);
   return 0;
