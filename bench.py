@@ -380,13 +380,22 @@ def main():
 
     use_graph = bool(args.graph) and world == 1
     graph_note = "eager"
+    graph_check = None
     if use_graph:
         try:
             trainer.capture(past, fut, warmup=2)
-            graph_note = "hipGraph"
+            # the graph is only timed if it computes what the eager step computes: 3 eager steps vs 3 replays from the same state
+            # (loss terms, gradient norm, post-step parameters); the state is restored afterwards
+            ok, graph_check = trainer.verify_graph(past, fut, steps=3, rtol=2e-3)
+            graph_check["nodes"] = trainer.graph_nodes
+            if ok:
+                graph_note = "hipGraph"
+            else:
+                trainer._graph = None
+                graph_note = "eager (hipGraph replays disagree with eager steps: %s)" % (graph_check.get("worst_term"),)
         except Exception as e:  # noqa: keep the bench alive, report eager numbers
             trainer._graph = None
-            graph_note = "eager (graph capture failed: %s)" % str(e).split("\n")[0][:120]
+            graph_note = "eager (graph capture failed: %s)" % str(e).split("\n")[0][:160]
 
     def sync():
         torch.cuda.synchronize()
@@ -407,6 +416,10 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(out["T_total"])
+    terms = {k: round(float(v), 6) for k, v in out.items()}
+    # the decoder ends in Tanh and the targets lie in [-0.22, 0.15]: MSE <= 1.5, GDL <= 4, BiPatchNCE ~ ln 64; anything else is a broken step
+    loss_sane = bool(0.0 <= terms["T_MSE"] <= 1.5 and 0.0 <= terms["T_GDL"] <= 4.0 and 0.0 < terms["T_bpc"] < 8.0
+                     and terms["grad_norm"] == terms["grad_norm"] and terms["grad_norm"] < 1e3)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -423,7 +436,7 @@ def main():
                        "launch": graph_note, "dec_weight_grads": True,
                        "alg_tflop_per_step_per_gpu": round(GF_PER_SAMPLE * args.batch / 1e3, 2),
                        "step_tflops_per_gpu": round(GF_PER_SAMPLE * args.batch / 1e3 / (ms * 1e-3), 1)},
-            "final_loss": round(loss, 5),
+            "final_loss": round(loss, 5), "final_terms": terms, "loss_sane": loss_sane, "graph_check": graph_check,
         }
         if not args.no_roofline:
             try:

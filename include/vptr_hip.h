@@ -346,6 +346,32 @@ int vptr_conv7_in_bwd_weight(const float* dy, const float* x, float* dw, int B, 
                              vptr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Losses of the train steps (model/criterion.py) and the stochastic-depth vectors as plain kernel launches: a whole-step
+ * hipGraph must not hold memset nodes (ATen's multi-block reductions issue cudaMemsetAsync).
+ * ---------------------------------------------------------------------------------------------- */
+/* MSELoss + GDL(alpha = 1), no temporal weights (criterion.py:105-132, 134-204; call sites train_NAR.py:87-88,
+ * train_FAR.py:37-38, train_AutoEncoder.py:37-38).  pred, gt: [planes, H, W] (planes = N*T*Cimg).
+ * scratch: planes * ceil(H / 16) * 3 floats.  mse_out / gdl_out: one float each.  Deterministic (fixed-order sums). */
+int vptr_mse_gdl_fwd(const float* pred, const float* gt, float* scratch, float* mse_out, float* gdl_out, int planes, int H,
+                     int W, vptr_stream_t stream);
+/* dpred = g_mse[0] * d mse / d pred + g_gdl[0] * d gdl / d pred; g_mse / g_gdl: DEVICE scalars (null = 0). */
+int vptr_mse_gdl_bwd(const float* pred, const float* gt, const float* g_mse, const float* g_gdl, float* dpred, int planes,
+                     int H, int W, vptr_stream_t stream);
+/* BiPatchNCE (criterion.py:206-259) INCLUDING the F.normalize(p = 2, dim = channel) in front of it (train_NAR.py:81-84):
+ * g = NCE_projector(gt features), p = NCE_projector(predicted features), token-major [frames * L, C], L = h*w patches
+ * per frame.  scratch (kept for the backward): frames * L * (4 + L) + frames floats
+ * (inverse norms [2 R] | scores [frames][L][L] | row / column log-sum-exp [R] each | per-frame partials), R = frames * L. */
+int vptr_nce_fwd(const float* g, const float* p, float* scratch, float* loss_out, int frames, int L, int C,
+                 float temperature, vptr_stream_t stream);
+/* dg, dp [frames * L, C] = gout[0] * d loss / d (g, p) (gout: DEVICE scalar, null = 1); C % 4 == 0, C <= 640. */
+int vptr_nce_bwd(const float* g, const float* p, const float* scratch, const float* gout, float* dg, float* dp, int frames,
+                 int L, int C, float temperature, vptr_stream_t stream);
+/* DropPath scale vectors (VidHRFormer_modules.py:563-575): out[r][k] = floor(keep[r] + U(seed, site0 + r, k)) / keep[r] for
+ * nreq requests of up to maxcount indices each, from the counter-based hash of the step's dropout seed. */
+int vptr_droppath_scales(const float* keep, float* out, int nreq, int maxcount, const uint64_t* seed_dev, uint32_t site0,
+                         vptr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimizer: global-norm clip + AdamW on flat fp32 buffers (train_NAR.py:85-86,205).
  * ---------------------------------------------------------------------------------------------- */
 /* sumsq_dev[0] += sum(g^2) */

@@ -1,8 +1,13 @@
 """Whole-step hipGraph (`NARTrainer.capture`): replays must equal eager steps.  The step is deterministic up to the order of fp32
-atomics -- also with dropout 0.1, because the dropout masks come from the device-resident counter seed that eager steps and replays
-advance identically; only the DropPath vectors come from torch's generator (whose offsets differ under capture), so they are
-switched off here.  Losses, gradient norms and post-step parameters of 10 replays (5 with a device -> host read after each, 5
-back-to-back) are compared with 10 eager steps from the same initial state."""
+atomics -- also with dropout 0.1 and DropPath ON, because every mask and stochastic-depth vector comes from the device-resident
+counter seed that eager steps and replays advance identically (no torch generator in the step since round 3).  Losses, gradient
+norms and post-step parameters of 10 replays (5 with a device -> host read after each, 5 back-to-back) are compared with 10 eager
+steps from the same initial state -- on the tiny model and at the bench configuration (K64, 4 + 8 layers, batch 4, dropout 0.1).
+
+Round-2 post-mortem: the bench-size graph trained on garbage from its second replay on, because ATen's
+F.normalize backward (BiPatchNCE branch) zeroes reduction semaphores with cudaMemsetAsync and a captured memset node is broken on
+this HIP runtime; the tiny test could not see it (its reductions are single-block).  `capture()` now refuses graphs with memset
+nodes and the losses are plain kernels; both are tested here."""
 import pytest
 import torch
 
@@ -34,7 +39,6 @@ def test_graph_replays_match_eager_steps(dev, dropout, monkeypatch):
     import vptr_amd.model.vidhrformer as V
     from vptr_amd import ops
     from vptr_amd.train import NARTrainer
-    monkeypatch.setattr(V, "_droppath_scale", lambda p, training, count, device: None)
     if dropout == 0.0:   # the 2e-4 comparison needs a reproducible forward: conv-FFN statistics on the separate deterministic pass (the
         monkeypatch.setattr(ops.config, "fused_frame_stats", False)   # atomics-accumulated default is covered by the dropout 0.1 case)
     z = load("step_tiny")
@@ -77,3 +81,44 @@ def test_graph_replays_match_eager_steps(dev, dropout, monkeypatch):
                 num += float((g[1][k].double() - v.double()).pow(2).sum())
                 den += float(v.double().pow(2).sum())
         assert (num / den) ** 0.5 < 1e-5, (num / den) ** 0.5
+
+
+def test_graph_k64_bench_config_droppath_on(dev):
+    """the bench configuration itself (VPTRFormerNAR 4 + 8 layers, d 528, dropout 0.1, DropPath on, random init as bench.py builds it)
+    at batch 4: 10 replays == 10 eager steps term by term, every loss term inside its mathematical range"""
+    import bench
+    from vptr_amd import ops
+    from vptr_amd.train import NARTrainer
+    ops.unregister_flat_slabs()
+    ops.manual_seed(dev, 99)
+    enc, dec, T = bench.build_models(dev, 0.1)
+    n = 4
+    tr = NARTrainer(enc, dec, T, batch_size=n, lr=1e-4, max_grad_norm=1.0, lam_pc=0.1)
+    past, fut = bench.synth_batch(n, 0, dev)
+    tr.capture(past, fut, warmup=2)
+    assert "memset" not in tr.graph_nodes and tr.graph_nodes.get("kernel", 0) > 500, tr.graph_nodes
+    ok, rep = tr.verify_graph(past, fut, steps=10, rtol=2e-3)
+    assert ok, rep
+    g = rep["graph_last"]
+    assert 0.0 <= g["T_GDL"] <= 4.0 and 0.0 <= g["T_MSE"] <= 1.5 and 0.0 < g["T_bpc"] < 8.0 and g["grad_norm"] < 100.0, g
+    del tr
+    ops.unregister_flat_slabs()
+    torch.cuda.empty_cache()
+
+
+def test_graph_census_sees_memset_nodes(dev):
+    """the guard itself: a captured hipMemsetAsync shows up as a memset node in graph_node_census (capture() raises on those)"""
+    import ctypes
+    from vptr_amd.train import graph_node_census
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    x = torch.ones(1024, device=dev)
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g):
+        x.add_(1.0)
+        rc = hip.hipMemsetAsync(ctypes.c_void_p(x.data_ptr()), 0, 4096, ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(dev.index or 0)))
+        x.mul_(2.0)
+    assert rc == 0
+    census = graph_node_census(g)
+    assert census.get("memset") == 1 and census.get("kernel") == 2, census
+    g.reset()

@@ -572,3 +572,62 @@ def test_window_copy_pad_and_crop(ops, dev):
     y.backward(g)
     gref = g.cpu().view(frames, Hp, Wp, C)[:, (Hp - H) // 2:(Hp - H) // 2 + H, (Wp - W) // 2:(Wp - W) // 2 + W].reshape(-1, C)
     assert torch.equal(x.grad.cpu(), gref)
+
+
+# ---------------------------------------------------------------------------------------------------------------- losses
+@pytest.mark.parametrize("shape", [(3, 2, 1, 64, 64), (2, 3, 3, 20, 36), (5, 1, 17, 9)])
+def test_mse_gdl_fused(ops, dev, shape):
+    """vptr_mse_gdl_fwd / bwd vs the oracle's MSELoss + GDL in fp64 (values 1e-6, gradient 2e-6), with unequal upstream weights"""
+    gt = rn(shape, 901, 0.3)
+    pr = rn(shape, 902, 0.3)
+    pr[..., :3, :] = gt[..., :3, :]            # exact ties: sign(0) = 0 branches
+    ref_p = pr.double().requires_grad_(True)
+    lm, lg = O.mse_loss(gt.double(), ref_p), O.gdl_loss(gt.double(), ref_p)
+    (0.7 * lm + 1.9 * lg).backward()
+    x = pr.to(dev).requires_grad_(True)
+    m, g = ops.mse_gdl(x, gt.to(dev))
+    (0.7 * m + 1.9 * g).backward()
+    assert abs(float(m) - float(lm)) < 1e-6 * abs(float(lm)) and abs(float(g) - float(lg)) < 1e-6 * abs(float(lg))
+    assert rel(x.grad, ref_p.grad) < 2e-6
+
+
+@pytest.mark.parametrize("frames,h,w,C,tau", [(6, 8, 8, 528, 1.0), (3, 16, 16, 48, 0.07), (2, 5, 7, 96, 0.5), (1, 4, 4, 16, 1.0)])
+def test_bipatch_nce_fused(ops, dev, frames, h, w, C, tau):
+    """vptr_nce_fwd / bwd (normalise + scores + both cross-entropies + stop-gradient structure) vs F.normalize + the oracle's
+    BiPatchNCE in fp64: value 1e-6, both gradients 1e-5; one all-zero token exercises the eps clamp of the normalisation"""
+    L = h * w
+    g = rn((frames * L, C), 911, 1.0)
+    p = rn((frames * L, C), 912, 1.0) + 0.5 * g
+    p[1] = 0.0
+    gd, pd = g.double().requires_grad_(True), p.double().requires_grad_(True)
+
+    def as5(t):   # token-major [frames * L, C] -> (N = 1, T = frames, C, h, w)
+        return t.reshape(1, frames, h, w, C).permute(0, 1, 4, 2, 3)
+    ref = O.bipatch_nce(F.normalize(as5(gd), p=2.0, dim=2), F.normalize(as5(pd), p=2.0, dim=2), tau)
+    (1.3 * ref).backward()
+    gx, px = g.to(dev).requires_grad_(True), p.to(dev).requires_grad_(True)
+    out = ops.nce_loss(gx, px, frames, L, tau)
+    (1.3 * out).backward()
+    assert abs(float(out) - float(ref)) < 2e-6 * abs(float(ref)), (float(out), float(ref))
+    assert rel(gx.grad, gd.grad) < 1e-5, rel(gx.grad, gd.grad)
+    keep = torch.ones(frames * L, dtype=torch.bool)
+    keep[1] = False                               # the zero token: d/dx of x / max(|x|, 1e-12) is 1e12 * dxh -- compare the others
+    assert rel(px.grad[keep.to(dev)], pd.grad[keep]) < 1e-5, rel(px.grad[keep.to(dev)], pd.grad[keep])
+
+
+def test_droppath_scales(ops, dev):
+    """vptr_droppath_scales: values in {0, 1/keep}, keep rates as requested, deterministic under the scope seed, different per site"""
+    ops.manual_seed(dev, 4242)
+    ops.new_seed_scope(dev)
+    keep = torch.tensor([0.9, 0.5, 0.75], device=dev)
+    a = ops.droppath_scales(keep, 20000, dev)
+    b = ops.droppath_scales(keep, 20000, dev)
+    assert torch.equal(a, b)
+    for r, k in enumerate([0.9, 0.5, 0.75]):
+        vals = torch.unique(a[r]).cpu()
+        assert all(min(abs(float(v)), abs(float(v) - 1.0 / k)) < 1e-6 for v in vals), vals
+        assert abs(float((a[r] > 0).float().mean()) - k) < 0.015
+    c = ops.droppath_scales(keep, 20000, dev, site_offset=3)
+    assert not torch.equal(a[0], c[0])
+    ops.new_seed_scope(dev)
+    assert not torch.equal(a, ops.droppath_scales(keep, 20000, dev))

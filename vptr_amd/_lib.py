@@ -91,6 +91,11 @@ SIGNATURES = {
     "vptr_im2col_nhwc": [P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "vptr_reflect_fold": [P, P, I, I, I, I, I, P],
     "vptr_conv7_in_bwd_weight": [P, P, P, I, I, I, I, I, P],
+    "vptr_mse_gdl_fwd": [P, P, P, P, P, I, I, I, P],
+    "vptr_mse_gdl_bwd": [P, P, P, P, P, I, I, I, P],
+    "vptr_nce_fwd": [P, P, P, P, I, I, I, F, P],
+    "vptr_nce_bwd": [P, P, P, P, P, P, I, I, I, F, P],
+    "vptr_droppath_scales": [P, P, I, I, P, U, P],
     "vptr_sumsq": [P, L, P, P],
     "vptr_adamw": [P, P, P, P, L, F, F, F, F, F, P, P, F, F, P],
 }
@@ -109,7 +114,7 @@ def _load():
         fn.restype = c_int
     lib.vptr_abi_version.restype = c_int
     lib.vptr_last_error.restype = ctypes.c_char_p
-    if lib.vptr_abi_version() != 5:
+    if lib.vptr_abi_version() != 6:
         raise ImportError("vptr_amd: ABI version mismatch in %s" % LIB_PATH)
     return lib
 

@@ -24,9 +24,11 @@ def _get_clones(module, n):
 
 
 class _DropPathPlan:
-    """All stochastic-depth scale vectors of one model forward in three launches instead of four per call site (~40 call
-    sites in the K64 NAR model): the sequence of (p, count) requests of a forward is recorded, and the next forward with
-    the same sequence draws one uniform matrix and evaluates floor(keep + U) / keep for every request at once."""
+    """All stochastic-depth scale vectors of one model forward in ONE launch (vptr_droppath_scales) instead of four ATen ops per call
+    site (~40 call sites in the K64 NAR model): the sequence of (p, count) requests of a forward is recorded, and the next forward
+    with the same sequence evaluates floor(keep + U) / keep for every request at once.  U comes from the counter-based hash of the
+    step's dropout seed (ops.seed_tensor), not from torch's generator: eager steps and hipGraph replays draw identical vectors, and
+    request i always hashes site DROPPATH_SITE0 + i whether it was planned or not."""
 
     def __init__(self):
         self.plan, self.rec, self.idx, self.scales = None, [], 0, None
@@ -36,11 +38,8 @@ class _DropPathPlan:
         self.rec, self.idx, self.scales = [], 0, None
         if self.plan:
             if self._keep is None or self._keep[0] != self.plan or self._keep[1] != device:
-                self._keep = (list(self.plan), device,
-                              torch.tensor([1.0 - p for p, _ in self.plan], device=device, dtype=torch.float32)[:, None])
-            keep = self._keep[2]
-            u = torch.rand((len(self.plan), max(c for _, c in self.plan)), device=device, dtype=torch.float32)
-            self.scales = torch.floor(u + keep) / keep
+                self._keep = (list(self.plan), device, torch.tensor([1.0 - p for p, _ in self.plan], device=device, dtype=torch.float32))
+            self.scales = ops.droppath_scales(self._keep[2], max(c for _, c in self.plan), device)
 
     def get(self, p, count, device):
         self.rec.append((p, count))
@@ -48,15 +47,15 @@ class _DropPathPlan:
         self.idx += 1
         if self.scales is not None and i < len(self.plan) and self.plan[i] == (p, count):
             return self.scales[i, :count]
-        self.scales = None  # the sequence changed: fall back for the rest of this forward, re-plan at its end
-        keep = 1.0 - p
-        return torch.floor(keep + torch.rand(count, device=device, dtype=torch.float32)) / keep
+        self.scales = None  # the sequence changed: single requests for the rest of this forward, re-plan at its end
+        return ops.droppath_scales(torch.full((1,), 1.0 - p, device=device, dtype=torch.float32), count, device, site_offset=i)[0]
 
     def end(self):
         self.plan = list(self.rec)
 
 
 _dp_plan = [None]  # the plan of the model forward in flight (set by VidHRFormerNAR / VidHRFormerFAR)
+_dp_loose = [0]    # running request index of blocks called outside a model forward (stand-alone use, tests)
 
 
 def _droppath_scale(p, training, count, device):
@@ -65,8 +64,9 @@ def _droppath_scale(p, training, count, device):
         return None
     if _dp_plan[0] is not None:
         return _dp_plan[0].get(p, count, device)
-    keep = 1.0 - p
-    return torch.floor(keep + torch.rand(count, device=device, dtype=torch.float32)) / keep
+    _dp_loose[0] = (_dp_loose[0] + 1) % 0x4000
+    return ops.droppath_scales(torch.full((1,), 1.0 - p, device=device, dtype=torch.float32), count, device,
+                               site_offset=0x4000 + _dp_loose[0])[0]
 
 
 class DropPath(nn.Module):

@@ -23,7 +23,33 @@ import torch.nn.functional as F
 
 from . import ops
 from ._lib import check, lib, ptr, stream
-from .model.criterion import GDL, BiPatchNCE, GANLoss, MSELoss
+from .model.criterion import GANLoss
+
+
+_HIP_NODE_TYPES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event", 7: "event_record",
+                   10: "mem_alloc", 11: "mem_free"}
+
+
+def graph_node_census(g):
+    """{node type: count} of a torch.cuda.CUDAGraph captured with keep_graph=True (hipGraphGetNodes / hipGraphNodeGetType on the
+    runtime torch itself loaded)"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    graph = ctypes.c_void_p(int(g.raw_cuda_graph()))
+    n = ctypes.c_size_t(0)
+    if hip.hipGraphGetNodes(graph, None, ctypes.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    nodes = (ctypes.c_void_p * max(n.value, 1))()
+    if n.value and hip.hipGraphGetNodes(graph, nodes, ctypes.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    out = {}
+    for i in range(n.value):
+        t = ctypes.c_int(-1)
+        if hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t)) != 0:
+            raise RuntimeError("hipGraphNodeGetType failed")
+        name = _HIP_NODE_TYPES.get(t.value, "type%d" % t.value)
+        out[name] = out.get(name, 0) + 1
+    return out
 
 
 DP_CHUNKS = 4  # grouped weight-gradient launches per step when gradients are exchanged between ranks
@@ -189,8 +215,9 @@ class NARTrainer:
             mod._vptr_frozen = True  # never stepped here: packed conv weights / eval-BN folds are cached (ops.frozen_weights)
         self.opt = FlatAdamW(self.T.parameters(), lr=lr, max_grad_norm=max_grad_norm, channel_last=_channel_last_ids(self.T))
         dev = self.opt.flat.device
-        self.mse, self.gdl = MSELoss(), GDL(alpha=1)
-        self.bpnce = BiPatchNCE(batch_size, self.T.num_future_frames, self.T.transformer.H, self.T.transformer.W, 1.0).to(dev)
+        # loss_name_list MSE / GDL(alpha=1) / BiPatchNCE(N, Tf, 8, 8, temperature 1.0) of train_NAR.py:176-179 run as the fused kernels of
+        # csrc/losses.hip (ops.mse_gdl, ops.nce_loss): plain kernel launches only, so the step can live in a hipGraph
+        self.nce_temperature = 1.0
         self.lam_pc = lam_pc
         self._bufsync = None
         if process_group is not None and torch.distributed.get_world_size(process_group) > 1:
@@ -274,11 +301,12 @@ class NARTrainer:
         grad.mul_(1.0 / self.world)
 
     def losses(self, pred_frames, future, pred_feats, future_feats):
-        a = self.T.NCE_projector(pred_feats.permute(0, 1, 3, 4, 2)).permute(0, 1, 4, 2, 3)
-        b = self.T.NCE_projector(future_feats.permute(0, 1, 3, 4, 2)).permute(0, 1, 4, 2, 3)
-        l_mse = self.mse(pred_frames, future)
-        l_gdl = self.gdl(future, pred_frames)
-        l_pc = self.bpnce(F.normalize(b, p=2.0, dim=2), F.normalize(a, p=2.0, dim=2))
+        """cal_lossT (train_NAR.py:32-47, 81-91): MSE + GDL on the frames, lam_pc * BiPatchNCE on the L2-normalised NCE projections"""
+        a = self.T.NCE_projector(pred_feats.permute(0, 1, 3, 4, 2))      # (N, T, h, w, C): token-major memory
+        b = self.T.NCE_projector(future_feats.permute(0, 1, 3, 4, 2))
+        N, T, h, w, C = a.shape
+        l_mse, l_gdl = ops.mse_gdl(pred_frames, future)
+        l_pc = ops.nce_loss(b.reshape(-1, C), a.reshape(-1, C), N * T, h * w, self.nce_temperature)
         return l_gdl + l_mse + self.lam_pc * l_pc, l_gdl, l_mse, l_pc
 
     def _step_impl(self, past, future):
@@ -326,7 +354,13 @@ class NARTrainer:
 
     def capture(self, past, future, warmup=3):
         """Capture the whole step (forward, losses, backward, clip, AdamW) into one hipGraph.  `past`/`future` give the
-        static shapes; real data is copied into the captured input buffers by `step`."""
+        static shapes; real data is copied into the captured input buffers by `step`.
+
+        The captured graph is inspected before it is instantiated: it must consist of kernel and memcpy nodes only.  A MEMSET
+        node (hipMemsetAsync under capture -- ATen's multi-block reductions zero their semaphores that way) writes garbage from
+        the second replay on with this HIP runtime (tools/memset_node_probe.py), which is what corrupted the round-2 graph
+        (F.normalize's backward in the BiPatchNCE branch); the step's own losses are plain kernels now (csrc/losses.hip) and
+        any memset node that sneaks back in raises here instead of silently training on garbage."""
         if self.pg is not None and self.world > 1:
             raise RuntimeError("graph capture of the data-parallel step is not enabled (RCCL calls stay eager)")
         self._static_past, self._static_future = past.clone(), future.clone()
@@ -337,11 +371,67 @@ class NARTrainer:
             for _ in range(warmup):
                 self._step_impl(self._static_past, self._static_future)
         torch.cuda.current_stream().wait_stream(s)
-        g = torch.cuda.CUDAGraph()
+        g = torch.cuda.CUDAGraph(keep_graph=True)
         with torch.cuda.graph(g):
             self._static_out = self._step_impl(self._static_past, self._static_future)
+        self.graph_nodes = graph_node_census(g)
+        bad = {k: v for k, v in self.graph_nodes.items() if k not in ("kernel", "memcpy", "empty")}
+        if bad:
+            g.reset()
+            raise RuntimeError("captured step holds node types that are not replay-safe on this HIP runtime: %s (all nodes: %s)"
+                               % (bad, self.graph_nodes))
+        g.instantiate()
         self._graph = g
         return g
+
+    # -- replay == eager, checked on the live model (bench.py runs this before it times a graph) -------------------------------------
+    def _snapshot(self):
+        dev = self.opt.flat.device
+        return {"flat": self.opt.flat.clone(), "m": self.opt.m.clone(), "v": self.opt.v.clone(), "step": self.opt.step_dev.clone(),
+                "buffers": [b.detach().clone() for b in self.T.buffers()], "seed": ops._master_seed(dev).clone()}
+
+    def _restore(self, snap):
+        dev = self.opt.flat.device
+        with torch.no_grad():
+            self.opt.flat.copy_(snap["flat"]); self.opt.m.copy_(snap["m"]); self.opt.v.copy_(snap["v"]); self.opt.step_dev.copy_(snap["step"])
+            for b, v in zip(self.T.buffers(), snap["buffers"]):
+                b.copy_(v)
+            ops._master_seed(dev).copy_(snap["seed"])
+        ops._seed_scope.pop(ops._dev_key(dev), None)
+        if self.opt.planes is not None:
+            self.opt.planes.refresh()
+
+    def verify_graph(self, past, future, steps=3, rtol=2e-3):
+        """`steps` eager steps and `steps` replays from the same state (parameters, Adam moments, BatchNorm statistics, dropout seed)
+        must report the same loss terms / gradient norm and end at the same parameters; the state is restored afterwards.  Dropout
+        and DropPath masks come from the device-resident counter seed, so both runs draw identical masks; the residual difference is
+        the order of fp32 atomics.  -> (ok, report)"""
+        if self._graph is None:
+            raise RuntimeError("verify_graph: capture() first")
+        snap = self._snapshot()
+        g, runs = self._graph, {}
+        for mode in ("eager", "graph"):
+            self._restore(snap)
+            self._graph = g if mode == "graph" else None
+            recs = []
+            for _ in range(steps):
+                out = self.step(past, future)
+                recs.append({k: float(v) for k, v in out.items()})
+            runs[mode] = (recs, self.opt.flat.clone())
+        self._graph = g
+        self._restore(snap)
+        worst, where = 0.0, None
+        for i, (re_, rg) in enumerate(zip(runs["eager"][0], runs["graph"][0])):
+            for k in re_:
+                a, b = re_[k], rg[k]
+                d = abs(a - b) / (abs(a) + 1e-6) if (b == b and abs(b) < 1e30) else float("inf")
+                if d > worst:
+                    worst, where = d, (i, k, a, b)
+        pe, pg = runs["eager"][1].double(), runs["graph"][1].double()
+        prel = float((pe - pg).norm() / pe.norm())
+        ok = worst <= rtol and prel <= 1e-4
+        return ok, {"steps": steps, "worst_term_rel_diff": worst, "worst_term": where, "param_rel_l2": prel,
+                    "eager_last": runs["eager"][0][-1], "graph_last": runs["graph"][0][-1]}
 
     @torch.no_grad()
     def predict(self, past):
@@ -371,7 +461,6 @@ class FARTrainer(NARTrainer):
         for mod in list(self.enc.modules()) + list(self.dec.modules()):
             mod._vptr_frozen = True
         self.opt = FlatAdamW(self.T.parameters(), lr=lr, max_grad_norm=max_grad_norm, channel_last=_channel_last_ids(self.T))
-        self.mse, self.gdl = MSELoss(), GDL(alpha=1)
         self._bufsync = None   # the FAR transformer has no BatchNorm (LayerNorm conv-FFNs): nothing to broadcast per forward
         self._graph = None
 
@@ -388,8 +477,7 @@ class FARTrainer(NARTrainer):
         if self.disc is not None:                                            # cal_lossD(VPTR_Disc, pred_frames, future_frames) :72
             extra = self._disc_update(pred_frames, future)
         real = torch.cat([past[:, 1:], future], dim=1)                       # :80
-        l_mse = self.mse(pred_frames, real)                                  # cal_lossT :32-46
-        l_gdl = self.gdl(real, pred_frames)
+        l_mse, l_gdl = ops.mse_gdl(pred_frames, real)                        # cal_lossT :32-46
         loss = l_gdl + l_mse
         if self.disc is not None:
             t_gan = self.gan(self.disc(pred_frames.flatten(0, 1)), True)
@@ -421,7 +509,6 @@ class AETrainer:
         self.opt_G = FlatAdamW(list(enc.parameters()) + list(dec.parameters()), lr=lr, betas=betas, weight_decay=0.0)
         self.opt_D = FlatAdamW(list(disc.parameters()), lr=lr, betas=betas, weight_decay=0.0)
         self.gan = GANLoss(gan_mode, target_real_label=1.0, target_fake_label=0.0).to(self.opt_G.flat.device)
-        self.mse, self.gdl = MSELoss(), GDL(alpha=1)
         self.lam_gan = lam_gan
 
     def step(self, past, future):
@@ -447,7 +534,7 @@ class AETrainer:
         for p in self.disc.parameters():
             p.requires_grad_(False)
         l_gan = self.gan(self.disc(rec.flatten(0, 1)), True)
-        l_mse, l_gdl = self.mse(rec, x), self.gdl(x, rec)
+        l_mse, l_gdl = ops.mse_gdl(rec, x)
         loss_G = self.lam_gan * l_gan + l_mse + l_gdl
         loss_G.backward()
         self.opt_G.step()
