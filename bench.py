@@ -342,6 +342,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): --batch clips per GPU; strong: the reference's DistributedSampler semantics, a fixed "
                          "--global-batch split as global // world per rank (utils/dataset.py:72)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="one GPU only: bring up a ONE-rank RCCL process group and run the step through the multi-rank code path (chunked "
+                         "weight-gradient launches + asynchronous all-reduces of the 473.5 MB gradient slab on c10d's RCCL stream); eager")
     ap.add_argument("--global-batch", type=int, default=64, help="global batch of --scaling strong (train_FAR_mp.py:300 uses 64)")
     args = ap.parse_args()
 
@@ -364,6 +367,12 @@ def main():
         else:
             torch.distributed.init_process_group(backend, rank=rank, world_size=world)
         pg = torch.distributed.group.WORLD
+    elif args.force_exchange:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ["VPTR_DP_FORCE_EXCHANGE"] = "1"
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        pg = torch.distributed.group.WORLD
 
     import vptr_amd.ops as ops
     from vptr_amd.train import NARTrainer
@@ -378,8 +387,8 @@ def main():
     trainer = NARTrainer(enc, dec, T, batch_size=args.batch, lr=1e-4, max_grad_norm=1.0, lam_pc=0.1, process_group=pg)
     past, fut = synth_batch(args.batch, rank, dev)
 
-    use_graph = bool(args.graph) and world == 1
-    graph_note = "eager"
+    use_graph = bool(args.graph) and world == 1 and not args.force_exchange
+    graph_note = "eager (one-rank RCCL group, forced gradient exchange)" if args.force_exchange else "eager"
     graph_check = None
     if use_graph:
         try:
@@ -455,6 +464,7 @@ def main():
         print(json.dumps(res))
     if world > 1:
         torch.distributed.barrier()
+    if world > 1 or args.force_exchange:
         torch.distributed.destroy_process_group()
 
 

@@ -1,0 +1,121 @@
+"""The data-parallel exchange on the REAL backend: torch.distributed "nccl" (= RCCL) with a one-rank group on the one GPU this box
+has (RCCL refuses two ranks on one device, so world size 1 is what can execute here).  VPTR_DP_FORCE_EXCHANGE=1 sends the step down
+the multi-rank code path of train_NAR_mp.py:94-118,167,191-198 as this build re-does it (`NARTrainer._backward_and_exchange`):
+chunked grouped weight-gradient launches, asynchronous all-reduces of <= 64 MB slab pieces on c10d's RCCL stream, Work.wait()
+before the optimizer.  What this pins: ProcessGroupNCCL's stream / event ordering against the weight-gradient GEMMs (gloo's
+synchronous host path says nothing about it) -- forced-overlap == forced-plain == no process group, for the gradient slab and the
+post-step parameters, on the tiny FAR model and on the K64 NAR model (473.5 MB slab, 8 pieces)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", VPTR_FUSED_STATS="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        import bench
+        import vptr_amd.model as pkg
+        from helpers import build_transformer, jload, load
+        from oracle import fill
+        from vptr_amd import ops
+        from vptr_amd.train import FARTrainer, NARTrainer
+        res = {"backend": dist.get_backend()}
+        # a bare collective first: the RCCL communicator really comes up and reduces
+        t = torch.arange(1 << 20, device=dev, dtype=torch.float32)
+        w = dist.all_reduce(t, async_op=True)
+        w.wait()
+        res["allreduce_ok"] = bool(torch.equal(t, torch.arange(1 << 20, device=dev, dtype=torch.float32)))
+
+        def rel(a, b):
+            return float((a.double() - b.double()).norm() / b.double().norm())
+
+        def run_far(mode):
+            os.environ["VPTR_DP_FORCE_EXCHANGE"] = "0" if mode == "none" else "1"
+            os.environ["VPTR_DP_OVERLAP"] = "0" if mode == "plain" else "1"
+            ops.unregister_flat_slabs()
+            z = load("step_far_tiny")
+            cfg, meta = jload(z, "cfg"), jload(z, "meta")
+            enc = pkg.VPTREnc(1, meta["feat"], 3, "reflect")
+            dec = pkg.VPTRDec(1, meta["feat"], 3, meta["out_layer"], "reflect")
+            T = build_transformer(pkg, cfg, True)
+            fill.apply_fill(enc, meta["seed"]); fill.apply_fill(dec, meta["seed"] + 10); fill.apply_fill(T, meta["seed"] + 20)
+            tr = FARTrainer(enc.to(dev), dec.to(dev), T.to(dev), lr=1e-4, max_grad_norm=1.0,
+                            process_group=None if mode == "none" else dist.group.WORLD)
+            grads = []
+            for s in range(2):
+                past = fill.rand_input((4, cfg["Tp"], 1, meta["HW"], meta["HW"]), meta["seed"] + 100 + s).to(dev)
+                fut = fill.rand_input((4, cfg["Tf"], 1, meta["HW"], meta["HW"]), meta["seed"] + 200 + s).to(dev)
+                tr.step(past, fut)
+                grads.append(tr.opt.grad.detach().clone())
+            return grads, tr.opt.flat.detach().clone()
+
+        g_ov, p_ov = run_far("overlap")
+        g_pl, p_pl = run_far("plain")
+        g_no, p_no = run_far("none")
+        res["far_grad_overlap_vs_none"] = max(rel(a, b) for a, b in zip(g_ov, g_no))
+        res["far_grad_plain_vs_none"] = max(rel(a, b) for a, b in zip(g_pl, g_no))
+        res["far_param_overlap_vs_none"] = rel(p_ov, p_no)
+
+        def run_k64(mode):
+            os.environ["VPTR_DP_FORCE_EXCHANGE"] = "0" if mode == "none" else "1"
+            os.environ["VPTR_DP_OVERLAP"] = "1"
+            ops.unregister_flat_slabs()
+            ops.manual_seed(dev, 5)
+            enc, dec, T = bench.build_models(dev, 0.1)
+            tr = NARTrainer(enc, dec, T, batch_size=2, lr=1e-4, max_grad_norm=1.0, lam_pc=0.1,
+                            process_group=None if mode == "none" else dist.group.WORLD)
+            past, fut = bench.synth_batch(2, 0, dev)
+            outs = [{k: float(v) for k, v in tr.step(past, fut).items()} for _ in range(3)]
+            flat = tr.opt.flat.detach().clone()
+            del tr
+            torch.cuda.empty_cache()
+            return outs, flat
+
+        o_ov, f_ov = run_k64("overlap")
+        o_no, f_no = run_k64("none")
+        res["k64_terms_rel"] = max(abs(a[k] - b[k]) / (abs(b[k]) + 1e-6) for a, b in zip(o_ov, o_no) for k in a)
+        res["k64_param_rel"] = rel(f_ov, f_no)
+        res["k64_last"] = o_ov[-1]
+        q.put(res)
+    except Exception as e:  # noqa
+        import traceback
+        q.put({"error": "%s\n%s" % (e, traceback.format_exc()[-1500:])})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world1_forced_exchange():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=900)
+    p.join(120)
+    assert "error" not in res, res["error"]
+    assert res["backend"] == "nccl" and res["allreduce_ok"], res
+    assert res["far_grad_overlap_vs_none"] < 1e-6 and res["far_grad_plain_vs_none"] < 1e-6, res   # one rank: sum == identity, bit for bit
+    assert res["far_param_overlap_vs_none"] < 1e-6, res
+    assert res["k64_terms_rel"] < 2e-3 and res["k64_param_rel"] < 1e-5, res       # dropout 0.1 + atomics-accumulated statistics
+    assert 0.0 <= res["k64_last"]["T_GDL"] <= 4.0, res

@@ -69,10 +69,11 @@ class BufferSync:
                 off += n
 
 
-def allreduce_mean_(flat, group=None, bucket_elems=16 << 20):
-    """In-place mean over ranks of a flat tensor, in buckets of `bucket_elems` elements (64 MB fp32 by default)."""
+def allreduce_mean_(flat, group=None, bucket_elems=16 << 20, force=False):
+    """In-place mean over ranks of a flat tensor, in buckets of `bucket_elems` elements (64 MB fp32 by default).  force: issue the
+    collectives on a one-rank group too (functional runs of the RCCL path on a one-GPU box)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return flat
     n = flat.numel()
     for off in range(0, n, bucket_elems):

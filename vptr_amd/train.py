@@ -262,17 +262,21 @@ class NARTrainer:
 
     # -- data-parallel gradient exchange: a few large RCCL all-reduces on the flat gradient slab ---------------------
     def _allreduce_grads(self):
-        if self.pg is None or self.world == 1:
+        if self.pg is None or (self.world == 1 and os.environ.get("VPTR_DP_FORCE_EXCHANGE") != "1"):
             return
         from .parallel import allreduce_mean_
-        allreduce_mean_(self.opt.grad, self.pg, self.bucket_elems)
+        allreduce_mean_(self.opt.grad, self.pg, self.bucket_elems, force=True)
 
     def _backward_and_exchange(self, loss):
         """loss.backward(), the grouped weight-gradient GEMMs and the data-parallel gradient exchange.  With more than one
         rank the weight gradients are flushed in DP_CHUNKS grouped launches ordered by slab address; as soon as a chunk has
         been enqueued, the slab range below the next chunk's first destination is final and its all-reduce is issued
         asynchronously (RCCL runs it on its own stream), overlapping the next chunk's GEMM."""
-        if self.pg is None or self.world == 1 or os.environ.get("VPTR_DP_OVERLAP", "1") == "0":
+        # VPTR_DP_FORCE_EXCHANGE=1: take the exchange path on a one-rank group too (a one-GPU box can then drive c10d's RCCL backend
+        # -- its own stream, async Work objects, event ordering against the weight-gradient launches -- through the same code the
+        # 8-GPU job runs: tests/test_rccl_gpu.py, bench.py --force-exchange)
+        force = self.pg is not None and os.environ.get("VPTR_DP_FORCE_EXCHANGE") == "1"
+        if self.pg is None or (self.world == 1 and not force) or os.environ.get("VPTR_DP_OVERLAP", "1") == "0":
             loss.backward()
             ops.flush_wgrads()  # no-op: the grouped weight-gradient launch already ran at the end of backward
             self._allreduce_grads()
