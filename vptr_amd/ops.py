@@ -28,6 +28,8 @@ class _Config:
     """
     gemm_precision = 3
     group_wgrads = True
+    # plain parameters (no FlatAdamW slab) join the grouped launch through their own .grad (ops._loose_grad_for); 0 = A/B switch
+    group_loose_wgrads = os.environ.get("VPTR_LOOSE_WGRADS", "1") != "0"
     weights_frozen = False  # set by the frozen_weights scope only
     # P16 ("convert once") operands for every nn.Linear-shaped GEMM whose dimensions are multiples of 16 (precision 3 only):
     # the GEMMs stage pre-split bf16 hi / lo granules with global_load_lds instead of splitting fp32 in their main loops
@@ -282,10 +284,14 @@ class WeightPlanes:
     def refresh(self):
         check(lib.vptr_weight_planes(ptr(self.table), ptr(self.starts), len(self.weights), self.tiles, stream()), "vptr_weight_planes")
         self.versions = [t[5]._version for t in self.index]
+        self.dirty = False
+
+    dirty = False   # set by invalidate_weight_planes(): a write torch's version counters cannot see (.data, slab writes, c10d collectives)
 
     def stale(self):
-        """True when a registered weight changed through torch (load_state_dict, an external optimizer) since the last refresh"""
-        return any(v != t[5]._version for v, t in zip(self.versions, self.index))
+        """True when a registered weight changed through torch (load_state_dict, an external optimizer) since the last refresh, or
+        when somebody declared the planes invalid (invalidate_weight_planes)"""
+        return self.dirty or any(v != t[5]._version for v, t in zip(self.versions, self.index))
 
     def lookup(self, W):
         """(Wp, ld, WT, ld) for W = a registered weight or a whole-row slice of one, or None; stale planes (the weight changed
@@ -299,7 +305,7 @@ class WeightPlanes:
             return None
         if w.stride(0) != K or W.shape[1] != K or W.stride(0) != K or (p - base) % (K * 4):
             return None
-        if self.versions[i] != w._version:
+        if self.dirty or self.versions[i] != w._version:
             self.refresh()
         r0, n = (p - base) // (K * 4), W.shape[0]
         if r0 % 16 or n % 16 or r0 + n > N:
@@ -321,6 +327,20 @@ _WPLANE_CACHE_BYTES = 3 << 30
 def register_weight_planes(store):
     import weakref
     _wplane_stores.append(weakref.ref(store))
+
+
+def invalidate_weight_planes():
+    """Declare every cached P16 weight image stale.  The images are keyed on torch's tensor version counters, which miss writes
+    through `param.data`, direct writes to an optimizer slab and the in-place c10d collectives (dist.broadcast bumps no version):
+    vptr_amd.parallel.broadcast_module / _broadcast_any and FlatAdamW.load_state_dict call this; so must any other code that
+    rewrites weights behind autograd's back.  The next GEMM that needs a weight's planes rebuilds them (one launch per store)."""
+    for ref in list(_wplane_stores):
+        st = ref()
+        if st is None:
+            _wplane_stores.remove(ref)
+        else:
+            st.dirty = True
+    _wplane_cache.clear()
 
 
 def weight_planes_for(W):
@@ -602,6 +622,12 @@ def unregister_flat_slabs():
     del _flat_slabs[:]
 
 
+def unregister_flat_slab(param_slab):
+    """drop the registration of one slab (FlatAdamW.close / __del__)"""
+    base = param_slab.data_ptr()
+    _flat_slabs[:] = [e for e in _flat_slabs if e[0] != base]
+
+
 def flat_grad_for(t):
     """Gradient-slab view for a parameter tensor (or a contiguous slice of one) that lives in a registered slab."""
     if t is None or not _flat_slabs or not t.is_contiguous():
@@ -617,18 +643,54 @@ def flat_grad_for(t):
     return None
 
 
+def _loose_grad_for(t):
+    """Gradient destination for a parameter OUTSIDE any flat slab (the reference's scripts: plain nn.Parameters, torch.optim.AdamW,
+    zero_grad(set_to_none=True)): a view into the `.grad` of the leaf parameter that `t` is (or is a contiguous view of -- a row
+    block of in_proj_weight, a 1x1 conv weight seen as [N, K]), created zero-filled if it is None.  The weight gradient can then
+    join the grouped end-of-backward launch exactly like a slab-backed one, instead of running as a launch of its own (12-60 tiles
+    with a 10 240-token K loop on 256 CUs: 196 of those made the script-style step 2.7x slower than NARTrainer's).  Returns None
+    -- the caller then hands a fresh tensor to autograd -- outside a backward pass, in a torch.distributed job (DDP's reducer must
+    see gradients arrive through AccumulateGrad hooks) and for parameters with hooks."""
+    if not (config.group_wgrads and config.group_loose_wgrads) or t is None or not t.is_contiguous():
+        return None
+    if torch._C._current_graph_task_id() < 0:
+        return None
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return None
+    base = t if t.is_leaf else t._base
+    if base is None or not base.is_leaf or not base.requires_grad or not base.is_contiguous() or base.dtype != torch.float32:
+        return None
+    if base._backward_hooks or getattr(base, "_post_accumulate_grad_hooks", None):
+        return None
+    off = (t.data_ptr() - base.data_ptr()) // 4
+    if off < 0 or off + t.numel() > base.numel():
+        return None
+    if base.grad is None:
+        base.grad = torch.zeros_like(base)
+    elif not base.grad.is_contiguous() or base.grad.dtype != torch.float32:
+        return None
+    return base.grad.view(-1)[off:off + t.numel()].view(t.shape)
+
+
+def grad_dest_for(t):
+    """where a parameter's gradient is accumulated in place: its range of a registered flat gradient slab, else its own `.grad`"""
+    d = flat_grad_for(t)
+    return d if d is not None else _loose_grad_for(t)
+
+
 def _linear_param_grads(g, x, W, bias_ref, need_w, need_b, alpha=1.0, p16=False):
     """dW[N,K] (+)= alpha * g^T . x and db (+)= alpha * column sums of g for y = x W^T + b with g = dL/dy [M, N].  With a flat
-    gradient slab the products are recorded for the grouped end-of-backward launch (which also takes the bias gradient from
-    its A staging registers) and (None, None) is returned; otherwise fresh tensors are."""
+    gradient slab -- or, for plain parameters, their own `.grad` (_loose_grad_for) -- the products are recorded for the grouped
+    end-of-backward launch (which also takes the bias gradient from its A staging registers) and (None, None) is returned;
+    otherwise fresh tensors are."""
     N, K = W.shape
     M = x.shape[0]
     dW = db = None
     bias_done = False
     if need_w:
-        slab = flat_grad_for(W)          # accumulate straight into the flat gradient slab when there is one
+        slab = grad_dest_for(W)          # accumulate straight into the flat gradient slab / the parameter's .grad
         if slab is not None and config.group_wgrads:
-            bslab = flat_grad_for(bias_ref) if (bias_ref is not None and need_b) else None
+            bslab = grad_dest_for(bias_ref) if (bias_ref is not None and need_b) else None
             defer_wgrad(g, x, slab, N, K, M, db=bslab, alpha=alpha, p16=p16)   # grouped at the end of backward
             bias_done = bslab is not None
         elif p16:
@@ -707,7 +769,7 @@ class _LinearFn(torch.autograd.Function):
             raise RuntimeError("linear: a ReLU epilogue saves its output for backward and cannot write it as P16")
         ctx.save_for_backward(xs, W, pre if act == ACT_GELU else (y if act == ACT_RELU else None), rowscale)
         ctx.cfg = (alpha, act, rs_div, rs_mod, dropout_p, site, b is not None, residual is not None, use, dy_p16)
-        ctx.bias_ref = b.detach() if b is not None else None  # only its address is used (flat gradient slab lookup)
+        ctx.bias_ref = b   # the parameter (or a view of it) itself: gradient-destination lookup (flat slab by address, else its .grad)
         return y
 
     @staticmethod
@@ -719,8 +781,8 @@ class _LinearFn(torch.autograd.Function):
         N = W.shape[0]
         # a bare output scale (the q projections' head_dim^-0.5) needs no pass of its own when the weight / bias gradients go
         # through the grouped launch: dx = alpha * (dy . W) and dW = alpha * (dy^T . x) take alpha in their GEMM epilogues
-        wslab = flat_grad_for(W) if ctx.needs_input_grad[1] else None
-        bslab0 = flat_grad_for(ctx.bias_ref) if (has_b and ctx.needs_input_grad[2]) else None
+        wslab = grad_dest_for(W) if ctx.needs_input_grad[1] else None
+        bslab0 = grad_dest_for(ctx.bias_ref) if (has_b and ctx.needs_input_grad[2]) else None
         fold_alpha = (alpha != 1.0 and act == ACT_NONE and rowscale is None and p == 0 and config.group_wgrads
                       and ctx.needs_input_grad[1] and wslab is not None and (not (has_b and ctx.needs_input_grad[2]) or bslab0 is not None))
         galpha = alpha if fold_alpha else 1.0
@@ -807,7 +869,7 @@ class _MlpFn(torch.autograd.Function):
         gemm_raw(h, W2p, y, M, N, Fh, A_P16, B_P16, lda=Fh, ldb=ld2, bias=b2, dropout_p=p, site=site2, residual=res, seed=ctx.seed)
         ctx.save_for_backward(xs, W1, W2, h, pre)
         ctx.cfg = (p, site1, site2, residual is not None)
-        ctx.b1_ref, ctx.b2_ref = b1.detach(), b2.detach()   # only their addresses are used (flat gradient slab lookup)
+        ctx.b1_ref, ctx.b2_ref = b1, b2   # the parameters themselves: gradient-destination lookup (grad_dest_for)
         return y
 
     @staticmethod
@@ -1084,7 +1146,7 @@ class _ProjAttnFn(torch.autograd.Function):
             check(lib.vptr_tattn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), Nb, Tq, Tk, HW, N, nh, causal, p, ptr(ctx.seed), site,
                                      int(o_p16), stream()), "vptr_tattn_fwd")
         ctx.save_for_backward(xq, xk, xv, Wq, Wk, Wv, q, k, v, table, rel_index)
-        ctx.bias_refs = tuple(b.detach() if b is not None else None for b in (bq, bk, bv))
+        ctx.bias_refs = (bq, bk, bv)   # the parameters (or views of them) themselves: gradient-destination lookup
         ctx.cfg = (kind, geom, nh, p, site, alpha, same_qk, same_v, merge_v, use)
         return o
 

@@ -23,6 +23,16 @@ def _broadcast_any(t, src, group):
         tmp = t.contiguous()
         dist.broadcast(tmp, src, group=group)
         t.copy_(tmp)
+    _planes_dirty()
+
+
+def _planes_dirty():
+    """c10d collectives write tensors without bumping autograd's version counters: cached P16 weight images must be rebuilt"""
+    try:
+        from . import ops
+    except ImportError:      # CPU-only host (gloo tests of this module): no HIP library, no planes
+        return
+    ops.invalidate_weight_planes()
 
 
 def broadcast_module(module, src=0, group=None):

@@ -151,6 +151,19 @@ class FlatAdamW:
                         raise ValueError("FlatAdamW.load_state_dict: per-parameter step counts differ (%g vs %g)" % (s_i, step))
                     step = s_i
             self.step_dev.fill_(0.0 if step is None else step)
+        ops.invalidate_weight_planes()   # a checkpoint load usually rewrites the parameters too (possibly through .data)
+
+    def close(self):
+        """drop this optimizer's process-wide registrations (gradient-slab lookup, weight planes); also runs when it is collected"""
+        if getattr(self, "flat", None) is not None:
+            ops.unregister_flat_slab(self.flat)
+        self.planes = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: interpreter shutdown
+            pass
 
     def zero_grad(self):
         p0 = self.params[0]
@@ -544,3 +557,29 @@ class AETrainer:
         self.opt_G.step()
         return {"AEgan": l_gan.detach(), "AE_MSE": l_mse.detach(), "AE_GDL": l_gdl.detach(), "AE_total": loss_G.detach(),
                 "Dtotal": loss_D.detach(), "Dfake": l_fake.detach(), "Dreal": l_real.detach()}
+
+
+def script_style_nar_iter(enc, dec, transformer, optimizer, past, future, mse_loss, gdl_loss, bpnce, lam_pc=0.1, max_grad_norm=1.0):
+    """One stage-2 iteration the way the reference's OWN script drives the `model` package (train_NAR.py:49-107 without the GAN
+    branch): module calls, `zero_grad(set_to_none=True)`, the criterion classes + F.normalize, `loss.backward()`,
+    `nn.utils.clip_grad_norm_`, a stock `torch.optim` optimizer -- no NARTrainer, no flat slab, no fused losses.  This is what
+    "train_NAR.py drops in unchanged" executes on this package; tests/test_dropin_gpu.py pins it against the reference's step
+    records and bench.py times it beside the NARTrainer step (`other_configs.drop_in_single_iter`)."""
+    with torch.no_grad():
+        past_feats = enc(past)
+        future_feats = enc(future)
+    transformer = transformer.train()
+    transformer.zero_grad(set_to_none=True)
+    dec.zero_grad(set_to_none=True)
+    pred_feats = transformer(past_feats)
+    pred_frames = dec(pred_feats)
+    pf = transformer.NCE_projector(pred_feats.permute(0, 1, 3, 4, 2)).permute(0, 1, 4, 2, 3)
+    gf = transformer.NCE_projector(future_feats.permute(0, 1, 3, 4, 2)).permute(0, 1, 4, 2, 3)
+    l_mse = mse_loss(pred_frames, future)
+    l_gdl = gdl_loss(future, pred_frames)
+    l_pc = bpnce(F.normalize(gf, p=2.0, dim=2), F.normalize(pf, p=2.0, dim=2))
+    loss = l_gdl + l_mse + lam_pc * l_pc
+    loss.backward()
+    gn = torch.nn.utils.clip_grad_norm_(transformer.parameters(), max_norm=max_grad_norm, norm_type=2)
+    optimizer.step()
+    return {"T_total": loss.detach(), "T_GDL": l_gdl.detach(), "T_MSE": l_mse.detach(), "T_bpc": l_pc.detach(), "grad_norm": gn.detach()}
