@@ -611,6 +611,9 @@ def main():
         ("step_ae_tiny", lambda n: ae_step_case(ref, n, 1, 48, 32, 2, 2, 81)),
         ("metrics_tiny", lambda n: metrics_case(ref, n)),
         ("nar_k64_digest", lambda n: transformer_case(ref, n, k64, False, 1, 51, full=False, check64=False)),
+        # batch 4 = 2560 tokens: > 256-tile GEMM grids (the two-stage nt instantiations the batch-16 bench step runs), 4-sample BatchNorm statistics
+        ("nar_k64_digest_n4", lambda n: transformer_case(ref, n, k64, False, 4, 55, full=False, check64=False)),
+        ("step_k64_n4_digest", lambda n: step_case(ref, n, k64, 528, 64, 4, 102, steps=2, sample=1024)),
         ("nar_kth128_digest", lambda n: transformer_case(ref, n, dict(k64, Tf=40, H=16, W=16, window_size=8), False, 1, 53, full=False,
                                                           check64=False)),
         ("far_bair_digest", lambda n: transformer_case(ref, n, far, True, 1, 52, full=False, check64=False)),

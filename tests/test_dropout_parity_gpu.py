@@ -44,11 +44,24 @@ def attn_kernels(request):
 
 @pytest.mark.parametrize("far", [False, True])
 def test_dropout_and_droppath_masks_match_reference_semantics(dev, far, attn_kernels):
+    _mask_parity(dev, far, N=3, T=3, C=48, n_enc=2, n_dec=2)
+
+
+def test_dropout_masks_k64_layout(dev):
+    """the same check on the bench model's own layout: VPTRFormerNAR(10, 10, 8, 8, 528, 8 heads, 4 encoder + 8 decoder blocks) -- 12
+    blocks x 16 call-site ids, 640-token P16 GEMM epilogues, F = 2112 conv-FFN masks -- at batch 1 with dropout 0.1 and DropPath on"""
+    # output and input gradient at the 1e-3 bar; parameter gradients at 2e-3: the worst one (encoder.layers.0.norm2.bias, 12 blocks of
+    # backward away from the loss, batch-1 BatchNorm statistics behind it) measures 1.0e-3 against the fp64 oracle and 1.1e-3 against
+    # the fp32 one -- accumulated split-bf16 operand rounding (2^-17 per GEMM operand), not a mask: a wrong mask shows as O(0.1)
+    _mask_parity(dev, False, N=1, T=10, C=528, n_enc=4, n_dec=8, param_tol=2e-3)
+
+
+def _mask_parity(dev, far, N, T, C, n_enc, n_dec, ref_dtype=torch.float32, param_tol=TOL):
     import vptr_amd.model as pkg
     import vptr_amd.model.vidhrformer as V
     from vptr_amd import ops
-    N, T, H, W, C, nh, ws = 3, 3, 8, 8, 48, 8, 4
-    cfg = dict(Tp=T, Tf=T, H=H, W=W, C=C, nhead=nh, window_size=ws, num_encoder_layers=2, num_decoder_layers=2, rpe=True)
+    H, W, nh, ws = 8, 8, 8, 4
+    cfg = dict(Tp=T, Tf=T, H=H, W=W, C=C, nhead=nh, window_size=ws, num_encoder_layers=n_enc, num_decoder_layers=n_dec, rpe=True)
     m = build_transformer(pkg, cfg, far, dropout=P_DROP)
     fill.apply_fill(m, 321)
     P = {k: v.detach().clone() for k, v in m.state_dict().items()}
@@ -114,23 +127,24 @@ def test_dropout_and_droppath_masks_match_reference_semantics(dev, far, attn_ker
     assert 0.08 < dropped < 0.12, dropped          # the masks really are ~10 % zeros (element-weighted: DropPath vectors are tiny)
 
     # ---- oracle with the injected masks
-    Pt = {k: v.clone() for k, v in P.items()}
+    Pt = {k: (v.to(ref_dtype) if v.is_floating_point() else v.clone()) for k, v in P.items()}
+    masks = {k: v.to(ref_dtype) for k, v in masks.items()}
     for k, v in Pt.items():
         if v.is_floating_point() and not (k.endswith("running_mean") or k.endswith("running_var") or k in ("temporal_pos", "lw_pos", "Tlw_pos")):
             v.requires_grad_(True)
-    xr = x.clone().requires_grad_(True)
+    xr = x.to(ref_dtype).requires_grad_(True)
     fwd = O.far_forward if far else O.nar_forward
     with O.dropout_masks(masks):
         ref, pre = fwd(Pt, xr, cfg, training=True, return_pre=True)
-    g = fill.rand_normal(tuple(ref.shape), 323)
+    g = fill.rand_normal(tuple(ref.shape), 323).to(ref_dtype)
     g = torch.where(pre.detach().abs() < 2e-3, torch.zeros_like(g), g)     # stay off the final ReLU's kink (oracle/make_golden.py)
     (ref * g).sum().backward()
     e = rel(out, ref)
     assert e < TOL, "train forward with dropout: %.3e" % e
     # sanity: without the masks the oracle is far away (the test would be vacuous otherwise)
     with torch.no_grad():
-        assert rel(fwd({k: v.detach() for k, v in Pt.items()}, x, cfg, training=True), ref) > 10 * TOL
-    (out * g.to(dev)).sum().backward()
+        assert rel(fwd({k: v.detach() for k, v in Pt.items()}, x.to(ref_dtype), cfg, training=True), ref) > 10 * TOL
+    (out * g.float().to(dev)).sum().backward()
     assert rel(xd.grad, xr.grad) < TOL, "input gradient with dropout: %.3e" % rel(xd.grad, xr.grad)
     refg = {k: v.grad for k, v in Pt.items() if v.requires_grad and v.grad is not None}
     floor = grad_floor(float(v.norm()) for v in refg.values())
@@ -140,4 +154,4 @@ def test_dropout_and_droppath_masks_match_reference_semantics(dev, far, attn_ker
             e = rel(p.grad, refg[k], floor)
             if e > worst[1]:
                 worst = (k, e)
-    assert worst[1] < TOL, "parameter gradient %s with dropout: %.3e" % worst
+    assert worst[1] < param_tol, "parameter gradient %s with dropout: %.3e" % worst

@@ -113,6 +113,44 @@ def test_wgrad_p16_grouped(ops, dev):
             assert rel(db, rb) < TOL3, i
 
 
+def test_wgrad_p16_grouped_bench_size(ops, dev):
+    """the grouped tn launch at the token count of the timed step (T = 10 240: 320 K-steps per tile) on the two weight shapes that
+    dominate it, (2112, 528) and (528, 2112), plus a 528 x 528 problem with a bias gradient -- checked on GPU in fp64 against the
+    P16-decoded operands (what the kernel is given), so the only error left is the kernel's own fp32 accumulation"""
+    T = 10240
+    probs = [(2112, 528), (528, 2112), (528, 528)]
+    keep = []
+    for i, (N, K) in enumerate(probs):
+        gd = ops.to_p16(torch.randn((T, N), device=dev, generator=torch.Generator(device=dev).manual_seed(50 + i)) * 0.05)
+        xd = ops.to_p16(torch.randn((T, K), device=dev, generator=torch.Generator(device=dev).manual_seed(60 + i)))
+        dW, db = torch.zeros((N, K), device=dev), torch.zeros((N,), device=dev)
+        keep.append((gd, xd, dW, db))
+        ops.defer_wgrad(gd, xd, dW, N, K, T, db=db, alpha=1.0, p16=True)
+    ops.flush_wgrads()
+    for i, (gd, xd, dW, db) in enumerate(keep):
+        g64, x64 = ops.p16_decode(gd).double(), ops.p16_decode(xd).double()
+        assert rel(dW, g64.t() @ x64) < TOL3, i
+        assert rel(db, g64.sum(0)) < TOL3, i
+
+
+@pytest.mark.parametrize("M,N,K", [(10240, 2112, 528), (10240, 528, 2112), (10240, 528, 528), (2560, 2112, 528)])
+def test_gemm_p16_nt_bench_size(ops, dev, M, N, K):
+    """the nt instantiations the timed step launches: > 256-tile grids (two-stage loop) and the 240-tile N = 528 grids (three-stage
+    loop), lean epilogue (bias + residual) and the GELU + saved pre-activation + P16-output epilogue of fc1 / linear1"""
+    gen = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn((M, K), device=dev, generator=gen)
+    W = torch.randn((N, K), device=dev, generator=gen) * K ** -0.5
+    b, r = torch.randn((N,), device=dev, generator=gen), torch.randn((M, N), device=dev, generator=gen)
+    xp, Wp = ops.to_p16(x), ops.to_p16(W)
+    ref_pre = ops.p16_decode(xp).double() @ ops.p16_decode(Wp).double().t() + b.double()
+    y = torch.empty((M, N), device=dev)
+    ops.gemm_raw(xp, Wp, y, M, N, K, ops.A_P16, ops.B_P16, bias=b, residual=r)
+    assert rel(y, ref_pre + r.double()) < TOL3
+    yp, pre = torch.empty((M, N), device=dev), torch.empty((M, N), device=dev)
+    ops.gemm_raw(xp, Wp, yp, M, N, K, ops.A_P16, ops.B_P16, bias=b, act=ops.ACT_GELU, Dpre=pre, d_p16=True)
+    assert rel(pre, ref_pre) < TOL3 and rel(ops.p16_decode(yp), F.gelu(ref_pre)) < TOL3
+
+
 def test_linear_autograd_p16(ops, dev):
     """ops.linear through the P16 kernels (inputs converted on the fly, weights through the plane cache) vs torch autograd,
     including a chain in which the first layer's output and the second layer's incoming gradient never exist as fp32"""
