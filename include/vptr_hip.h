@@ -122,6 +122,12 @@ typedef struct vptr_gemm_desc {
      vptr_norm_act_fwd(raw_stats = ...) turns them into mean / rstd -- no separate statistics pass over D. */
   float* frame_stats;
   int frame_rows;
+  /* vptr_gemm_grouped with token-major P16 operands only: != 0 stores the product TRANSPOSED, D[n * ldd + m] (+)= alpha * acc[m][n]
+     (D is [N, ldd]), and a_rowsum then receives the column sums of the B operand: a_rowsum[n] += alpha * sum_t B[t][n].  The host
+     uses it to put the 176-wide tile side on the dimension it divides: dW[528][2112] = dY^T . X is computed as X^T . dY (A = X,
+     B = dY: 17 x 3 tiles instead of 5 x 12 with one eighth-full row tile in five) and lands in dW's own layout; the bias gradient
+     (column sums of dY) rides in a wave row of the last row tile that lies beyond M (needs >= 32 such rows: M % 128 in 1..96). */
+  int d_transposed;
 } vptr_gemm_desc;
 
 int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream);

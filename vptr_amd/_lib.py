@@ -40,6 +40,7 @@ class GemmDesc(ctypes.Structure):
         ("d_p16", c_int),
         ("act_grad_src", c_void_p),
         ("frame_stats", c_void_p), ("frame_rows", c_int),
+        ("d_transposed", c_int),
     ]
 
 

@@ -296,10 +296,10 @@ __device__ __forceinline__ bf16x8 p16_tr_frag(const unsigned char* st, const int
 
 template <int NSTAGE>   // 2: two workgroups per CU; 3: one workgroup per CU with the DMA two K-steps ahead (experiment, VPTR_WGRAD_STAGES=3)
 __global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
-                                                                const int count) {
+                                                                const int count, const int xmode) {
   constexpr int BN = 176;
   extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
-  const int lg = xcd_logical_block();
+  const int lg = xmode == 1 ? (int)blockIdx.x : xcd_logical_block();
   int lo = 0, hi = count - 1;  // last g with tile_start[g] <= lg (workgroup-uniform scalar search)
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -368,7 +368,9 @@ __global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kerne
   }
   // bias gradient: column tile 0 only, odd wave column, its 6th (otherwise idle) fragment multiplies by ones: acc[mi][5][r] =
   // sum_t G[t][row] for every column of the fragment
-  const bool want_rowsum = p.a_rowsum != nullptr && n0 == 0 && wn == 1;   // wave-uniform
+  const bool flip = p.d_transposed != 0;   // D stored transposed; a_rowsum = column sums of B, taken by a wave row beyond M (see vptr_hip.h)
+  const bool want_rowsum = !flip && p.a_rowsum != nullptr && n0 == 0 && wn == 1;   // wave-uniform
+  const bool colsum_wave = flip && p.a_rowsum != nullptr && m0 + GBM > NG && wm == (NG - m0 + 31) / 32;   // wave-uniform: first wave row entirely beyond M
   const __bf16 one = (__bf16)1.0f, zero = (__bf16)0.0f;
   const bf16x8 ones = {one, one, one, one, one, one, one, one};
   const bf16x8 zeros = {zero, zero, zero, zero, zero, zero, zero, zero};
@@ -386,13 +388,16 @@ __global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kerne
     } else if (kt + 1 < nk) {
       issue(kt + 1, (kt + 1) & 1);
     }
-    if (!rows_live) continue;   // wave-uniform: this wave's 32 rows lie beyond NG (the last row tile of a 528-row problem keeps 16 of 128)
+    if (!rows_live && !colsum_wave) continue;   // wave-uniform: this wave's 32 rows lie beyond NG (the last row tile of a 528-row problem keeps 16 of 128)
     const unsigned char* st = p16_smem + (NSTAGE == 3 ? kt % 3 : (kt & 1)) * P16_STAGE;
     bf16x8 ah[2], al[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       ah[mi] = p16_tr_frag(st, offA[mi], rb0);
       al[mi] = p16_tr_frag(st, offA[mi] + 256, rb0);
+    }
+    if (colsum_wave) {   // rows beyond M: a fragment of ONES instead -- acc[0][ni] rows all become sum_t B[t][n]
+      ah[0] = ones; al[0] = zeros; ah[1] = zeros; al[1] = zeros;
     }
     if (ttail && kt == nk - 1) {   // workgroup-uniform: zero the A values of tokens beyond T
       const int tv = T - kt * 32;  // valid tokens of this step
@@ -444,11 +449,18 @@ __global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kerne
         for (int r = 0; r < 4; ++r) {
           const int row = m0 + wm * 32 + mi * 16 + lq * 4 + r;
           if (row < NG) {
-            float* dst = p.D + (int64_t)row * p.ldd + col;
+            float* dst = flip ? p.D + (int64_t)col * p.ldd + row : p.D + (int64_t)row * p.ldd + col;
             if (p.atomic) unsafeAtomicAdd(dst, acc[mi][ni][r] * alpha);
             else *dst = acc[mi][ni][r] * alpha;
           }
         }
+    }
+  }
+  if (colsum_wave && lq == 0) {   // row 0 of the ones-fragment product: lane lr holds the column sum of column lr of every fragment
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) {
+      const int nf = wn * 6 + ni, col = n0 + nf * 16 + lr;
+      if (nf < 11 && col < KX) unsafeAtomicAdd(p.a_rowsum + col, acc[0][ni][0] * alpha);
     }
   }
   if (want_rowsum && lr == 0) {
@@ -563,8 +575,10 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
 int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* descs_dev, const int* tile_start_dev, int count, int total_tiles,
                           hipStream_t st) {
   VPTR_CHECK(proto->b_mode == VPTR_B_P16T && proto->precision == 3, "vptr_gemm_grouped(p16): both operands token-major P16, precision 3");
-  static int stages = -1;
+  static int stages = -1, xmode = 0;
   if (stages < 0) {
+    const char* xm = getenv("VPTR_WGRAD_XCD");
+    xmode = xm ? atoi(xm) : 0;
     const char* e = getenv("VPTR_WGRAD_STAGES");
     stages = (e && atoi(e) == 3) ? 3 : 2;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
@@ -574,7 +588,7 @@ int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* des
       return -1;
     }
   }
-  if (stages == 3) vptr_wgrad_p16_kernel<3><<<total_tiles, GNT, 3 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count);
-  else vptr_wgrad_p16_kernel<2><<<total_tiles, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count);
+  if (stages == 3) vptr_wgrad_p16_kernel<3><<<total_tiles, GNT, 3 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode);
+  else vptr_wgrad_p16_kernel<2><<<total_tiles, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode);
   return 0;
 }

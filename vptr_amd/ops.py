@@ -30,6 +30,8 @@ class _Config:
     group_wgrads = True
     # plain parameters (no FlatAdamW slab) join the grouped launch through their own .grad (ops._loose_grad_for); 0 = A/B switch
     group_loose_wgrads = os.environ.get("VPTR_LOOSE_WGRADS", "1") != "0"
+    # grouped token-major weight gradients: transposed-store orientation for dW whose row count leaves eighth-full tiles; 0 = A/B switch
+    wgrad_flip = os.environ.get("VPTR_WGRAD_FLIP", "1") != "0"
     weights_frozen = False  # set by the frozen_weights scope only
     # P16 ("convert once") operands for every nn.Linear-shaped GEMM whose dimensions are multiples of 16 (precision 3 only):
     # the GEMMs stage pre-split bf16 hi / lo granules with global_load_lds instead of splitting fp32 in their main loops
@@ -505,10 +507,7 @@ def _to_device_async(host_bytes, dev):
             raise RuntimeError("graph capture: no reserved pinned staging buffer of %d bytes (ops.reserve_graph_staging)" % n)
         buf[:n].copy_(torch.frombuffer(bytearray(host_bytes), dtype=torch.uint8))
         _graph_keepalive.append(buf)
-        out = buf[:n].to(dev, non_blocking=True)
-        if os.environ.get("VPTR_DBG_KEEP_TABLES") == "1":
-            _graph_keepalive.append(out)
-        return out
+        return buf[:n].to(dev, non_blocking=True)
     pool = _pin_pool
     i = pool["next"] % 16
     pool["next"] += 1
@@ -528,8 +527,6 @@ def _to_device_async(host_bytes, dev):
 
 
 def _launch_wgrad_group(its):
-    if os.environ.get("VPTR_DBG_KEEP_ITEMS") == "1" and torch.cuda.is_current_stream_capturing():
-        _graph_keepalive.append(list(its))
     groups = {}
     for it in its:
         p16 = it[9]
@@ -542,14 +539,26 @@ def _launch_wgrad_group(its):
         flops = 0.0
         for i, (g, x, dW, N, K, M, _, db, alpha, _p) in enumerate(grp):
             d = descs[i]
-            d.A, d.B, d.D = ptr(g), ptr(x), ptr(dW)
-            d.a_rowsum = ptr(db)
-            d.lda, d.ldb, d.ldd = g.stride(0), x.stride(0), dW.stride(0)
-            d.M, d.N, d.K = N, K, M
-            d.a_mode, d.b_mode = (A_P16T, B_P16T) if p16 else (1, 1)
             d.precision, d.split_k, d.atomic, d.alpha = prec, 1, 1, alpha
+            # token-major P16 problems: put the 176-wide tile side on the dimension it divides.  dW[528][2112] as 128 x 176 tiles of
+            # (rows of dW) x (columns) is 5 x 12 tiles with every fifth row tile one-eighth full; computed as X^T . dY and stored
+            # transposed (vptr_gemm_desc.d_transposed) it is 17 x 3 tiles.  The bias gradient then needs >= 32 tile rows beyond K.
+            flip = (p16 and config.wgrad_flip and N < K and N % 176 == 0 and K % 128 != 0 and 128 - K % 128 >= 32)
+            if flip:
+                d.A, d.B, d.D = ptr(x), ptr(g), ptr(dW)
+                d.lda, d.ldb, d.ldd = x.stride(0), g.stride(0), dW.stride(0)
+                d.M, d.N, d.K = K, N, M
+                d.d_transposed = 1
+                rows_, cols_ = K, N
+            else:
+                d.A, d.B, d.D = ptr(g), ptr(x), ptr(dW)
+                d.lda, d.ldb, d.ldd = g.stride(0), x.stride(0), dW.stride(0)
+                d.M, d.N, d.K = N, K, M
+                rows_, cols_ = N, K
+            d.a_rowsum = ptr(db)
+            d.a_mode, d.b_mode = (A_P16T, B_P16T) if p16 else (1, 1)
             starts.append(total)
-            total += ((N + 127) // 128) * ((K + cols - 1) // cols)
+            total += ((rows_ + 127) // 128) * ((cols_ + cols - 1) // cols)
             flops += 2.0 * M * N * K
         dev = grp[0][0].device
         import struct
@@ -579,6 +588,9 @@ def flush_wgrads(chunks=1, on_chunk=None):
     items = list(_wgrad_q)
     del _wgrad_q[:]
     if chunks <= 1 or len(items) < 2 * chunks:
+        # largest problems first (their 51-tile waves fill the chip; the 15-tile problems then pack the tail), problems that read the
+        # same X next to each other: 8.55 -> 8.42 ms on the K64 step's 196 problems (tools/wgrad_ab.sh)
+        items.sort(key=lambda it: (-it[3] * it[4], it[1].data_ptr(), it[2].data_ptr()))
         _launch_wgrad_group(items)
         if on_chunk is not None:
             on_chunk(None)
