@@ -128,6 +128,12 @@ typedef struct vptr_gemm_desc {
      B = dY: 17 x 3 tiles instead of 5 x 12 with one eighth-full row tile in five) and lands in dW's own layout; the bias gradient
      (column sums of dY) rides in a wave row of the last row tile that lies beyond M (needs >= 32 such rows: M % 128 in 1..96). */
   int d_transposed;
+  /* fp32-staged kernels (a_mode 0 .. 2), fragment-layout epilogues only (no residual / Dpre): d_row_w > 0 sends output row m to row
+     m + d_row_w * (m / d_row_w) + d_row_off of D (row pitch ldd).  With ldd = 2 * Cout, d_row_w = IW, d_row_off = py * IW and
+     D offset by px * Cout this interleaves the four parity classes of a stride-2 ConvTranspose2d (ResNetAutoEncoder.py:74-88) into
+     the NHWC output: each class is an ordinary stride-1 gather over the INPUT grid with 1, 2, 2 or 4 taps instead of a 9-tap
+     gather form in which three quarters of the products are zeros. */
+  int d_row_w, d_row_off;
 } vptr_gemm_desc;
 
 int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream);

@@ -226,12 +226,20 @@ def test_conv_planes_matches_register_staged(ops, dev, pad_mode, stride, Cin, Co
             assert none is None and torch.equal(po2, po)
 
 
-def test_conv_transposed_gather(ops, dev):
-    B, Cin, Cout, H, W = 2, 24, 20, 6, 5
+@pytest.mark.parametrize("subpixel", [True, False])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 24, 20, 6, 5), (3, 528, 256, 8, 8), (2, 128, 64, 32, 32)])
+def test_conv_transposed_gather(ops, dev, monkeypatch, subpixel, B, Cin, Cout, H, W):
+    """ConvTranspose2d(3x3, s2, p1, op1) + folded BN + ReLU: as four output-parity classes through the GEMM's output row map (default)
+    and as the 9-tap gather form"""
+    monkeypatch.setattr(ops.config, "subpixel_convt", subpixel)
     x, w = rn((B, Cin, H, W), 32), rn((Cin, Cout, 3, 3), 33, 0.1)
-    ref = F.conv_transpose2d(x.double(), w.double(), stride=2, padding=1, output_padding=1)
+    sc, sh = rn((Cout,), 34).abs() + 0.5, rn((Cout,), 35)
+    ref = torch.relu(F.conv_transpose2d(x.double(), w.double(), stride=2, padding=1, output_padding=1) * sc.double()[None, :, None, None]
+                     + sh.double()[None, :, None, None])
     xt = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().to(dev)
-    y = ops.conv_nhwc(xt, ops.conv_weight_as_gemm_b(w, True).to(dev), B, H, W, Cin, 2 * H, 2 * W, 3, 3, 2, 1, "zero", True, Cout)
+    Bm = ops.conv_weight_as_gemm_b(w.to(dev), True)
+    assert isinstance(Bm, ops.SubpixelWeights) == subpixel
+    y = ops.conv_nhwc(xt, Bm, B, H, W, Cin, 2 * H, 2 * W, 3, 3, 2, 1, "zero", True, Cout, colscale=sc.to(dev), bias=sh.to(dev), act=ops.ACT_RELU)
     assert rel(y.reshape(B, 2 * H, 2 * W, Cout).permute(0, 3, 1, 2), ref) < TOL3
 
 

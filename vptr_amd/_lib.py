@@ -41,6 +41,7 @@ class GemmDesc(ctypes.Structure):
         ("act_grad_src", c_void_p),
         ("frame_stats", c_void_p), ("frame_rows", c_int),
         ("d_transposed", c_int),
+        ("d_row_w", c_int), ("d_row_off", c_int),
     ]
 
 

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(GNT, 4) void vptr_gemm_kernel(const vptr_gemm_desc 
   // (176-wide tiles only: with 64 / 128-wide tiles -- the auto-encoder's convs, M up to 655 360 -- the LDS round trip and its
   // barriers cost more than the short rows gain: stage-1 step 32.8 -> 35.3 ms; and no atomic accumulation: float atomics
   // stay scalar, so the round trip buys nothing)
-  if (NFN == 11 && epi_rows && !use_atomic && epi_vec_ok(p)) gemm_epilogue_rows_halves<NFN>(p, mb, acc, reinterpret_cast<float*>(sraw), m0, n0, wm, wn, lr, lq, tid, split == 0, use_atomic);
+  if (NFN == 11 && epi_rows && !use_atomic && epi_vec_ok(p) && p.d_row_w == 0) gemm_epilogue_rows_halves<NFN>(p, mb, acc, reinterpret_cast<float*>(sraw), m0, n0, wm, wn, lr, lq, tid, split == 0, use_atomic);
   else gemm_epilogue_serial<NFN>(p, mb, acc, m0, n0, wm, wn, lr, lq, split == 0, use_atomic);
   TS(5)
   TS_FLUSH
@@ -498,7 +498,7 @@ __device__ __forceinline__ void gemm_tile_p(const vptr_gemm_desc& p, const Membe
       TS(2)
     }
   }
-  if (epi_rows && !use_atomic && epi_vec_ok(p)) gemm_epilogue_rows<NFN>(p, mb, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, lr, lq, tid, first_split, use_atomic);
+  if (epi_rows && !use_atomic && epi_vec_ok(p) && p.d_row_w == 0) gemm_epilogue_rows<NFN>(p, mb, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, lr, lq, tid, first_split, use_atomic);
   else gemm_epilogue<NFN, 1>(p, mb, acc, m0, n0, wm, wn, lr, lq, first_split, use_atomic);
   if constexpr (AMODE == VPTR_A_KSTRIDED) {
     if (p.a_rowsum && n0 == 0) {  // workgroup-uniform: column tile 0 owns the row sums of its A panel
@@ -859,15 +859,20 @@ extern "C" int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream) {
   if (d.D_planes) VPTR_CHECK(d.a_mode == VPTR_A_CONV_PLANES, "vptr_gemm: D_planes is an output of the conv plane kernel only");
   VPTR_CHECK(d.precision == 1 || d.precision == 3, "vptr_gemm: precision must be 1 or 3 (got %d)", d.precision);
   if (d.a_mode == VPTR_A_P16 || d.b_mode == VPTR_B_P16) {
+    VPTR_CHECK(d.d_row_w == 0, "vptr_gemm(p16): no output row map");
     const int rc = vptr_gemm_p16_launch(d, reinterpret_cast<hipStream_t>(stream));
     if (rc) return rc;
     VPTR_LAUNCH_CHECK();
     return 0;
   }
   VPTR_CHECK(!d.d_p16, "vptr_gemm: d_p16 is an output format of the P16 kernels only");
+  if (d.d_row_w > 0 || d.d_row_off != 0)
+    VPTR_CHECK(d.d_row_w > 0 && d.a_mode <= VPTR_A_CONV && !d.residual && !d.Dpre && d.batch <= 1 && !d.atomic && d.split_k <= 1,
+               "vptr_gemm: the output row map (d_row_w / d_row_off) is an option of the fp32-staged kernels without residual / Dpre / batch / atomics");
   VPTR_CHECK(!d.act_grad_src && !d.frame_stats, "vptr_gemm: act_grad_src / frame_stats are epilogues of the P16 kernels only");
   VPTR_CHECK(d.a_mode != 4, "vptr_gemm: a_mode 4 (k-contiguous 32-wide planes) was replaced by VPTR_A_P16");
   if (d.a_mode == VPTR_A_CONV_PLANES) {
+    VPTR_CHECK(d.d_row_w == 0, "vptr_gemm(planes): no output row map");
     if (d.alpha == 0.f) d.alpha = 1.f;
     if (d.batch < 1) d.batch = 1;
     if (d.batch > 1) {

@@ -57,6 +57,11 @@ __device__ __forceinline__ Member member_of(const vptr_gemm_desc& p, const int m
   return m;
 }
 
+// output row of GEMM row m (vptr_gemm_desc.d_row_w: parity-class interleave of a stride-2 transposed convolution)
+__device__ __forceinline__ int64_t epi_drow(const vptr_gemm_desc& p, const int row) {
+  return p.d_row_w > 0 ? (int64_t)row + (int64_t)p.d_row_w * (row / p.d_row_w) + p.d_row_off : (int64_t)row;
+}
+
 // ---- fragment-layout epilogue of the pipelined loop, used when the row-major one below cannot be (N % 4 != 0, unaligned
 // pointers).  One workgroup per CU: nothing else hides its latencies, so all loads are issued before the first store.
 template <int NFN, int NGRP>  // NGRP: column-fragment groups, each = all its loads, then its stores
@@ -115,7 +120,7 @@ __device__ __forceinline__ void gemm_epilogue(const vptr_gemm_desc& p, const Mem
           const int row = row_base + mi * 16 + r;
           if (colok[ni] && row < p.M) {
             const float v = acc[mi][ni][r] + bs[ni] + res[ni - g0][mi][r];
-            float* dst = mb.D + (int64_t)row * p.ldd + col[ni];
+            float* dst = mb.D + epi_drow(p, row) * p.ldd + col[ni];
             if (use_atomic) unsafeAtomicAdd(dst, v);
             else *dst = v;
           }
@@ -137,7 +142,7 @@ __device__ __forceinline__ void gemm_epilogue(const vptr_gemm_desc& p, const Mem
             if (p.dropout_p > 0.f) v *= vptr_drop_scale(seed, p.site, (uint64_t)row * (uint64_t)p.N + col[ni], p.dropout_p);
             v += res[ni - g0][mi][r];
             if (p.act_after) v = v > 0.f ? v : 0.f;
-            float* dst = mb.D + (int64_t)row * p.ldd + col[ni];
+            float* dst = mb.D + epi_drow(p, row) * p.ldd + col[ni];
             if (use_atomic) unsafeAtomicAdd(dst, v);
             else *dst = v;
           }
@@ -225,7 +230,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const vptr_gemm_desc& p, cons
           v[e] = t;
         }
       }
-      float* dst = mb.D + (int64_t)row * p.ldd + col;
+      float* dst = mb.D + epi_drow(p, row) * p.ldd + col;
       if (use_atomic) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e, v[e]);
@@ -299,7 +304,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_halves(const vptr_gemm_desc& 
           *reinterpret_cast<uint2*>(o + 32) = make_uint2(lo[0], lo[1]);
         }
         if (mb.D) {
-          float* dst = mb.D + (int64_t)row * p.ldd + col;
+          float* dst = mb.D + epi_drow(p, row) * p.ldd + col;
           if (p.d_p16) {   // the consumer GEMM's operand format straight from this epilogue
             vptr_p16_store4(reinterpret_cast<unsigned char*>(mb.D), (int64_t)row * p.ldd + col, make_float4(v[0], v[1], v[2], v[3]));
           } else if (use_atomic) {
@@ -415,7 +420,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_halves_batched(const vptr_gem
           *reinterpret_cast<uint2*>(o + 32) = make_uint2(lo[0], lo[1]);
         }
         if (mb.D) {
-          float* dst = mb.D + (int64_t)row * p.ldd + col;
+          float* dst = mb.D + epi_drow(p, row) * p.ldd + col;
           if (p.d_p16) {   // the consumer GEMM's operand format straight from this epilogue
             vptr_p16_store4(reinterpret_cast<unsigned char*>(mb.D), (int64_t)row * p.ldd + col, make_float4(v[0], v[1], v[2], v[3]));
           } else if (use_atomic) {
@@ -476,7 +481,7 @@ __device__ __forceinline__ void gemm_epilogue_serial(const vptr_gemm_desc& p, co
           if (colok && row < p.M) {
             float v = acc[mi][ni][r] + bs;
             if (p.residual && first_split) v += p.residual[(int64_t)row * p.ldr + col];
-            float* dst = mb.D + (int64_t)row * p.ldd + col;
+            float* dst = mb.D + epi_drow(p, row) * p.ldd + col;
             if (use_atomic) unsafeAtomicAdd(dst, v);
             else *dst = v;
           }
@@ -506,7 +511,7 @@ __device__ __forceinline__ void gemm_epilogue_serial(const vptr_gemm_desc& p, co
             if (p.dropout_p > 0.f) v *= vptr_drop_scale(seed, p.site, (uint64_t)row * (uint64_t)p.N + col, p.dropout_p);
             if (p.residual && first_split) v += p.residual[(int64_t)row * p.ldr + col];
             if (p.act_after) v = v > 0.f ? v : 0.f;
-            float* dst = mb.D + (int64_t)row * p.ldd + col;
+            float* dst = mb.D + epi_drow(p, row) * p.ldd + col;
             if (use_atomic) unsafeAtomicAdd(dst, v);
             else *dst = v;
           }

@@ -32,6 +32,8 @@ class _Config:
     group_loose_wgrads = os.environ.get("VPTR_LOOSE_WGRADS", "1") != "0"
     # grouped token-major weight gradients: transposed-store orientation for dW whose row count leaves eighth-full tiles; 0 = A/B switch
     wgrad_flip = os.environ.get("VPTR_WGRAD_FLIP", "1") != "0"
+    # stride-2 3x3 transposed convolutions as four parity-class gathers (ops.SubpixelWeights) instead of one 9-tap gather form; 0 = A/B
+    subpixel_convt = os.environ.get("VPTR_SUBPIXEL_CONVT", "1") != "0"
     weights_frozen = False  # set by the frozen_weights scope only
     # P16 ("convert once") operands for every nn.Linear-shaped GEMM whose dimensions are multiples of 16 (precision 3 only):
     # the GEMMs stage pre-split bf16 hi / lo granules with global_load_lds instead of splitting fp32 in their main loops
@@ -123,7 +125,7 @@ def _c(t):
 def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None, colscale=None, alpha=1.0, act=ACT_NONE,
              Dpre=None, rowscale=None, rs_div=1, rs_mod=1, dropout_p=0.0, site=0, residual=None, act_after=False,
              atomic=False, split_k=1, conv=None, precision=None, seed=None, a_rowsum=None, batch_extra=None, kseg_extra=None,
-             planes_out=None, d_p16=False, act_grad_src=None, frame_stats=None, frame_rows=0):
+             planes_out=None, d_p16=False, act_grad_src=None, frame_stats=None, frame_rows=0, row_map=None, ldd=None):
     """One vptr_gemm launch.  batch_extra = [(A, B, D, bias, alpha), ...] adds up to two same-shaped independent problems to
     the grid; kseg_extra = [(A, B), ...] adds up to two K-segments accumulated into the same D (include/vptr_hip.h)."""
     d = GemmDesc()
@@ -145,7 +147,9 @@ def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None
     d.A, d.B, d.D, d.Dpre = ptr(A), ptr(B), ptr(D), ptr(Dpre)
     d.lda = lda if lda is not None else (A.stride(0) if a_mode != 2 else 0)
     d.ldb = ldb if ldb is not None else B.stride(0)
-    d.ldd = D.stride(0) if D is not None else N
+    d.ldd = ldd if ldd is not None else (D.stride(0) if D is not None else N)
+    if row_map is not None:
+        d.d_row_w, d.d_row_off = int(row_map[0]), int(row_map[1])
     d.M, d.N, d.K = M, N, K
     d.a_mode, d.b_mode = a_mode, b_mode
     d.precision = precision if precision is not None else config.gemm_precision
@@ -1510,13 +1514,31 @@ def tokens_to_nchw(x, B, C, H, W, relu=False):
 # ------------------------------------------------------------------------------------------------------------------
 # auto-encoder convolutions (implicit GEMM on NHWC) -- see vptr_amd/model/autoencoder.py for the layer wiring
 # ------------------------------------------------------------------------------------------------------------------
+class SubpixelWeights:
+    """ConvTranspose2d(3x3, stride 2, pad 1, output_padding 1) weight [Cin, Cout, 3, 3] split by output parity: class (py, px)
+    keeps the taps that reach output pixels (2y + py, 2x + px): ky = 1 for py = 0; for py = 1 the taps ky = 2 (input row y) and
+    ky = 0 (input row y + 1), in the order a stride-1, pad-0 gather with KH' = 2 walks them; likewise in x.
+    classes = [(py, px, B[n = Cout][k = (ky', kx', ci)])]; `full` = the 9-tap gather-form matrix (residual epilogues, other geometries)."""
+
+    def __init__(self, weight):
+        self.full = weight.permute(1, 2, 3, 0).reshape(weight.shape[1], -1).contiguous()
+        taps = {0: [1], 1: [2, 0]}
+        self.classes = []
+        for py in (0, 1):
+            for px in (0, 1):
+                w = weight[:, :, taps[py]][:, :, :, taps[px]]                      # [Cin, Cout, KH', KW']
+                self.classes.append((py, px, w.permute(1, 2, 3, 0).reshape(weight.shape[1], -1).contiguous()))
+
+
 def conv_weight_as_gemm_b(weight, transposed):
     """PyTorch conv weight -> B[n = Cout][k = (ky, kx, ci)] (k contiguous).
 
-    Conv2d weight [Cout, Cin, KH, KW]; ConvTranspose2d weight [Cin, Cout, KH, KW].
+    Conv2d weight [Cout, Cin, KH, KW]; ConvTranspose2d weight [Cin, Cout, KH, KW] (3x3: a SubpixelWeights, see conv_nhwc).
     """
     def pack():
         if transposed:
+            if config.subpixel_convt and weight.shape[2] == 3 and weight.shape[3] == 3:
+                return SubpixelWeights(weight)
             return weight.permute(1, 2, 3, 0).reshape(weight.shape[1], -1).contiguous()
         return weight.permute(0, 2, 3, 1).reshape(weight.shape[0], -1).contiguous()
 
@@ -1559,6 +1581,18 @@ def conv_nhwc(x, Bmat, frames, IH, IW, Cin, OH, OW, KH, KW, stride, pad, pad_mod
     """Implicit-GEMM convolution: x NHWC [frames*IH*IW, Cin] -> [frames*OH*OW, Cout] with fused folded-BN/ReLU/residual."""
     M = frames * OH * OW
     y = torch.empty((M, Cout), device=x.device, dtype=torch.float32)
+    if (transposed and isinstance(Bmat, SubpixelWeights) and residual is None and KH == 3 and KW == 3 and stride == 2 and pad == 1
+            and OH == 2 * IH and OW == 2 * IW and Cin % 4 == 0):
+        # ConvTranspose2d(3x3, stride 2, pad 1, output_padding 1) as its four output-parity classes: class (py, px) is a stride-1
+        # gather over the INPUT grid with (1 + py) x (1 + px) taps whose rows land on output pixels (2y + py, 2x + px) through the
+        # GEMM's output row map -- 2.25 taps per output pixel on average instead of the 9-tap gather form's 6.75 zero products
+        for (py, px, Bc) in Bmat.classes:
+            gemm_raw(x, Bc, y[:, :] if px == 0 else y.view(-1)[px * Cout:], frames * IH * IW, Cout, (1 + py) * (1 + px) * Cin, 2, 0, lda=0,
+                     colscale=colscale, bias=bias, act=act, act_after=act_after, ldd=2 * Cout, row_map=(IW, py * IW),
+                     conv=(IH, IW, Cin, IH, IW, 1 + py, 1 + px, 1, 0, PAD_MODES["zero"], 0))
+        return y
+    if isinstance(Bmat, SubpixelWeights):
+        Bmat = Bmat.full
     gemm_raw(x, Bmat, y, M, Cout, KH * KW * Cin, 2, 0, lda=0, colscale=colscale, bias=bias, act=act, residual=residual,
              act_after=act_after, conv=(IH, IW, Cin, OH, OW, KH, KW, stride, pad, PAD_MODES[pad_mode], int(transposed)))
     return y
