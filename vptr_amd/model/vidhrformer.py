@@ -424,8 +424,10 @@ class VidHRFormerBlockDecNAR(nn.Module):
         else:
             dpt = _droppath_scale(self.drop_path_p, self.training, T2, tgt.device)
             # mem / mem_k arrive as P16 tensors when P (converted once per forward by VidHRformerDecoderNAR.forward_tokens)
+            # qpos_tpos_tab = frame_queries + temporal positions (a buffer): its gradient is frame_queries' gradient
             _, uq, xr = ops.layernorm(x, self.norm5.weight, self.norm5.bias, tab=qpos_tpos_tab, tab_div=1, tab_mod=per_n,
-                                      eps=self.norm5.eps, passthrough=True, out_p16=P)
+                                      eps=self.norm5.eps, passthrough=True, out_p16=P,
+                                      tab_grad_to=None if tpos_f.requires_grad else qpos_tab)
             x = _mha_tokens(self.EncDecAttn, uq, mem_k, mem, xr, g.N, T2, T1, HW, False, p, s + 7, rowscale=dpt, rs_div=HW, rs_mod=T2,
                             x_p16=P)
         dp = _droppath_scale(self.drop_path_p, self.training, g.N, tgt.device)
@@ -456,6 +458,15 @@ class VidHRformerDecoderNAR(nn.Module):
         if self.norm is not None:
             x = ops.layernorm(x, self.norm.weight, self.norm.bias, eps=self.norm.eps)
         return x
+
+
+def _ln_ffn_stats_floats(stack, frames):
+    """floats of frame-statistics accumulators one forward of `stack` requests (3 x [frames, 2] per LayerNorm conv-FFN)"""
+    n = getattr(stack, "_n_ln_ffn", None)
+    if n is None:
+        n = sum(1 for m in stack.modules() if isinstance(m, MlpDWBN) and m.layer_norm)
+        stack.__dict__["_n_ln_ffn"] = n
+    return n * 3 * frames * 2
 
 
 def _assign_sites(module, base=0):
@@ -492,6 +503,8 @@ class VidHRFormerNAR(nn.Module):
         plan = self.__dict__.setdefault("_dp", {}).setdefault((self.training, N, Tp, Tf), _DropPathPlan())
         _dp_plan[0] = plan
         plan.begin(src.device)
+        arena = ops.zero_arena(_ln_ffn_stats_floats(self.encoder, N * Tp) + _ln_ffn_stats_floats(self.decoder, N * Tf), src.device)
+        arena.__enter__()
         try:
             x = ops.nchw_to_tokens(src.reshape(N * Tp, C, H, W))
             mem = self.encoder.forward_tokens(x, Geom(N, Tp, H, W), local_window_pos_embed, temporal_pos_embed[:Tp])
@@ -500,6 +513,7 @@ class VidHRFormerNAR(nn.Module):
                                               temporal_pos_embed[Tp:], temporal_pos_embed[:Tp], TS_local_pos_embed)
             out = ops.tokens_to_nchw(out, N * Tf, C, H, W, relu=True).reshape(N, Tf, C, H, W)
         finally:
+            arena.__exit__(None, None, None)
             plan.end()
             _dp_plan[0] = None
         return out, mem.reshape(N, Tp, H, W, C)
@@ -524,11 +538,14 @@ class VidHRFormerFAR(nn.Module):
         plan = self.__dict__.setdefault("_dp", {}).setdefault((self.training, N, T), _DropPathPlan())
         _dp_plan[0] = plan
         plan.begin(input_feat.device)
+        arena = ops.zero_arena(_ln_ffn_stats_floats(self.encoder, N * T), input_feat.device)
+        arena.__enter__()
         try:
             x = ops.nchw_to_tokens(input_feat.reshape(N * T, C, H, W))
             x = self.encoder.forward_tokens(x, Geom(N, T, H, W), local_window_pos_embed, temporal_pos_embed[:T])
             out = ops.tokens_to_nchw(x, N * T, C, H, W, relu=True).reshape(N, T, C, H, W)
         finally:
+            arena.__exit__(None, None, None)
             plan.end()
             _dp_plan[0] = None
         return out

@@ -851,8 +851,37 @@ def frame_stats_ok(rows, HW, F, W=None):
             and (W is None or (W % 2 == 0 and ((W // 2) * (F // 4)) % 64 == 0)))
 
 
+_zero_arena = {"buf": None, "off": 0}
+
+
+class zero_arena:
+    """Scope of one model forward in which the small zero-initialised accumulators (frame_stats_buffer) are slices of ONE zero-filled
+    tensor: one fill launch per forward instead of one per conv-FFN (16 in the K64 NAR model).  The arena tensor stays alive as long
+    as any slice does (autograd saves them); requests beyond its size fall back to their own torch.zeros."""
+
+    def __init__(self, nfloats, device):
+        self.n, self.device = int(nfloats), device
+
+    def __enter__(self):
+        self.prev = dict(_zero_arena)
+        _zero_arena["buf"] = torch.zeros(self.n, device=self.device, dtype=torch.float32) if self.n > 0 else None
+        _zero_arena["off"] = 0
+        return self
+
+    def __exit__(self, *exc):
+        _zero_arena.update(self.prev)
+        return False
+
+
 def frame_stats_buffer(frames, device):
-    """a zeroed [frames, 2] fp32 buffer for one producer / consumer pair (one tiny fill; inside a graph capture it is re-zeroed at every replay)"""
+    """a zeroed [frames, 2] fp32 buffer for one producer / consumer pair (a slice of the forward's zero_arena when one is open;
+    inside a graph capture the arena's fill is re-run at every replay)"""
+    n = 2 * int(frames)
+    buf = _zero_arena["buf"]
+    if buf is not None and buf.device == torch.device(device) and _zero_arena["off"] + n <= buf.numel():
+        off = _zero_arena["off"]
+        _zero_arena["off"] = off + n
+        return buf[off:off + n].view(frames, 2)
     return torch.zeros((frames, 2), device=device, dtype=torch.float32)
 
 
@@ -933,7 +962,7 @@ class _LayerNormFn(torch.autograd.Function):
     (dx_add) instead of by an autograd accumulation pass."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, tab, tab_div, tab_mod, eps, passthrough, out_p16):
+    def forward(ctx, x, gamma, beta, tab, tab_div, tab_mod, eps, passthrough, out_p16, tab_grad_to=None):
         _lib.require_cuda(x)
         ctx.set_materialize_grads(False)  # an unused output (e.g. y when only y + tab is consumed) arrives as None, not zeros
         x = _c(x)
@@ -948,6 +977,7 @@ class _LayerNormFn(torch.autograd.Function):
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.beta_ref = beta.detach()
         ctx.tab = (tab is not None, tab_div, tab_mod, tuple(tab.shape) if tab is not None else None)
+        ctx.tab_ref = tab_grad_to if tab_grad_to is not None else tab   # whose gradient destination receives the table gradient
         ctx.passthrough = passthrough
         outs = (y,) if tab is None else (y, y2)
         if passthrough:
@@ -967,7 +997,7 @@ class _LayerNormFn(torch.autograd.Function):
         dres = _c(dres) if dres is not None else None
         if dy is None:  # only the position-added output was consumed
             if dy2 is None:
-                return (dres,) + (None,) * 8
+                return (dres,) + (None,) * 9
             k1, k2 = dy2, None
         else:
             k1, k2 = _c(dy), dy2
@@ -982,20 +1012,28 @@ class _LayerNormFn(torch.autograd.Function):
             dgamma = dbeta = None
         dtab = None
         if has_tab and ctx.needs_input_grad[3] and dy2 is not None:
-            dtab = torch.zeros((tab_mod, C), device=x.device, dtype=torch.float32)
-            check(lib.vptr_rowmod_sum(ptr(dy2), ptr(dtab), rows, C, tab_div, tab_mod, stream()), "vptr_rowmod_sum")
-            dtab = dtab.reshape(tab_shape)
-        return dx, dgamma, dbeta, dtab, None, None, None, None, None
+            dst = grad_dest_for(ctx.tab_ref) if ctx.tab_ref is not None else None
+            if dst is not None and dst.numel() == tab_mod * C:
+                # the table is (a view of, or an affine image of) a parameter with an in-place gradient destination: accumulate there
+                # -- no zero-filled temporary, no autograd add per call site (8 decoder blocks x 2 share frame_queries)
+                check(lib.vptr_rowmod_sum(ptr(dy2), ptr(dst), rows, C, tab_div, tab_mod, stream()), "vptr_rowmod_sum")
+            else:
+                dtab = torch.zeros((tab_mod, C), device=x.device, dtype=torch.float32)
+                check(lib.vptr_rowmod_sum(ptr(dy2), ptr(dtab), rows, C, tab_div, tab_mod, stream()), "vptr_rowmod_sum")
+                dtab = dtab.reshape(tab_shape)
+        return dx, dgamma, dbeta, dtab, None, None, None, None, None, None
 
 
 _LayerNormFn_apply = _direct_apply(_LayerNormFn)
 
 
-def layernorm(x, gamma, beta, tab=None, tab_div=1, tab_mod=1, eps=1e-5, passthrough=False, out_p16=False):
+def layernorm(x, gamma, beta, tab=None, tab_div=1, tab_mod=1, eps=1e-5, passthrough=False, out_p16=False, tab_grad_to=None):
     """y = LN(x) [, y2 = y + tab[(row // tab_div) % tab_mod]] [, xr]; x [rows, C]; tab [tab_mod, C].
     passthrough=True appends xr (= x, for use as the residual of the sub-layer this LayerNorm feeds; see _LayerNormFn).
-    out_p16: y and y2 are written as P16 tensors (they only feed GEMMs; their gradients arrive as ordinary fp32)."""
-    return _LayerNormFn_apply(x, gamma, beta, tab, int(tab_div), int(tab_mod), float(eps), bool(passthrough), bool(out_p16))
+    out_p16: y and y2 are written as P16 tensors (they only feed GEMMs; their gradients arrive as ordinary fp32).
+    tab_grad_to: a tensor of tab's size whose gradient IS tab's gradient (tab = tab_grad_to + constants): when it has an in-place
+    gradient destination (flat slab / .grad) the table gradient is accumulated there instead of being handed to autograd."""
+    return _LayerNormFn_apply(x, gamma, beta, tab, int(tab_div), int(tab_mod), float(eps), bool(passthrough), bool(out_p16), tab_grad_to)
 
 
 class _AddRowTabFn(torch.autograd.Function):
