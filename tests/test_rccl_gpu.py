@@ -68,14 +68,18 @@ def _worker(port, q):
                 past = fill.rand_input((4, cfg["Tp"], 1, meta["HW"], meta["HW"]), meta["seed"] + 100 + s).to(dev)
                 fut = fill.rand_input((4, cfg["Tf"], 1, meta["HW"], meta["HW"]), meta["seed"] + 200 + s).to(dev)
                 tr.step(past, fut)
-                grads.append(tr.opt.grad.detach().clone())
+                grads.append(tr.opt.grad.detach().clone() * tr._grad_scale)
             return grads, tr.opt.flat.detach().clone()
 
         g_ov, p_ov = run_far("overlap")
         g_pl, p_pl = run_far("plain")
         g_no, p_no = run_far("none")
-        res["far_grad_overlap_vs_none"] = max(rel(a, b) for a, b in zip(g_ov, g_no))
-        res["far_grad_plain_vs_none"] = max(rel(a, b) for a, b in zip(g_pl, g_no))
+        # step 0: identical inputs -> identical gradients up to the order of fp32 atomics (~1e-7); step 1 starts from parameters that
+        # already differ (the first AdamW update is ~lr * sign(g): a 1e-7 gradient difference flips single elements by 2 lr), which a
+        # second forward / backward amplifies to ~5e-5 -- also between two runs of the SAME mode (tools/dbg_far_det.py)
+        res["far_grad_overlap_vs_none"] = rel(g_ov[0], g_no[0])
+        res["far_grad_plain_vs_none"] = rel(g_pl[0], g_no[0])
+        res["far_grad_step1"] = max(rel(g_ov[1], g_no[1]), rel(g_pl[1], g_no[1]))
         res["far_param_overlap_vs_none"] = rel(p_ov, p_no)
 
         def run_k64(mode):
@@ -116,6 +120,6 @@ def test_rccl_world1_forced_exchange():
     assert "error" not in res, res["error"]
     assert res["backend"] == "nccl" and res["allreduce_ok"], res
     assert res["far_grad_overlap_vs_none"] < 1e-6 and res["far_grad_plain_vs_none"] < 1e-6, res   # one rank: sum == identity, bit for bit
-    assert res["far_param_overlap_vs_none"] < 1e-6, res
+    assert res["far_grad_step1"] < 1e-3 and res["far_param_overlap_vs_none"] < 1e-5, res
     assert res["k64_terms_rel"] < 2e-3 and res["k64_param_rel"] < 1e-5, res       # dropout 0.1 + atomics-accumulated statistics
     assert 0.0 <= res["k64_last"]["T_GDL"] <= 4.0, res

@@ -92,6 +92,15 @@ def allreduce_mean_(flat, group=None, bucket_elems=16 << 20, force=False):
     return flat
 
 
+def allreduce_sum_(flat, group=None, bucket_elems=16 << 20):
+    """In-place SUM over ranks of a flat tensor in buckets of `bucket_elems` elements; issued on one-rank groups too.  The trainers fold
+    the 1 / world of the mean into the optimizer kernel's gradient scale instead of running another pass over the slab."""
+    n = flat.numel()
+    for off in range(0, n, bucket_elems):
+        dist.all_reduce(flat[off:off + bucket_elems], op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
 def shard_batch(global_batch, rank, world):
     """The reference's DistributedSampler split: per-rank batch = global // world (utils/dataset.py:71-77).  Raises on
     the degenerate configuration the reference script ships (batch 2 on 4 ranks -> 0 per rank, train_NAR_mp.py:297,313)."""

@@ -274,11 +274,14 @@ class NARTrainer:
         return {"Dtotal": loss_D.detach(), "Dfake": l_fake.detach(), "Dreal": l_real.detach()}
 
     # -- data-parallel gradient exchange: a few large RCCL all-reduces on the flat gradient slab ---------------------
+    _grad_scale = 1.0   # factor the next optimizer step applies to the gradient slab (1 / world after a summed exchange)
+
     def _allreduce_grads(self):
         if self.pg is None or (self.world == 1 and os.environ.get("VPTR_DP_FORCE_EXCHANGE") != "1"):
             return
-        from .parallel import allreduce_mean_
-        allreduce_mean_(self.opt.grad, self.pg, self.bucket_elems, force=True)
+        from .parallel import allreduce_sum_
+        allreduce_sum_(self.opt.grad, self.pg, self.bucket_elems)
+        self._grad_scale = 1.0 / self.world
 
     def _backward_and_exchange(self, loss):
         """loss.backward(), the grouped weight-gradient GEMMs and the data-parallel gradient exchange.  With more than one
@@ -289,6 +292,7 @@ class NARTrainer:
         # -- its own stream, async Work objects, event ordering against the weight-gradient launches -- through the same code the
         # 8-GPU job runs: tests/test_rccl_gpu.py, bench.py --force-exchange)
         force = self.pg is not None and os.environ.get("VPTR_DP_FORCE_EXCHANGE") == "1"
+        self._grad_scale = 1.0
         if self.pg is None or (self.world == 1 and not force) or os.environ.get("VPTR_DP_OVERLAP", "1") == "0":
             loss.backward()
             ops.flush_wgrads()  # no-op: the grouped weight-gradient launch already ran at the end of backward
@@ -315,7 +319,7 @@ class NARTrainer:
             send_upto(None)
         for w in works:
             w.wait()
-        grad.mul_(1.0 / self.world)
+        self._grad_scale = 1.0 / self.world   # the mean over ranks is folded into the optimizer kernel (FlatAdamW.step(grad_scale)): no extra pass over the slab
 
     def losses(self, pred_frames, future, pred_feats, future_feats):
         """cal_lossT (train_NAR.py:32-47, 81-91): MSE + GDL on the frames, lam_pc * BiPatchNCE on the L2-normalised NCE projections"""
@@ -353,7 +357,7 @@ class NARTrainer:
             loss = loss + self.lam_gan * extra["T_gan"]
             extra["T_gan"] = extra["T_gan"].detach()
         self._backward_and_exchange(loss)
-        self.opt.step()
+        self.opt.step(grad_scale=self._grad_scale)
         return dict({"T_total": loss.detach(), "T_GDL": l_gdl.detach(), "T_MSE": l_mse.detach(), "T_bpc": l_pc.detach(),
                      "grad_norm": self.opt.grad_norm()}, **extra)
 
@@ -501,7 +505,7 @@ class FARTrainer(NARTrainer):
             loss = loss + self.lam_gan * t_gan
             extra["T_gan"] = t_gan.detach()
         self._backward_and_exchange(loss)
-        self.opt.step()
+        self.opt.step(grad_scale=self._grad_scale)
         return dict({"T_total": loss.detach(), "T_GDL": l_gdl.detach(), "T_MSE": l_mse.detach(), "grad_norm": self.opt.grad_norm()},
                     **extra)
 
