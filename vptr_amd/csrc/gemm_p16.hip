@@ -296,10 +296,10 @@ __device__ __forceinline__ bf16x8 p16_tr_frag(const unsigned char* st, const int
 
 template <int NSTAGE>   // 2: two workgroups per CU; 3: one workgroup per CU with the DMA two K-steps ahead (experiment, VPTR_WGRAD_STAGES=3)
 __global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
-                                                                const int count, const int xmode) {
+                                                                const int count, const int xmode, const int tile_base) {
   constexpr int BN = 176;
   extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
-  const int lg = xmode == 1 ? (int)blockIdx.x : xcd_logical_block();
+  const int lg = tile_base + (xmode == 1 ? (int)blockIdx.x : xcd_logical_block());
   int lo = 0, hi = count - 1;  // last g with tile_start[g] <= lg (workgroup-uniform scalar search)
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -575,10 +575,12 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
 int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* descs_dev, const int* tile_start_dev, int count, int total_tiles,
                           hipStream_t st) {
   VPTR_CHECK(proto->b_mode == VPTR_B_P16T && proto->precision == 3, "vptr_gemm_grouped(p16): both operands token-major P16, precision 3");
-  static int stages = -1, xmode = 0;
+  static int stages = -1, xmode = 0, gen = 0;
   if (stages < 0) {
     const char* xm = getenv("VPTR_WGRAD_XCD");
     xmode = xm ? atoi(xm) : 0;
+    const char* ge = getenv("VPTR_WGRAD_GEN");
+    gen = ge ? atoi(ge) : 0;
     const char* e = getenv("VPTR_WGRAD_STAGES");
     stages = (e && atoi(e) == 3) ? 3 : 2;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
@@ -588,7 +590,13 @@ int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* des
       return -1;
     }
   }
-  if (stages == 3) vptr_wgrad_p16_kernel<3><<<total_tiles, GNT, 3 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode);
-  else vptr_wgrad_p16_kernel<2><<<total_tiles, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode);
+  // gen > 0: the tile list as consecutive launches of `gen` tiles (one "generation" of resident workgroups each): every launch starts its
+  // tiles together, so tiles that share operand panels begin in step instead of inheriting the finishing skew of their predecessors
+  const int per = gen > 0 ? gen : total_tiles;
+  for (int base = 0; base < total_tiles; base += per) {
+    const int nt = total_tiles - base < per ? total_tiles - base : per;
+    if (stages == 3) vptr_wgrad_p16_kernel<3><<<nt, GNT, 3 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode, base);
+    else vptr_wgrad_p16_kernel<2><<<nt, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode, base);
+  }
   return 0;
 }

@@ -32,6 +32,8 @@ class _Config:
     group_loose_wgrads = os.environ.get("VPTR_LOOSE_WGRADS", "1") != "0"
     # grouped token-major weight gradients: transposed-store orientation for dW whose row count leaves eighth-full tiles; 0 = A/B switch
     wgrad_flip = os.environ.get("VPTR_WGRAD_FLIP", "1") != "0"
+    # partly filled last row tiles as separate problems launched after all full tiles (equal-duration tiles stay in step); 0 = A/B switch
+    wgrad_split = os.environ.get("VPTR_WGRAD_SPLIT", "0") != "0"   # measured: no change (7.03 vs 7.05 ms bare launch): off
     # stride-2 3x3 transposed convolutions as four parity-class gathers (ops.SubpixelWeights) instead of one 9-tap gather form; 0 = A/B
     subpixel_convt = os.environ.get("VPTR_SUBPIXEL_CONVT", "1") != "0"
     weights_frozen = False  # set by the frozen_weights scope only
@@ -536,34 +538,47 @@ def _launch_wgrad_group(its):
         p16 = it[9]
         groups.setdefault((176 if p16 else int(lib.vptr_gemm_tile_cols(it[4])), it[6], p16), []).append(it)
     for (cols, prec, p16), grp in groups.items():
-        n = len(grp)
-        descs = (GemmDesc * n)()
-        starts = []
-        total = 0
+        # sub-problems: (A ptr, B ptr, D ptr, rowsum ptr, lda, ldb, ldd, rows, cols, tokens, alpha, transposed)
+        subs = []
         flops = 0.0
-        for i, (g, x, dW, N, K, M, _, db, alpha, _p) in enumerate(grp):
-            d = descs[i]
-            d.precision, d.split_k, d.atomic, d.alpha = prec, 1, 1, alpha
+        for (g, x, dW, N, K, M, _, db, alpha, _p) in grp:
+            flops += 2.0 * M * N * K
             # token-major P16 problems: put the 176-wide tile side on the dimension it divides.  dW[528][2112] as 128 x 176 tiles of
             # (rows of dW) x (columns) is 5 x 12 tiles with every fifth row tile one-eighth full; computed as X^T . dY and stored
             # transposed (vptr_gemm_desc.d_transposed) it is 17 x 3 tiles.  The bias gradient then needs >= 32 tile rows beyond K.
             flip = (p16 and config.wgrad_flip and N < K and N % 176 == 0 and K % 128 != 0 and 128 - K % 128 >= 32)
             if flip:
-                d.A, d.B, d.D = ptr(x), ptr(g), ptr(dW)
-                d.lda, d.ldb, d.ldd = x.stride(0), g.stride(0), dW.stride(0)
-                d.M, d.N, d.K = K, N, M
-                d.d_transposed = 1
-                rows_, cols_ = K, N
+                a, b, rows_, cols_, lda, ldb = x, g, K, N, x.stride(0), g.stride(0)
             else:
-                d.A, d.B, d.D = ptr(g), ptr(x), ptr(dW)
-                d.lda, d.ldb, d.ldd = g.stride(0), x.stride(0), dW.stride(0)
-                d.M, d.N, d.K = N, K, M
-                rows_, cols_ = N, K
-            d.a_rowsum = ptr(db)
+                a, b, rows_, cols_, lda, ldb = g, x, N, K, g.stride(0), x.stride(0)
+            ap, bp, dp, rp, ldd = a.data_ptr(), b.data_ptr(), dW.data_ptr(), (db.data_ptr() if db is not None else 0), dW.stride(0)
+            rem = rows_ % 128
+            if p16 and config.wgrad_split and rem and rows_ > 128:
+                # the partly filled last row tile of every problem becomes a problem of its own, launched after all full tiles: full
+                # tiles then all take the same time, so the tiles that share an operand panel stay in step (and in one L2), instead
+                # of being scattered by the short tiles that used to finish early between them
+                full = rows_ - rem
+                subs.append((ap, bp, dp, 0 if flip else rp, lda, ldb, ldd, full, cols_, M, alpha, flip))
+                subs.append((ap + full * 4, bp, dp + (full * 4 if flip else full * ldd * 4), (rp + (0 if flip else full * 4)) if rp else 0,
+                             lda, ldb, ldd, rem, cols_, M, alpha, flip))
+            else:
+                subs.append((ap, bp, dp, rp, lda, ldb, ldd, rows_, cols_, M, alpha, flip))
+        if p16 and config.wgrad_split:
+            subs.sort(key=lambda t: (0 if t[7] >= 128 else 1, -t[7] * t[8], t[1], t[2]))   # full-tile problems first (largest first), remainders last
+        n = len(subs)
+        descs = (GemmDesc * n)()
+        starts = []
+        total = 0
+        for i, (ap, bp, dp, rp, lda, ldb, ldd, rows_, cols_, M, alpha, flip) in enumerate(subs):
+            d = descs[i]
+            d.precision, d.split_k, d.atomic, d.alpha = prec, 1, 1, alpha
+            d.A, d.B, d.D, d.a_rowsum = ap, bp, dp, (rp or None)
+            d.lda, d.ldb, d.ldd = lda, ldb, ldd
+            d.M, d.N, d.K = rows_, cols_, M
+            d.d_transposed = int(flip)
             d.a_mode, d.b_mode = (A_P16T, B_P16T) if p16 else (1, 1)
             starts.append(total)
             total += ((rows_ + 127) // 128) * ((cols_ + cols - 1) // cols)
-            flops += 2.0 * M * N * K
         dev = grp[0][0].device
         import struct
         raw = _to_device_async(bytes(descs), dev)
