@@ -302,14 +302,27 @@ def test_rowtab_colsum(ops, dev):
 TOLA = 5e-5   # attention cores: split-bf16 MFMA products (forward; gradients 1e-4)
 
 
-@pytest.fixture(params=["mfma", "vector"])
+@pytest.fixture(params=["default", "attn16", "mfma", "vector"])
 def attn_mode(request):
-    """every attention geometry through both families of kernels: VPTR_ATTN_MFMA=2 forces the matrix-core kernels wherever they
-    cover the geometry, 0 the fp32 vector kernels (the default mixes them by problem size)"""
+    """every attention geometry through all kernel families: the default (problems of at most 16 tokens: forward on the LDS-free MFMA
+    kernels of attn16.hip, backward on the fp32 vector kernels; larger ones on the LDS-staged MFMA kernels of attn_mfma.hip),
+    VPTR_ATTN16=2 (attn16.hip forward AND backward), VPTR_ATTN_MFMA=2 (attn_mfma.hip wherever it covers the geometry) and
+    VPTR_ATTN_MFMA=0 (the fp32 vector kernels of attn.hip everywhere)"""
     import os
     old = os.environ.get("VPTR_ATTN_MFMA")
-    os.environ["VPTR_ATTN_MFMA"] = "2" if request.param == "mfma" else "0"
+    old16 = os.environ.get("VPTR_ATTN16")
+    os.environ.pop("VPTR_ATTN16", None)
+    if request.param in ("default", "attn16"):
+        os.environ.pop("VPTR_ATTN_MFMA", None)
+        if request.param == "attn16":
+            os.environ["VPTR_ATTN16"] = "2"
+    else:
+        os.environ["VPTR_ATTN_MFMA"] = "2" if request.param == "mfma" else "0"
     yield request.param
+    if old16 is None:
+        os.environ.pop("VPTR_ATTN16", None)
+    else:
+        os.environ["VPTR_ATTN16"] = old16
     if old is None:
         os.environ.pop("VPTR_ATTN_MFMA", None)
     else:

@@ -312,6 +312,13 @@ extern "C" int vptr_winattn_fwd(const float* q, const float* k, const float* v, 
     VPTR_LAUNCH_CHECK();
     return 0;
   }
+  if (vptr_attn16_ok(0, L, L, C, nh, ws, 0)) {   // 4 x 4 windows: LDS-free MFMA kernels (attn16.hip)
+    A16Geom g16 = {0, H, W, 0, 0, 0, C, nh, hd, 16, 16, B * (H / 4) * (W / 4), 0};
+    const int rc = vptr_attn16_fwd(q, k, v, bias_table, rel_index, o, g16, dropout_p, seed_dev, site, p16, (hipStream_t)stream);
+    if (rc) return rc;
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
   if (ws == 4 && hd % 2 == 0 && C % 2 == 0) {
     const int nwin = B * (H / 4) * (W / 4);
     const int wpb = nwin >= 64 ? 2 : 1;   // two windows per workgroup: the second one's loads overlap the first one's math
@@ -445,6 +452,14 @@ extern "C" int vptr_winattn_bwd(const float* q, const float* k, const float* v, 
     AmGeom gm = {0, H, W, ws, 0, 0, 0, L, L, C, nh, hd, nwin};
     const int rc = vptr_attn_mfma_bwd(q, k, v, bias_table, rel_index, dout, dq, dk, dv, dbias_table, gm, 0, dropout_p, seed_dev, site, dq_scale, p16,
                                       (hipStream_t)stream);
+    if (rc) return rc;
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
+  if (vptr_attn16_ok(0, L, L, C, nh, ws, 1)) {
+    A16Geom g16 = {0, H, W, 0, 0, 0, C, nh, hd, 16, 16, nwin, 0};
+    const int rc = vptr_attn16_bwd(q, k, v, bias_table, rel_index, dout, dq, dk, dv, dbias_table, g16, dropout_p, seed_dev, site, dq_scale, p16,
+                                   (hipStream_t)stream);
     if (rc) return rc;
     VPTR_LAUNCH_CHECK();
     return 0;
@@ -747,6 +762,13 @@ extern "C" int vptr_tattn_fwd(const float* q, const float* k, const float* v, fl
     VPTR_LAUNCH_CHECK();
     return 0;
   }
+  if (vptr_attn16_ok(1, Tq, Tk, C, nh, 0, 0)) {   // T <= 16: LDS-free MFMA kernels (attn16.hip)
+    A16Geom g16 = {1, 0, 0, Tq, Tk, HW, C, nh, hd, Tq, Tk, Nb * HW, causal};
+    const int rc = vptr_attn16_fwd(q, k, v, nullptr, nullptr, o, g16, dropout_p, seed_dev, site, p16, (hipStream_t)stream);
+    if (rc) return rc;
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
   if (Tq <= 16 && Tk <= 16 && hd % 2 == 0 && C % 2 == 0) {
     const size_t lds16 = sizeof(float) * ((Tq + 2 * Tk) * att_pitch(hd) + 16 * 20);
     const int items = (Tq > Tk ? Tq : Tk) * (att_pitch(hd) / 2);
@@ -866,6 +888,14 @@ extern "C" int vptr_tattn_bwd(const float* q, const float* k, const float* v, co
     AmGeom gm = {1, 0, 0, 0, Tq, Tk, HW, Tq, Tk, C, nh, hd, Nb * HW};
     const int rc = vptr_attn_mfma_bwd(q, k, v, nullptr, nullptr, dout, dq, dk, dv, nullptr, gm, causal, dropout_p, seed_dev, site, dq_scale, p16,
                                       (hipStream_t)stream);
+    if (rc) return rc;
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
+  if (vptr_attn16_ok(1, Tq, Tk, C, nh, 0, 1)) {
+    A16Geom g16 = {1, 0, 0, Tq, Tk, HW, C, nh, hd, Tq, Tk, Nb * HW, causal};
+    const int rc = vptr_attn16_bwd(q, k, v, nullptr, nullptr, dout, dq, dk, dv, nullptr, g16, dropout_p, seed_dev, site, dq_scale, p16,
+                                   (hipStream_t)stream);
     if (rc) return rc;
     VPTR_LAUNCH_CHECK();
     return 0;

@@ -18,3 +18,20 @@ int vptr_attn_mfma_fwd(const float* q, const float* k, const float* v, const flo
 int vptr_attn_mfma_bwd(const float* q, const float* k, const float* v, const float* table, const int64_t* rel_index, const float* dout, float* dq, float* dk,
                        float* dv, float* dtable, const AmGeom& gm, int causal, float p, const uint64_t* seed_dev, uint32_t site, float dq_scale, int p16,
                        hipStream_t st);
+
+// attn16.hip: problems of at most 16 x 16 tokens (4 x 4 windows, T <= 16) on the matrix units without LDS
+struct A16Geom {
+  int kind;          // 0: 4 x 4 windows of [B, H, W] frames; 1: temporal
+  int H, W;          // kind 0
+  int Tq, Tk, HW;    // kind 1
+  int C, nh, hd;
+  int Lq, Lk;        // rows per problem (<= 16)
+  int nprob;         // windows, or N * HW pixels
+  int causal;
+};
+bool vptr_attn16_ok(int kind, int Lq, int Lk, int C, int nh, int ws, int backward);
+int vptr_attn16_fwd(const float* q, const float* k, const float* v, const float* table, const int64_t* rel_index, float* o, const A16Geom& g, float p,
+                    const uint64_t* seed_dev, uint32_t site, int p16, hipStream_t st);
+int vptr_attn16_bwd(const float* q, const float* k, const float* v, const float* table, const int64_t* rel_index, const float* dout, float* dq, float* dk,
+                    float* dv, float* dtable, const A16Geom& g, float p, const uint64_t* seed_dev, uint32_t site, float dq_scale, int p16,
+                    hipStream_t st);
