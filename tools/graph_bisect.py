@@ -168,14 +168,6 @@ def main():
             rows.sort(reverse=True)
             for r in rows[:args.top]:
                 print("    |g| %.4e  max %.4e  %s %s" % r)
-        if os.environ.get("VPTR_DBG_KEEP_ITEMS") == "1" and args.mode == "graph":
-            its = [k for k in ops._graph_keepalive if isinstance(k, list)][-1]
-            for j, it in enumerate(its[:6] + its[-2:]):
-                g, x, dW, N_, K_, M_ = it[:6]
-                gd, xd = ops.p16_decode(g).double(), ops.p16_decode(x).double()
-                ref = gd.t() @ xd
-                print("    item %d N %d K %d M %d |g| %.3e |x| %.3e |dW slab| %.3e |g^T x| %.3e gptr %x xptr %x" % (
-                    j, N_, K_, M_, float(gd.norm()), float(xd.norm()), float(dW.double().norm()), float(ref.norm()), g.data_ptr(), x.data_ptr()))
         for k_, v_ in hookbuf.items():
             print("    grad tap %-7s norm %.4e" % (k_, float(v_.double().norm())))
         print(args.mode, "N", args.batch, "dp_off" if args.no_droppath else "dp_on", "stash" if args.stash else "", s, line, flush=True)
