@@ -95,7 +95,7 @@ extern "C" int vptr_weight_planes(const vptr_wplane_entry* table_dev, const int*
 // LEAN: plain epilogue only (gemm_shared.h).  NST = 3: the instantiation for grids of at most one workgroup per CU (nothing else on
 // the CU hides a stall): three stages with the DMA two K-steps ahead, its pieces issued between the MFMA groups instead of in a
 // burst after the barrier (cache-cold 10 240 x 528 x 2112: 79.7 -> 73.1 us in tools/gemm_p16_probe).  Both chosen by the launcher.
-template <int EPI, int NST>   // EPI: 0 every epilogue option, 1 lean, 2 activation gradient (gemm_shared.h)
+template <int EPI, int NST>   // EPI: 0 every epilogue option, 1 lean, 2 activation gradient, 3 lean + row scale + dropout (gemm_shared.h)
 __global__ __launch_bounds__(GNT, NST == 3 ? 2 : 4) void vptr_gemm_p16_kernel(const vptr_gemm_desc p, const int epi_rows) {
   constexpr int NFN = 11, BN = 176;
   extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
@@ -535,7 +535,9 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess) {
       vptr_set_error("vptr_gemm(p16): cannot reserve %d bytes of LDS", 2 * P16_STAGE);
       return -1;
     }
@@ -552,6 +554,10 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
 #endif
   const bool lean = (p16_epi_rows_flag() & 4) == 0 && !d.colscale && dpre_ok && !d.rowscale && d.act == VPTR_ACT_NONE && d.dropout_p == 0.f && !d.act_after && !d.atomic &&
                     (ebits & 15) == 0 && (d.N & 3) == 0 && (d.ldd & 3) == 0 && (d.ldr & 3) == 0;
+  // the same plus a DropPath row scale and / or dropout (out-projections and linear2 of every block: 46 launches of the K64 step)
+  const bool lean3 = !lean && (p16_epi_rows_flag() & 4) == 0 && !d.colscale && dpre_ok && (d.rowscale || d.dropout_p > 0.f) && d.act == VPTR_ACT_NONE &&
+                     !d.act_after && !d.atomic && !d.frame_stats && (ebits & 15) == 0 && (d.N & 3) == 0 && (d.ldd & 3) == 0 && (d.ldr & 3) == 0 &&
+                     getenv("VPTR_GEMM_NO_EPI3") == nullptr;
   const bool lone = tiles <= vptr_cu_count() && (p16_epi_rows_flag() & 16) == 0;   // at most one workgroup per CU
   const int rows = lean ? 1 : (p16_epi_rows_flag() & 2);
   if (d.frame_stats)   // served by the lean epilogue only: no fallback
@@ -565,7 +571,9 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
     else vptr_gemm_p16_kernel<2, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, 1);
     return 0;
   }
-  if (lean && lone) vptr_gemm_p16_kernel<1, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, rows);
+  if (lean3 && lone) vptr_gemm_p16_kernel<3, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, 1);
+  else if (lean3) vptr_gemm_p16_kernel<3, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, 1);
+  else if (lean && lone) vptr_gemm_p16_kernel<1, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, rows);
   else if (lean) vptr_gemm_p16_kernel<1, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, rows);
   else if (lone) vptr_gemm_p16_kernel<0, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, rows);
   else vptr_gemm_p16_kernel<0, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, rows);

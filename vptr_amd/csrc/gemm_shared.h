@@ -324,7 +324,8 @@ __device__ __forceinline__ void gemm_epilogue_rows_halves(const vptr_gemm_desc& 
 // LEAN: the instantiation for the plain launches (bias, alpha, residual, fp32 or P16 output only -- most launches of a step): the
 // other options are compiled out, which keeps the code a workgroup walks through after its K loop short (the full epilogue is
 // ~20 k instructions of mostly skipped branches; measured +9 us on a 25 us K = 528 GEMM).
-template <int NFN, int EPI>   // EPI: 0 every option, 1 lean (bias / alpha / residual), 2 activation gradient (desc.act_grad_src)
+template <int NFN, int EPI>   // EPI: 0 every option, 1 lean (bias / alpha / residual), 2 activation gradient (desc.act_grad_src),
+                              //      3 lean + DropPath row scale + dropout (out-projections, linear2: `x + drop_path(dropout(proj(.)))`)
 __device__ __forceinline__ void gemm_epilogue_rows_halves_batched(const vptr_gemm_desc& p, const Member& mb, f32x4 (&acc)[2][(NFN + 1) / 2], float* sE,
                                                           const int m0, const int n0, const int wm, const int wn, const int lr, const int lq,
                                                           const int tid, const bool first_split, const bool use_atomic_in, long long* tm = nullptr) {
@@ -335,9 +336,9 @@ __device__ __forceinline__ void gemm_epilogue_rows_halves_batched(const vptr_gem
   const bool use_atomic = !LEAN && use_atomic_in;
   const float* const colscale = LEAN ? nullptr : p.colscale;
   float* const Dpre = LEAN ? nullptr : p.Dpre;
-  const float* const rowscale = LEAN ? nullptr : p.rowscale;
+  const float* const rowscale = (LEAN && EPI != 3) ? nullptr : p.rowscale;
   const auto D_planes = LEAN ? decltype(p.D_planes)(nullptr) : p.D_planes;
-  const int act = EPI == 1 ? VPTR_ACT_NONE : p.act;
+  const int act = (EPI == 1 || EPI == 3) ? VPTR_ACT_NONE : p.act;
   const float dropout_p = EPI == 1 ? 0.f : p.dropout_p;
   const bool act_after = !LEAN && p.act_after;
   uint64_t seed = 0;
