@@ -134,6 +134,10 @@ typedef struct vptr_gemm_desc {
      the NHWC output: each class is an ordinary stride-1 gather over the INPUT grid with 1, 2, 2 or 4 taps instead of a 9-tap
      gather form in which three quarters of the products are zeros. */
   int d_row_w, d_row_off;
+  /* a_mode = VPTR_A_P16, plain launches (bias / alpha only) with batch > 1: bit i set = member i ACCUMULATES, D_i += result (its own
+     output is its residual).  The input gradients of the encoder memory arrive from the encoder-decoder attention of every decoder
+     block (VidHRFormer_modules.py:199-206): with this flag they are summed by the GEMMs instead of one autograd `add` per block. */
+  int batch_accum;
 } vptr_gemm_desc;
 
 int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream);

@@ -42,6 +42,7 @@ class GemmDesc(ctypes.Structure):
         ("frame_stats", c_void_p), ("frame_rows", c_int),
         ("d_transposed", c_int),
         ("d_row_w", c_int), ("d_row_off", c_int),
+        ("batch_accum", c_int),
     ]
 
 

@@ -571,6 +571,8 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
     else vptr_gemm_p16_kernel<2, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, 1);
     return 0;
   }
+  if (d.batch_accum)
+    VPTR_CHECK(lean && d.batch > 1 && !d.d_p16 && (d.batch_accum >> d.batch) == 0, "vptr_gemm(p16): batch_accum is an option of plain fp32-output batch launches");
   if (lean3 && lone) vptr_gemm_p16_kernel<3, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, 1);
   else if (lean3) vptr_gemm_p16_kernel<3, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, 1);
   else if (lean && lone) vptr_gemm_p16_kernel<1, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, rows);

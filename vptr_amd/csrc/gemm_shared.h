@@ -43,9 +43,11 @@ struct Member {
   float* D;
   const float* bias;
   float alpha;
+  const float* res;   // residual of this member (row pitch ldr): desc.residual for member 0; the member's own D when it accumulates
+  int64_t ldr;        // (desc.batch_accum) -- honoured by gemm_epilogue_rows_halves_batched only (the host admits nothing else)
 };
 __device__ __forceinline__ Member member_of(const vptr_gemm_desc& p, const int member) {
-  Member m = {p.A, p.B, p.D, p.bias, p.alpha};
+  Member m = {p.A, p.B, p.D, p.bias, p.alpha, p.residual, p.ldr};
   if (member > 0) {  // workgroup-uniform
     const bool one = member == 1;
     m.A = one ? p.A_x1 : p.A_x2;
@@ -53,7 +55,9 @@ __device__ __forceinline__ Member member_of(const vptr_gemm_desc& p, const int m
     m.D = one ? p.D_x1 : p.D_x2;
     m.bias = one ? p.bias_x1 : p.bias_x2;
     m.alpha = one ? p.alpha_x1 : p.alpha_x2;
+    m.res = nullptr;
   }
+  if ((p.batch_accum >> member) & 1) { m.res = m.D; m.ldr = p.ldd; }
   return m;
 }
 
@@ -331,7 +335,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_halves_batched(const vptr_gem
                                                           const int tid, const bool first_split, const bool use_atomic_in, long long* tm = nullptr) {
   constexpr int NFW = (NFN + 1) / 2, BN = 16 * NFN, PITCH = BN + 4, C4 = BN / 4, HR = GBM / 2, NPIECE = HR * C4;
   constexpr bool LEAN = EPI != 0, GRAD = EPI == 2;
-  const bool has_res = !GRAD && p.residual && first_split;
+  const bool has_res = !GRAD && mb.res && first_split;
   const bool has_bias = !GRAD && mb.bias && first_split;
   const bool use_atomic = !LEAN && use_atomic_in;
   const float* const colscale = LEAN ? nullptr : p.colscale;
@@ -370,7 +374,7 @@ __device__ __forceinline__ void gemm_epilogue_rows_halves_batched(const vptr_gem
       const int row = m0 + h * HR + rl, col = n0 + (piece - rl * C4) * 4;
       const bool ok = piece < NPIECE && row < p.M && col < p.N;
       res[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (has_res && ok) res[it] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)row * p.ldr + col);
+      if (has_res && ok) res[it] = *reinterpret_cast<const f32x4*>(mb.res + (int64_t)row * mb.ldr + col);
       if (GRAD && ok) res[it] = *reinterpret_cast<const f32x4*>(p.act_grad_src + (int64_t)row * p.ldd + col);   // the saved pre-activations
       rsv[it] = (rowscale && ok) ? rowscale[(row / p.rs_div) % p.rs_mod] : 1.f;
     }

@@ -265,14 +265,14 @@ class MlpDWBN(nn.Module):
 
 
 def _mha_tokens(mha, q_in, k_in, v_in, residual, Nb, Tq, Tk, HW, causal, p_attn, site, out_dropout=0.0, out_site=0,
-                rowscale=None, rs_div=1, rs_mod=1, merge_v_grad=False, x_p16=False):
+                rowscale=None, rs_div=1, rs_mod=1, merge_v_grad=False, x_p16=False, kv_acc=None):
     """Stock nn.MultiheadAttention (packed in_proj) over time on token-major inputs (VidHRFormer_modules.py:79-84).
     merge_v_grad: q_in is k_in = v_in + a table that needs no gradient, so the three input gradients may be returned as one."""
     C, nh = mha.embed_dim, mha.num_heads
     w, b = mha.in_proj_weight, mha.in_proj_bias
     P = ops.p16_ok(C)
     o = ops.proj_temporal_attention(q_in, k_in, v_in, w[:C], b[:C], w[C:2 * C], b[C:2 * C], w[2 * C:], b[2 * C:], Nb, Tq, Tk, HW, nh,
-                                    causal, p_attn, site, merge_v_grad=merge_v_grad, x_p16=x_p16, o_p16=P)
+                                    causal, p_attn, site, merge_v_grad=merge_v_grad, x_p16=x_p16, o_p16=P, kv_acc=kv_acc)
     return ops.linear(o, mha.out_proj.weight, mha.out_proj.bias, residual=residual, dropout_p=out_dropout, site=out_site,
                       rowscale=rowscale, rs_div=rs_div, rs_mod=rs_mod, x_p16=P)
 
@@ -384,7 +384,7 @@ class VidHRFormerBlockDecNAR(nn.Module):
         self.drop_path_p = drop_path
         self._site = 0
 
-    def forward_tokens(self, tgt, g, qpos_tab, qpos_tpos_tab, mem, mem_k, T1, lw_pos, tpos_f, Tlw_pos=None):
+    def forward_tokens(self, tgt, g, qpos_tab, qpos_tpos_tab, mem, mem_k, T1, lw_pos, tpos_f, Tlw_pos=None, kv_acc=None):
         """tgt [N*T2*HW, C]; qpos_tab = frame_queries as [T2*HW, C]; qpos_tpos_tab = frame_queries + tpos_f per (t, pixel);
         mem, mem_k = memory and memory + past temporal pos, [N*T1*HW, C]; tpos_f (T2, C); Tlw_pos (T1+T2, ws, ws, C)."""
         HW = g.H * g.W
@@ -429,7 +429,7 @@ class VidHRFormerBlockDecNAR(nn.Module):
                                       eps=self.norm5.eps, passthrough=True, out_p16=P,
                                       tab_grad_to=None if tpos_f.requires_grad else qpos_tab)
             x = _mha_tokens(self.EncDecAttn, uq, mem_k, mem, xr, g.N, T2, T1, HW, False, p, s + 7, rowscale=dpt, rs_div=HW, rs_mod=T2,
-                            x_p16=P)
+                            x_p16=P, kv_acc=kv_acc)
         dp = _droppath_scale(self.drop_path_p, self.training, g.N, tgt.device)
         u, xr = ops.layernorm(x, self.norm6.weight, self.norm6.bias, eps=self.norm6.eps, passthrough=True, out_p16=P)
         return self.SpatialFFN1.forward_tokens(u, xr, g, s + 8, rowscale=dp, rs_div=per_n, rs_mod=g.N, x_p16=P)
@@ -453,8 +453,10 @@ class VidHRformerDecoderNAR(nn.Module):
             # the encoder-decoder attentions of all layers project the same memory: its two P16 images are made once
             mem, mem_k = ops.as_p16(mem), ops.as_p16(mem_k)
         x = tgt
+        # every layer's encoder-decoder attention reads the same (mem_k, mem): their input gradients are summed inside the GEMMs
+        kv_acc = ops.KVGradAccum() if (torch.is_grad_enabled() and mem.requires_grad and len(self.layers) > 1) else None
         for layer in self.layers:
-            x = layer.forward_tokens(x, g, qpos_tab, qpos_tpos_tab, mem, mem_k, T1, lw_pos, tpos_f, Tlw_pos)
+            x = layer.forward_tokens(x, g, qpos_tab, qpos_tpos_tab, mem, mem_k, T1, lw_pos, tpos_f, Tlw_pos, kv_acc=kv_acc)
         if self.norm is not None:
             x = ops.layernorm(x, self.norm.weight, self.norm.bias, eps=self.norm.eps)
         return x

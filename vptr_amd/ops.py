@@ -127,7 +127,7 @@ def _c(t):
 def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None, colscale=None, alpha=1.0, act=ACT_NONE,
              Dpre=None, rowscale=None, rs_div=1, rs_mod=1, dropout_p=0.0, site=0, residual=None, act_after=False,
              atomic=False, split_k=1, conv=None, precision=None, seed=None, a_rowsum=None, batch_extra=None, kseg_extra=None,
-             planes_out=None, d_p16=False, act_grad_src=None, frame_stats=None, frame_rows=0, row_map=None, ldd=None):
+             planes_out=None, d_p16=False, act_grad_src=None, frame_stats=None, frame_rows=0, row_map=None, ldd=None, batch_accum=0):
     """One vptr_gemm launch.  batch_extra = [(A, B, D, bias, alpha), ...] adds up to two same-shaped independent problems to
     the grid; kseg_extra = [(A, B), ...] adds up to two K-segments accumulated into the same D (include/vptr_hip.h)."""
     d = GemmDesc()
@@ -152,6 +152,7 @@ def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None
     d.ldd = ldd if ldd is not None else (D.stride(0) if D is not None else N)
     if row_map is not None:
         d.d_row_w, d.d_row_off = int(row_map[0]), int(row_map[1])
+    d.batch_accum = int(batch_accum)
     d.M, d.N, d.K = M, N, K
     d.a_mode, d.b_mode = a_mode, b_mode
     d.precision = precision if precision is not None else config.gemm_precision
@@ -1153,6 +1154,16 @@ def temporal_attention(q, k, v, Nb, Tq, Tk, HW, nh, causal=False, dropout_p=0.0,
     return _TAttnFn_apply(q, k, v, int(Nb), int(Tq), int(Tk), int(HW), int(nh), int(bool(causal)), float(dropout_p), int(site))
 
 
+class KVGradAccum:
+    """Shared accumulators for the input gradients of ONE key / value source that several attentions read (the encoder memory of the
+    8 decoder blocks): every `_ProjAttnFn` forward that is handed the object counts itself in; in backward the first one allocates the
+    two [Mk, K] buffers, the following ones add into them inside their input-gradient GEMM (vptr_gemm_desc.batch_accum), and the LAST
+    one hands the sums to autograd -- the others return None.  One object per forward pass."""
+
+    def __init__(self):
+        self.uses, self.k, self.v = 0, None, None
+
+
 class _ProjAttnFn(torch.autograd.Function):
     """o = attention(alpha * (xq Wq^T + bq), xk Wk^T + bk, xv Wv^T + bv), alpha = head_dim^-0.5: the q/k/v projections
     (MultiHeadAttentionRPE.py:543-545,586; nn.MultiheadAttention's in_proj, VidHRFormer_modules.py:79-84) and the attention
@@ -1170,8 +1181,12 @@ class _ProjAttnFn(torch.autograd.Function):
     (xq = xv + a constant table): the whole input gradient is then returned for xq and None for xv."""
 
     @staticmethod
-    def forward(ctx, xq, xk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, kind, geom, nh, p, site, same_qk, same_v, merge_v, x_p16, o_p16):
+    def forward(ctx, xq, xk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, kind, geom, nh, p, site, same_qk, same_v, merge_v, x_p16, o_p16,
+                kv_acc=None):
         _lib.require_cuda(xq, xk, xv, Wq)
+        ctx.kv_acc = kv_acc
+        if kv_acc is not None:
+            kv_acc.uses += 1
         xq, xk, xv = _c(xq), _c(xk), _c(xv)
         Wq, Wk, Wv = _c(Wq), _c(Wk), _c(Wv)
         Mq, K = xq.shape
@@ -1268,6 +1283,17 @@ class _ProjAttnFn(torch.autograd.Function):
                 dxq = dgrad(dq, Tq_, new(Mq), Mq, kseg_extra=[(dk, Tk_)])
             if need[2]:
                 dxv = dgrad(dv, Tv_, new(Mk), Mk)
+        elif need[0] and need[1] and need[2] and Mq == Mk and use and ctx.kv_acc is not None:
+            acc = ctx.kv_acc     # shared key / value source: sum the gradients inside the GEMMs (see KVGradAccum)
+            first = acc.k is None
+            if first:
+                acc.k, acc.v = new(Mk), new(Mk)
+            dxq = new(Mq)
+            dgrad(dq, Tq_, dxq, Mq, batch_extra=[(dk, Tk_, acc.k, None, 1.0), (dv, Tv_, acc.v, None, 1.0)], batch_accum=0 if first else 0b110)
+            acc.uses -= 1
+            if acc.uses == 0:
+                dxk, dxv = acc.k, acc.v
+                acc.k = acc.v = None
         elif need[0] and need[1] and need[2] and Mq == Mk:
             dxq, dxk, dxv = new(Mq), new(Mk), new(Mk)
             dgrad(dq, Tq_, dxq, Mq, batch_extra=[(dk, Tk_, dxk, None, 1.0), (dv, Tv_, dxv, None, 1.0)])
@@ -1281,17 +1307,18 @@ class _ProjAttnFn(torch.autograd.Function):
                 dxk = dgrad(dk, Tk_, new(Mk), Mk)
             elif need[2]:
                 dxv = dgrad(dv, Tv_, new(Mk), Mk)
-        return (dxq, dxk, dxv, dWq, dbq, dWk, dbk, dWv, dbv, dtable) + (None,) * 11
+        return (dxq, dxk, dxv, dWq, dbq, dWk, dbk, dWv, dbv, dtable) + (None,) * 12
 
 
 _ProjAttnFn_apply = _direct_apply(_ProjAttnFn)
 
 
-def _proj_attention(xq, xk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, kind, geom, nh, p, site, merge_v_grad, x_p16=False, o_p16=False):
+def _proj_attention(xq, xk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, kind, geom, nh, p, site, merge_v_grad, x_p16=False, o_p16=False,
+                    kv_acc=None):
     same_qk = xk is xq
     same_v = same_qk and xv is xq
     return _ProjAttnFn_apply(xq, xk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, kind, geom, int(nh), float(p), int(site),
-                             same_qk, same_v, bool(merge_v_grad) and same_qk, bool(x_p16), bool(o_p16))
+                             same_qk, same_v, bool(merge_v_grad) and same_qk, bool(x_p16), bool(o_p16), kv_acc)
 
 
 def proj_window_attention(xqk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, B, H, W, nh, ws, dropout_p=0.0, site=0,
@@ -1303,10 +1330,11 @@ def proj_window_attention(xqk, xv, Wq, bq, Wk, bk, Wv, bv, table, rel_index, B, 
 
 
 def proj_temporal_attention(q_in, k_in, v_in, Wq, bq, Wk, bk, Wv, bv, Nb, Tq, Tk, HW, nh, causal=False, dropout_p=0.0, site=0,
-                            merge_v_grad=False, x_p16=False, o_p16=False):
-    """Temporal attention INCLUDING its q/k/v projections; q_in [(n,tq,p), C], k_in, v_in [(n,tk,p), C]."""
+                            merge_v_grad=False, x_p16=False, o_p16=False, kv_acc=None):
+    """Temporal attention INCLUDING its q/k/v projections; q_in [(n,tq,p), C], k_in, v_in [(n,tk,p), C].
+    kv_acc: a KVGradAccum shared by every attention that reads the same k_in / v_in tensors (gradients summed inside the GEMMs)."""
     return _proj_attention(q_in, k_in, v_in, Wq, bq, Wk, bk, Wv, bv, None, None, 1,
-                           (int(Nb), int(Tq), int(Tk), int(HW), int(bool(causal))), nh, dropout_p, site, merge_v_grad, x_p16, o_p16)
+                           (int(Nb), int(Tq), int(Tk), int(HW), int(bool(causal))), nh, dropout_p, site, merge_v_grad, x_p16, o_p16, kv_acc)
 
 
 class _TSAttnFn(torch.autograd.Function):
