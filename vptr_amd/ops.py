@@ -71,7 +71,11 @@ def _master_seed(device):
     masks, as the reference's per-process RNG streams do."""
     key = _dev_key(device)
     if key not in _seed_state:
-        rank = int(os.environ.get("RANK", "0"))
+        # the rank of the initialised process group (mp.spawn workers carry no RANK variable), else the launcher's RANK
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        else:
+            rank = int(os.environ.get("RANK", "0"))
         v = (torch.initial_seed() * 0x9E3779B97F4A7C15 + (rank + 1) * 0xBF58476D1CE4E5B9 + (key + 1) * 0x94D049BB133111EB) & 0x7FFFFFFFFFFFFFFF
         _seed_state[key] = torch.full((1,), v, dtype=torch.int64, device=device)
     return _seed_state[key]
@@ -490,8 +494,13 @@ _graph_keepalive = []   # pinned upload sources of captured launches (must outli
 _graph_reserve = []     # pinned buffers set aside for the next capture
 
 
+_upload_stats = {"count": 0, "max_bytes": 0}   # table uploads since the last reset (NARTrainer.capture sizes its reserve from a warm-up step)
+
+
 def reserve_graph_staging(count=8, nbytes=1 << 18):
-    """set `count` pinned staging buffers aside for the host-built tables of a whole-step graph capture"""
+    """set `count` pinned staging buffers of `nbytes` aside for the host-built tables of a whole-step graph capture (pinned memory
+    cannot be allocated while capturing); buffers that are too small are replaced"""
+    _graph_reserve[:] = [b for b in _graph_reserve if b.numel() >= nbytes]
     while len(_graph_reserve) < count:
         _graph_reserve.append(torch.empty(nbytes, dtype=torch.uint8).pin_memory())
 
@@ -501,6 +510,8 @@ def _to_device_async(host_bytes, dev):
     `.to(device)` would block the host until every kernel enqueued so far has finished (once per step, right where the host
     should be running ahead into the optimizer and the next forward pass)."""
     n = len(host_bytes)
+    _upload_stats["count"] += 1
+    _upload_stats["max_bytes"] = max(_upload_stats["max_bytes"], n)
     if os.environ.get("VPTR_SYNC_UPLOAD") == "1":
         return torch.frombuffer(bytearray(host_bytes), dtype=torch.uint8).to(dev)
     if torch.cuda.is_current_stream_capturing():

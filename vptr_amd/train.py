@@ -385,13 +385,17 @@ class NARTrainer:
         if self.pg is not None and self.world > 1:
             raise RuntimeError("graph capture of the data-parallel step is not enabled (RCCL calls stay eager)")
         self._static_past, self._static_future = past.clone(), future.clone()
-        ops.reserve_graph_staging()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(warmup):
+            for i in range(max(warmup, 1)):
+                if i == max(warmup, 1) - 1:
+                    ops._upload_stats.update(count=0, max_bytes=0)
                 self._step_impl(self._static_past, self._static_future)
         torch.cuda.current_stream().wait_stream(s)
+        # the captured step uploads as many host-built tables as the last warm-up step did (grouped launches: 2 per group, more with
+        # the GAN branch or non-P16 groups); each gets a pinned buffer of its own that lives as long as the graph
+        ops.reserve_graph_staging(count=ops._upload_stats["count"] + 2, nbytes=max(1 << 16, 2 * ops._upload_stats["max_bytes"]))
         g = torch.cuda.CUDAGraph(keep_graph=True)
         with torch.cuda.graph(g):
             self._static_out = self._step_impl(self._static_past, self._static_future)
