@@ -84,3 +84,28 @@ def test_flat_adamw_state_round_trip_through_torch_adamw(dev, fixture):
     topt.step()
     e = _update_err(T3.state_dict(), T2.state_dict(), before, [k for k, _ in T2.named_parameters()])
     assert e < 2e-3, "fourth step after importing torch.optim.AdamW state: update differs by %.3e" % e
+
+
+def test_two_optimizers_and_collection_keep_gradient_destinations(dev):
+    """process-wide slab registry: two FlatAdamW slabs alive at once route gradients by address; closing / collecting one (even after
+    a new slab was allocated at its address) leaves the other's registration intact"""
+    import gc
+    from vptr_amd import ops
+    from vptr_amd.train import FlatAdamW
+    ops.unregister_flat_slabs()
+    a = [torch.nn.Parameter(torch.randn(32, 16, device=dev)), torch.nn.Parameter(torch.randn(32, device=dev))]
+    b = [torch.nn.Parameter(torch.randn(48, 16, device=dev))]
+    oa, ob = FlatAdamW(a), FlatAdamW(b)
+    assert ops.flat_grad_for(a[0]).data_ptr() == oa.grad.data_ptr() and ops.flat_grad_for(b[0]).data_ptr() == ob.grad.data_ptr()
+    oa.close()
+    assert ops.flat_grad_for(a[0]) is None and ops.flat_grad_for(b[0]).data_ptr() == ob.grad.data_ptr()
+    del oa, a
+    gc.collect()
+    torch.cuda.empty_cache()
+    c = [torch.nn.Parameter(torch.randn(32, 16, device=dev)), torch.nn.Parameter(torch.randn(32, device=dev))]
+    oc = FlatAdamW(c)          # may reuse the collected slab's address
+    del ob
+    gc.collect()
+    assert ops.flat_grad_for(c[0]) is not None and ops.flat_grad_for(c[0]).data_ptr() == oc.grad.data_ptr()
+    oc.close()
+    ops.unregister_flat_slabs()

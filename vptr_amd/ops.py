@@ -667,9 +667,9 @@ def unregister_flat_slabs():
 
 
 def unregister_flat_slab(param_slab):
-    """drop the registration of one slab (FlatAdamW.close / __del__)"""
-    base = param_slab.data_ptr()
-    _flat_slabs[:] = [e for e in _flat_slabs if e[0] != base]
+    """drop the registration of ONE slab (FlatAdamW.close / __del__) and of slabs that no longer exist -- by identity, not by address:
+    a later optimizer's slab may have been given the address of a collected one"""
+    _flat_slabs[:] = [e for e in _flat_slabs if e[2]() is not None and e[2]() is not param_slab]
 
 
 def flat_grad_for(t):
