@@ -232,6 +232,16 @@ int vptr_winattn_bwd(const float* q, const float* k, const float* v, const float
                      const float* dout, float* dq, float* dk, float* dv, float* dbias_table, int B, int H, int W, int C,
                      int nh, int ws, float dropout_p, const uint64_t* seed_dev, uint32_t site, float dq_scale,
                      int p16, vptr_stream_t stream);
+/* The same with a caller-owned scratch buffer of vptr_winattn_bwd_workspace(nh) floats (16-byte aligned, contents irrelevant
+ * before and after the call): the MFMA kernel for 4 x 4 windows then leaves its bias-table gradient as per-workgroup partial
+ * sums that a small second kernel adds into dbias_table in a fixed order -- no atomics onto the table's 49 * nh words
+ * (which cost as much as the rest of the kernel) and a run-to-run reproducible table gradient.  workspace == null, a
+ * workspace that is too small, or a geometry that other kernels serve: behaves like vptr_winattn_bwd. */
+int vptr_winattn_bwd_ws(const float* q, const float* k, const float* v, const float* bias_table, const int64_t* rel_index,
+                        const float* dout, float* dq, float* dk, float* dv, float* dbias_table, int B, int H, int W, int C,
+                        int nh, int ws, float dropout_p, const uint64_t* seed_dev, uint32_t site, float dq_scale,
+                        int p16, float* workspace, int workspace_floats, vptr_stream_t stream);
+int vptr_winattn_bwd_workspace(int nh);   /* floats; a plain number, not an error code */
 
 /* ------------------------------------------------------------------------------------------------
  * Temporal attention core (nn.MultiheadAttention slow path, VidHRFormer_modules.py:74-84,183-187,199-206):

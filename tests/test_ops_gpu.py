@@ -302,20 +302,21 @@ def test_rowtab_colsum(ops, dev):
 TOLA = 5e-5   # attention cores: split-bf16 MFMA products (forward; gradients 1e-4)
 
 
-@pytest.fixture(params=["default", "attn16", "mfma", "vector"])
+@pytest.fixture(params=["default", "attn16", "attn16fwd", "mfma", "vector"])
 def attn_mode(request):
-    """every attention geometry through all kernel families: the default (problems of at most 16 tokens: forward on the LDS-free MFMA
-    kernels of attn16.hip, backward on the fp32 vector kernels; larger ones on the LDS-staged MFMA kernels of attn_mfma.hip),
-    VPTR_ATTN16=2 (attn16.hip forward AND backward), VPTR_ATTN_MFMA=2 (attn_mfma.hip wherever it covers the geometry) and
-    VPTR_ATTN_MFMA=0 (the fp32 vector kernels of attn.hip everywhere)"""
+    """every attention geometry through all kernel families: the default (problems of at most 16 tokens on the MFMA kernels of
+    attn16.hip -- forward without LDS, backward of the second generation when C % 4 == 0; larger ones on the LDS-staged MFMA kernels of
+    attn_mfma.hip), VPTR_ATTN16=2 (attn16.hip forward + its first-generation backward), VPTR_ATTN16=4 (attn16.hip forward, fp32 vector
+    backward), VPTR_ATTN_MFMA=2 (attn_mfma.hip wherever it covers the geometry) and VPTR_ATTN_MFMA=0 (the fp32 vector kernels of
+    attn.hip everywhere)"""
     import os
     old = os.environ.get("VPTR_ATTN_MFMA")
     old16 = os.environ.get("VPTR_ATTN16")
     os.environ.pop("VPTR_ATTN16", None)
-    if request.param in ("default", "attn16"):
+    if request.param in ("default", "attn16", "attn16fwd"):
         os.environ.pop("VPTR_ATTN_MFMA", None)
-        if request.param == "attn16":
-            os.environ["VPTR_ATTN16"] = "2"
+        if request.param != "default":
+            os.environ["VPTR_ATTN16"] = "2" if request.param == "attn16" else "4"
     else:
         os.environ["VPTR_ATTN_MFMA"] = "2" if request.param == "mfma" else "0"
     yield request.param

@@ -37,7 +37,11 @@ for p in (0.1, 0.0):
         f = timed(lambda: check(lib.vptr_winattn_fwd(ptr(q), ptr(k), ptr(v), ptr(tb), ptr(idx), ptr(o), B, H, W, C, nh, ws, p, ptr(seed), 3, P16, stream()), "f"))
         b = timed(lambda: check(lib.vptr_winattn_bwd(ptr(q), ptr(k), ptr(v), ptr(tb), ptr(idx), ptr(do), ptr(dq), ptr(dk), ptr(dv),
                                                      ptr(dtable) if tb is not None else None, B, H, W, C, nh, ws, p, ptr(seed), 3, 1.0, P16, stream()), "b"))
-        print("window   p=%.1f bias=%d  fwd %6.1f us  bwd %6.1f us" % (p, tb is not None, f, b))
+        wsp = torch.empty(lib.vptr_winattn_bwd_workspace(nh), device=dev)
+        b2 = timed(lambda: check(lib.vptr_winattn_bwd_ws(ptr(q), ptr(k), ptr(v), ptr(tb), ptr(idx), ptr(do), ptr(dq), ptr(dk), ptr(dv),
+                                                         ptr(dtable) if tb is not None else None, B, H, W, C, nh, ws, p, ptr(seed), 3, 1.0, P16,
+                                                         ptr(wsp), wsp.numel(), stream()), "b"))
+        print("window   p=%.1f bias=%d  fwd %6.1f us  bwd %6.1f us  bwd with workspace %6.1f us" % (p, tb is not None, f, b, b2))
 N, T, HW = 16, 10, 64
 for p in (0.1, 0.0):
     f = timed(lambda: check(lib.vptr_tattn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), N, T, T, HW, C, nh, 0, p, ptr(seed), 3, P16, stream()), "f"))

@@ -68,6 +68,8 @@ SIGNATURES = {
     "vptr_add_rowtab": [P, P, P, I, I, I, I, P],
     "vptr_winattn_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, I, P],
     "vptr_winattn_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, F, I, P],
+    "vptr_winattn_bwd_ws": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, F, I, P, I, P],
+    "vptr_winattn_bwd_workspace": [I],
     "vptr_tattn_fwd": [P, P, P, P, I, I, I, I, I, I, I, F, P, U, I, P],
     "vptr_tattn_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, P, U, F, I, P],
     "vptr_tsattn_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, F, P, U, I, P],
@@ -117,7 +119,7 @@ def _load():
         fn.restype = c_int
     lib.vptr_abi_version.restype = c_int
     lib.vptr_last_error.restype = ctypes.c_char_p
-    if lib.vptr_abi_version() != 6:
+    if lib.vptr_abi_version() != 7:
         raise ImportError("vptr_amd: ABI version mismatch in %s" % LIB_PATH)
     return lib
 

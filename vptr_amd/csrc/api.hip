@@ -13,4 +13,4 @@ void vptr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* vptr_last_error(void) { return g_err; }
-extern "C" int vptr_abi_version(void) { return 6; }
+extern "C" int vptr_abi_version(void) { return 7; }

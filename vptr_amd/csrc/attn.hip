@@ -437,10 +437,20 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const float* __restric
     for (int i = tid; i < ntab; i += 256) unsafeAtomicAdd(dtable + (int64_t)i * nh + h, stab[i]);
 }
 
+extern "C" int vptr_winattn_bwd_workspace(int nh) { return (int)vptr_attn16_ws_floats(nh); }
 extern "C" int vptr_winattn_bwd(const float* q, const float* k, const float* v, const float* bias_table,
                                 const int64_t* rel_index, const float* dout, float* dq, float* dk, float* dv,
                                 float* dbias_table, int B, int H, int W, int C, int nh, int ws, float dropout_p,
                                 const uint64_t* seed_dev, uint32_t site, float dq_scale, int p16, vptr_stream_t stream) {
+  return vptr_winattn_bwd_ws(q, k, v, bias_table, rel_index, dout, dq, dk, dv, dbias_table, B, H, W, C, nh, ws, dropout_p, seed_dev, site, dq_scale, p16,
+                             nullptr, 0, stream);
+}
+extern "C" int vptr_winattn_bwd_ws(const float* q, const float* k, const float* v, const float* bias_table,
+                                   const int64_t* rel_index, const float* dout, float* dq, float* dk, float* dv,
+                                   float* dbias_table, int B, int H, int W, int C, int nh, int ws, float dropout_p,
+                                   const uint64_t* seed_dev, uint32_t site, float dq_scale, int p16, float* workspace,
+                                   int workspace_floats, vptr_stream_t stream) {
+  if (workspace) VPTR_CHECK((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && workspace_floats > 0, "winattn_bwd: bad workspace");
   if (p16) VPTR_CHECK(C % 16 == 0, "winattn_bwd: P16 outputs need C %% 16 == 0 (got %d)", C);
   VPTR_CHECK(B > 0 && H > 0 && W > 0 && C > 0 && nh > 0 && ws > 0, "winattn_bwd: bad arguments");
   VPTR_CHECK(C % nh == 0 && H % ws == 0 && W % ws == 0 && ws * ws <= ATT_MAXL, "winattn_bwd: unsupported geometry");
@@ -459,7 +469,7 @@ extern "C" int vptr_winattn_bwd(const float* q, const float* k, const float* v, 
   if (vptr_attn16_ok(0, L, L, C, nh, ws, 1)) {
     A16Geom g16 = {0, H, W, 0, 0, 0, C, nh, hd, 16, 16, nwin, 0};
     const int rc = vptr_attn16_bwd(q, k, v, bias_table, rel_index, dout, dq, dk, dv, dbias_table, g16, dropout_p, seed_dev, site, dq_scale, p16,
-                                   (hipStream_t)stream);
+                                   workspace, workspace_floats, (hipStream_t)stream);
     if (rc) return rc;
     VPTR_LAUNCH_CHECK();
     return 0;
@@ -894,7 +904,7 @@ extern "C" int vptr_tattn_bwd(const float* q, const float* k, const float* v, co
   }
   if (vptr_attn16_ok(1, Tq, Tk, C, nh, 0, 1)) {
     A16Geom g16 = {1, 0, 0, Tq, Tk, HW, C, nh, hd, Tq, Tk, Nb * HW, causal};
-    const int rc = vptr_attn16_bwd(q, k, v, nullptr, nullptr, dout, dq, dk, dv, nullptr, g16, dropout_p, seed_dev, site, dq_scale, p16,
+    const int rc = vptr_attn16_bwd(q, k, v, nullptr, nullptr, dout, dq, dk, dv, nullptr, g16, dropout_p, seed_dev, site, dq_scale, p16, nullptr, 0,
                                    (hipStream_t)stream);
     if (rc) return rc;
     VPTR_LAUNCH_CHECK();

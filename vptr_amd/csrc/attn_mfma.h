@@ -34,4 +34,5 @@ int vptr_attn16_fwd(const float* q, const float* k, const float* v, const float*
                     const uint64_t* seed_dev, uint32_t site, int p16, hipStream_t st);
 int vptr_attn16_bwd(const float* q, const float* k, const float* v, const float* table, const int64_t* rel_index, const float* dout, float* dq, float* dk,
                     float* dv, float* dtable, const A16Geom& g, float p, const uint64_t* seed_dev, uint32_t site, float dq_scale, int p16,
-                    hipStream_t st);
+                    float* dtable_ws, int64_t ws_floats, hipStream_t st);
+int64_t vptr_attn16_ws_floats(int nh);

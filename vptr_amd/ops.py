@@ -1096,6 +1096,12 @@ def add_rowtab(x, tab, div, mod):
 # ------------------------------------------------------------------------------------------------------------------
 # attention cores
 # ------------------------------------------------------------------------------------------------------------------
+def _winattn_workspace(device, nh):
+    """scratch of one window-attention backward call (the bias-table gradient's per-workgroup partial sums, vptr_winattn_bwd_ws):
+    a fresh caching-allocator block per call -- stream-ordered like every other temporary, so calls may overlap nothing"""
+    return torch.empty((lib.vptr_winattn_bwd_workspace(int(nh)),), device=device, dtype=torch.float32)
+
+
 class _WinAttnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, table, rel_index, B, H, W, nh, ws, p, site):
@@ -1117,9 +1123,10 @@ class _WinAttnFn(torch.autograd.Function):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
         slab = flat_grad_for(table)
         dtable = slab if slab is not None else (torch.zeros_like(table) if table is not None else None)
-        check(lib.vptr_winattn_bwd(ptr(q), ptr(k), ptr(v), ptr(table), ptr(rel_index), ptr(do), ptr(dq), ptr(dk), ptr(dv),
-                                   ptr(dtable), B, H, W, q.shape[1], nh, ws, p, ptr(ctx.seed), site, 1.0, 0, stream()),
-              "vptr_winattn_bwd")
+        wsp = _winattn_workspace(q.device, nh) if dtable is not None else None
+        check(lib.vptr_winattn_bwd_ws(ptr(q), ptr(k), ptr(v), ptr(table), ptr(rel_index), ptr(do), ptr(dq), ptr(dk), ptr(dv),
+                                      ptr(dtable), B, H, W, q.shape[1], nh, ws, p, ptr(ctx.seed), site, 1.0, 0, ptr(wsp),
+                                      wsp.numel() if wsp is not None else 0, stream()), "vptr_winattn_bwd_ws")
         if slab is not None:
             dtable = None
         return dq, dk, dv, dtable, None, None, None, None, None, None, None, None
@@ -1260,8 +1267,10 @@ class _ProjAttnFn(torch.autograd.Function):
             B, H, W, ws = geom
             slab = flat_grad_for(table) if table is not None else None
             dtable = slab if slab is not None else (torch.zeros_like(table) if table is not None else None)
-            check(lib.vptr_winattn_bwd(ptr(q), ptr(k), ptr(v), ptr(table), ptr(rel_index), ptr(do), ptr(dq), ptr(dk), ptr(dv),
-                                       ptr(dtable), B, H, W, N, nh, ws, p, ptr(ctx.seed), site, alpha, int(use), stream()), "vptr_winattn_bwd")
+            wsp = _winattn_workspace(q.device, nh) if dtable is not None else None
+            check(lib.vptr_winattn_bwd_ws(ptr(q), ptr(k), ptr(v), ptr(table), ptr(rel_index), ptr(do), ptr(dq), ptr(dk), ptr(dv),
+                                          ptr(dtable), B, H, W, N, nh, ws, p, ptr(ctx.seed), site, alpha, int(use), ptr(wsp),
+                                          wsp.numel() if wsp is not None else 0, stream()), "vptr_winattn_bwd_ws")
             if slab is not None:
                 dtable = None
         else:
