@@ -351,12 +351,22 @@ int vptr_conv7_out_bwd_data(const float* dy, const float* y, const float* w, flo
 /* backward of the last layer w.r.t. weight/bias: dw [Cimg,Cin,7,7], db [Cimg] ACCUMULATED */
 int vptr_conv7_out_bwd_weight(const float* dy, const float* y, const float* x, float* dw, float* db, int B, int Cin, int H,
                               int W, int Cimg, int out_act, vptr_stream_t stream);
+/* The same with a caller-owned scratch buffer of vptr_conv7_out_bwd_weight_workspace(B, Cimg) floats (16-byte aligned): a second
+ * kernel (lane = input channel with its 49 taps in registers, the gradient window as broadcast LDS reads) leaves one partial
+ * per workgroup there and a reduction adds them in a fixed order -- no atomics on dw.  Without (enough) workspace: the call above. */
+int vptr_conv7_out_bwd_weight_ws(const float* dy, const float* y, const float* x, float* dw, float* db, int B, int Cin, int H, int W,
+                                 int Cimg, int out_act, float* workspace, int workspace_floats, vptr_stream_t stream);
+int vptr_conv7_out_bwd_weight_workspace(int B, int Cimg);   /* floats; a plain number, not an error code */
 /* dx = dy * (y > 0) * scale[c]   (ReLU + folded-BN backward on channel-last [rows, C]) */
 int vptr_bnrelu_bwd(const float* dy, const float* y, const float* scale, float* dx, int64_t rows, int C, vptr_stream_t stream);
 /* eval-mode BatchNorm2d affine gradients behind the ReLU, from the layer output y = relu(w*xhat + b) (ACCUMULATED):
  * db[c] += sum_{y>0} dy;  dw[c] += sum_{y>0} dy * (y - b[c]) / w[c]   (ResNetAutoEncoder.py:79-80 in stage 2) */
 int vptr_bnrelu_bwd_params(const float* dy, const float* y, const float* w, const float* b, float* dw, float* db, int64_t rows,
                            int C, vptr_stream_t stream);
+/* vptr_bnrelu_bwd and vptr_bnrelu_bwd_params in one pass over (dy, y): dx written, dw / db ACCUMULATED (C % 4 == 0).  The
+ * decoder backward of the stage-2 / stage-3 steps (every up-sampling layer's BatchNorm is trainable there although never stepped). */
+int vptr_bnrelu_bwd_fused(const float* dy, const float* y, const float* scale, const float* w, const float* b, float* dx,
+                          float* dw, float* db, int64_t rows, int C, vptr_stream_t stream);
 /* im2col on NHWC: out[(b,oy,ox)][(ky,kx,c)] = x[b, oy*stride-pad+ky, ox*stride-pad+kx, c] (pad_mode: VPTR_PAD_ZERO or
  * VPTR_PAD_REFLECT for out-of-range taps); the patch matrix is the k-strided operand of the convolution weight-gradient
  * GEMMs (autograd of ResNetAutoEncoder.py:33-48,74-88,138,151 and of the PatchGAN convs VPTR_modules.py:70-91). */

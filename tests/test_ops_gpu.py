@@ -520,10 +520,12 @@ def test_layout(ops, dev):
 
 
 # ------------------------------------------------------------------------------------------------------------ 7x7 convs
-@pytest.mark.parametrize("cimg", [1, 3])
-def test_conv7_ends(ops, dev, cimg):
+@pytest.mark.parametrize("cimg,geom", [(1, (2, 16, 24)), (3, (2, 16, 24)), (1, (3, 64, 64)), (3, (1, 64, 64)), (1, (2, 24, 64)), (1, (2, 8, 16))])
+def test_conv7_ends(ops, dev, cimg, geom):
+    """first / last 7x7 convolutions of the auto-encoder.  Single-channel images take the second-generation kernels (taps in
+    registers, broadcast LDS windows; backward-data only for W = 64), 3-channel images and odd widths the first-generation ones"""
     from vptr_amd._lib import check, lib, ptr, stream
-    B, H, W = 2, 16, 24
+    B, H, W = geom
     x, w = rn((B, cimg, H, W), 100), rn((64, cimg, 7, 7), 101, 0.1)
     sc, sh = rn((64,), 102).abs() + 0.5, rn((64,), 103)
     ref = torch.relu(F.conv2d(F.pad(x.double(), (3, 3, 3, 3), mode="reflect"), w.double()) * sc.double()[None, :, None, None]
@@ -556,6 +558,30 @@ def test_conv7_ends(ops, dev, cimg):
         check(lib.vptr_conv7_out_bwd_weight(ptr(gog), ptr(yo), ptr(xt), ptr(dw), ptr(db), B, 64, H, W, cimg, act, stream()),
               "c7obw")
         assert rel(dw, w2d.grad) < 5e-5 and rel(db, b2d.grad) < 5e-5
+        # the workspace variant (second kernel: taps in registers, partial sums reduced in a fixed order); accumulates like the first
+        wsp = torch.empty((lib.vptr_conv7_out_bwd_weight_workspace(B, cimg),), device=dev)
+        dw2, db2 = torch.ones((cimg, 64, 7, 7), device=dev), torch.ones((cimg,), device=dev)
+        check(lib.vptr_conv7_out_bwd_weight_ws(ptr(gog), ptr(yo), ptr(xt), ptr(dw2), ptr(db2), B, 64, H, W, cimg, act, ptr(wsp), wsp.numel(),
+                                               stream()), "c7obw_ws")
+        assert rel(dw2 - 1.0, w2d.grad) < 5e-5 and rel(db2 - 1.0, b2d.grad) < 5e-5
+
+
+def test_bnrelu_bwd_fused(dev):
+    """dx and the affine gradients of eval-BatchNorm + ReLU in one pass == the two separate kernels == autograd"""
+    from vptr_amd._lib import check, lib, ptr, stream
+    for rows, C in ((3000, 64), (1111, 128), (517, 256), (300, 24)):
+        xh = rn((rows, C), 120)
+        w, b, sc = rn((C,), 121).abs() + 0.5, rn((C,), 122, 0.3), rn((C,), 123).abs() + 0.2
+        dy = rn((rows, C), 124)
+        wd_, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+        y = torch.relu(xh.double() * wd_ + bd)
+        (y * dy.double()).sum().backward()
+        yd, dyd = y.detach().float().to(dev), dy.to(dev)
+        dx, dw, db = torch.empty((rows, C), device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        wg, bg, sg = w.to(dev), b.to(dev), sc.to(dev)
+        check(lib.vptr_bnrelu_bwd_fused(ptr(dyd), ptr(yd), ptr(sg), ptr(wg), ptr(bg), ptr(dx), ptr(dw), ptr(db), rows, C, stream()), "fused")
+        assert rel(dx, (y.detach() > 0).double() * dy.double() * sc.double()) < 1e-6
+        assert rel(dw, wd_.grad) < 2e-5 and rel(db, bd.grad) < 2e-5
 
 
 # ------------------------------------------------------------------------------------------------------------ optimizer

@@ -91,8 +91,11 @@ SIGNATURES = {
     "vptr_conv7_out_fwd": [P, P, P, P, I, I, I, I, I, I, P],
     "vptr_conv7_out_bwd_data": [P, P, P, P, I, I, I, I, I, I, P],
     "vptr_conv7_out_bwd_weight": [P, P, P, P, P, I, I, I, I, I, I, P],
+    "vptr_conv7_out_bwd_weight_ws": [P, P, P, P, P, I, I, I, I, I, I, P, I, P],
+    "vptr_conv7_out_bwd_weight_workspace": [I, I],
     "vptr_bnrelu_bwd": [P, P, P, P, L, I, P],
     "vptr_bnrelu_bwd_params": [P, P, P, P, P, P, L, I, P],
+    "vptr_bnrelu_bwd_fused": [P, P, P, P, P, P, P, P, L, I, P],
     "vptr_im2col_nhwc": [P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "vptr_reflect_fold": [P, P, I, I, I, I, I, P],
     "vptr_conv7_in_bwd_weight": [P, P, P, I, I, I, I, I, P],

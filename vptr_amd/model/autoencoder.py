@@ -269,20 +269,29 @@ class _DecoderFn(torch.autograd.Function):
         if want_w and conv.weight.requires_grad:
             dw7 = torch.zeros_like(conv.weight)
             db7 = torch.zeros_like(conv.bias)
-            check(lib.vptr_conv7_out_bwd_weight(ptr(dout), ptr(out), ptr(acts[-1]), ptr(dw7), ptr(db7), B, cin, h, w, cimg,
-                                                dec.out_act, stream()), "vptr_conv7_out_bwd_weight")
+            wsp = torch.empty((lib.vptr_conv7_out_bwd_weight_workspace(B, cimg),), device=dout.device, dtype=torch.float32)
+            check(lib.vptr_conv7_out_bwd_weight_ws(ptr(dout), ptr(out), ptr(acts[-1]), ptr(dw7), ptr(db7), B, cin, h, w, cimg,
+                                                   dec.out_act, ptr(wsp), wsp.numel(), stream()), "vptr_conv7_out_bwd_weight_ws")
             wgrads[id(conv.weight)], wgrads[id(conv.bias)] = dw7, db7
         for i in reversed(range(n_up)):
             ih, iw, ic, oh, ow, oc = geoms[i]
             gm = torch.empty_like(g)
-            check(lib.vptr_bnrelu_bwd(ptr(g), ptr(acts[i]), ptr(scales[i].contiguous()), ptr(gm), B * oh * ow, oc, stream()),
-                  "vptr_bnrelu_bwd")
             bn, convt = m[3 * i + 1], m[3 * i]
-            if want_w and bn.weight.requires_grad:
+            if want_w and bn.weight.requires_grad and oc % 4 == 0:
+                # masked gradient and the affine gradients in one pass over (g, activation)
                 dbw, dbb = torch.zeros_like(bn.weight), torch.zeros_like(bn.bias)
-                check(lib.vptr_bnrelu_bwd_params(ptr(g), ptr(acts[i]), ptr(bn.weight.contiguous()), ptr(bn.bias.contiguous()),
-                                                 ptr(dbw), ptr(dbb), B * oh * ow, oc, stream()), "vptr_bnrelu_bwd_params")
+                check(lib.vptr_bnrelu_bwd_fused(ptr(g), ptr(acts[i]), ptr(scales[i].contiguous()), ptr(bn.weight.contiguous()),
+                                                ptr(bn.bias.contiguous()), ptr(gm), ptr(dbw), ptr(dbb), B * oh * ow, oc, stream()),
+                      "vptr_bnrelu_bwd_fused")
                 wgrads[id(bn.weight)], wgrads[id(bn.bias)] = dbw, dbb
+            else:
+                check(lib.vptr_bnrelu_bwd(ptr(g), ptr(acts[i]), ptr(scales[i].contiguous()), ptr(gm), B * oh * ow, oc, stream()),
+                      "vptr_bnrelu_bwd")
+                if want_w and bn.weight.requires_grad:
+                    dbw, dbb = torch.zeros_like(bn.weight), torch.zeros_like(bn.bias)
+                    check(lib.vptr_bnrelu_bwd_params(ptr(g), ptr(acts[i]), ptr(bn.weight.contiguous()), ptr(bn.bias.contiguous()),
+                                                     ptr(dbw), ptr(dbb), B * oh * ow, oc, stream()), "vptr_bnrelu_bwd_params")
+                    wgrads[id(bn.weight)], wgrads[id(bn.bias)] = dbw, dbb
             if want_w and convt.weight.requires_grad:
                 # dW[ci][co][ky][kx] = sum_pix x[pix][ci] * gm[(iy*2-1+ky, ix*2-1+kx)][co]: im2col of gm (3x3, s2, p1) and one
                 # split-K GEMM  D[ci][(ky,kx,co)] = x^T . P  with both operands k-strided

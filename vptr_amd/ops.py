@@ -1895,8 +1895,9 @@ class _Conv7OutFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dW = torch.zeros_like(weight)
             db = torch.zeros((Cimg,), device=dy.device, dtype=torch.float32)
-            check(lib.vptr_conv7_out_bwd_weight(ptr(dy), ptr(y), ptr(x), ptr(dW), ptr(db), B, Cin, H, W, Cimg, out_act, stream()),
-                  "vptr_conv7_out_bwd_weight")
+            wsp = torch.empty((lib.vptr_conv7_out_bwd_weight_workspace(B, Cimg),), device=dy.device, dtype=torch.float32)
+            check(lib.vptr_conv7_out_bwd_weight_ws(ptr(dy), ptr(y), ptr(x), ptr(dW), ptr(db), B, Cin, H, W, Cimg, out_act, ptr(wsp),
+                                                   wsp.numel(), stream()), "vptr_conv7_out_bwd_weight_ws")
         return dx, dW, db, None, None, None, None
 
 
