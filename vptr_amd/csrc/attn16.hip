@@ -657,6 +657,99 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd2_kernel(const float* __rest
     else if (e2 < 49 && L.hlive && !dtable_ws) unsafeAtomicAdd(dtable + (int64_t)e2 * g.nh + h, stab[wv][e2]);
   }
 }
+// Forward with the same layout ideas (C % 4 == 0): 16-byte operand loads from the aligned head base, V left in a wave-private LDS
+// stash and read back transposed for O^T = V^T P^T (no 4-byte "down the column" loads), outputs as aligned quads, the next
+// problem's 18 loads in flight during the products.
+template <int NB32, int NB16, bool FULL>
+__global__ __launch_bounds__(256, 3) void attn16_fwd2_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                          const float* __restrict__ table, const int64_t* __restrict__ rel_index, float* __restrict__ o,
+                                                          const A16Geom g, const float p, const uint64_t* __restrict__ seed_dev, const uint32_t site,
+                                                          const int p16, const int rows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char a16_stash[];
+  constexpr int PITCH = NB16 * 32;
+  const int plane = rows * PITCH;
+  A16LaneB<NB32, NB16, FULL> L;
+  L.init(g, blockIdx.y, PITCH);
+  const int lr = L.lr, lq = L.lq, h = L.h, wv = threadIdx.x >> 6;
+  unsigned char* const sV = a16_stash + wv * (2 * plane);
+  const bool wr_row = lr < rows;
+  const bool rd_grp = 4 * lq < rows;
+  const int troff = rd_grp ? L.troff : (lr >> 2) * PITCH + 8 * (lr & 3);   // every lane executes the transposed reads (see the backward)
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  float bias[4] = {0.f, 0.f, 0.f, 0.f};   // S^T element (key j = 4 lq + r, query i = lr)
+  if (table) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = table[rel_index[lr * 16 + 4 * lq + r] * g.nh + h];
+  }
+  const int64_t orow = a16_loff(g, L.qok ? lr : 0);
+  A16Raw<NB32> rk, rq, rv;
+  int prob = blockIdx.x;
+  if (prob < g.nprob) {
+    const int64_t qb0 = a16_base(g, prob, false), kb0 = a16_base(g, prob, true);
+    a16b_load(k + kb0, L.koff, L, rk);
+    a16b_load(q + qb0, L.qoff, L, rq);
+    a16b_load(v + kb0, L.koff, L, rv);
+  }
+  for (; prob < g.nprob; prob += gridDim.x) {
+    const int64_t qb0 = a16_base(g, prob, false);
+    f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < NB32; ++b) {
+      bf16x8 kh, kl, qh, ql, vh, vl;
+      a16b_split(rk.v[b], L.kok, (L.kvm >> (4 * b)) & 15u, kh, kl);
+      a16b_split(rq.v[b], L.qok, 15u, qh, ql);
+      st = a16_mma32(kh, kl, qh, ql, st);     // S^T[j][i]
+      a16b_split(rv.v[b], L.kok, 15u, vh, vl);
+      if (wr_row && 32 * b + 8 * lq < 16 * NB16) a16b_stash(sV, plane, L.wroff, b, vh, vl);
+    }
+    {
+      const int nx = prob + gridDim.x;
+      if (nx < g.nprob) {
+        const int64_t qn = a16_base(g, nx, false), kn = a16_base(g, nx, true);
+        a16b_load(k + kn, L.koff, L, rk);
+        a16b_load(q + qn, L.qoff, L, rq);
+        a16b_load(v + kn, L.koff, L, rv);
+      }
+    }
+    float e[4], m = -INFINITY;
+    bool ok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 4 * lq + r;
+      ok[r] = FULL || (j < g.Lk && (!g.causal || j <= lr));
+      e[r] = ok[r] ? st[r] + bias[r] : -INFINITY;
+      m = fmaxf(m, e[r]);
+    }
+    m = a16_gmax(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { e[r] = ok[r] ? __expf(e[r] - m) : 0.f; sum += e[r]; }
+    sum = a16_gsum(sum);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      e[r] *= inv;
+      if (p > 0.f) e[r] *= vptr_drop_scale(seed, site, a16_pidx(g, prob, h, lr, 4 * lq + r), p);
+    }
+    s16x4 ph, pl;
+    a16_split4(e[0], e[1], e[2], e[3], ph, pl);
+    asm volatile("" ::: "memory");
+    const bool st_ok = L.qok && L.hlive;
+#pragma unroll
+    for (int b = 0; b < NB16; ++b) {
+      const s16x4 z4 = {0, 0, 0, 0};
+      s16x4 ah, al;
+      a16b_tr(sV, plane, troff, b, ah, al);
+      if (!rd_grp) ah = al = z4;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = a16_mma16(ah, al, ph, pl, acc);
+      if (st_ok) a16b_st4(o, qb0 + orow, b, acc, 1.f, L, p16);
+    }
+    asm volatile("" ::: "memory");
+  }
+}
+
 // dtable[e][h] += sum over workgroups of the workspace partials, in a fixed order: 16 thread groups take every 16th workgroup
 // (8 independent loads in flight per thread), then one thread per entry adds the 16 sums
 __global__ __launch_bounds__(1024) void attn16_dtable_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dtable, const int nwg, const int nhp, const int nh) {
@@ -686,14 +779,15 @@ __global__ __launch_bounds__(1024) void attn16_dtable_reduce_kernel(const float*
 // ---------------------------------------------------------------------------------------------------------------------------
 // host side (called by the entry points of attn.hip)
 // ---------------------------------------------------------------------------------------------------------------------------
-static int a16_mode() {   // read per call (tests switch modes inside one process).  VPTR_ATTN16: 0 = off; 1 (default) = forward kernel +
-  const char* m = getenv("VPTR_ATTN_MFMA");   // second-generation backward (C % 4 == 0, else the fp32 vector backward); 2 = forward + the
-  if (m && atoi(m) != 1) return 0;             // first-generation backward; 4 = forward only.  An explicit VPTR_ATTN_MFMA=0 / 2 (fp32 vector
-  const char* e = getenv("VPTR_ATTN16");       // kernels / LDS-staged MFMA kernels everywhere) turns these kernels off
-  return e ? atoi(e) : 1;
-}
+static int a16_mode() {   // read per call (tests switch modes inside one process).  VPTR_ATTN16: 0 = off; 1 (default) = second-generation
+  const char* m = getenv("VPTR_ATTN_MFMA");   // forward and backward (C % 4 == 0 and 16-byte aligned tensors, else the first-generation
+  if (m && atoi(m) != 1) return 0;             // forward + the fp32 vector backward); 2 = first-generation forward and backward; 4 = first-
+  const char* e = getenv("VPTR_ATTN16");       // generation forward, vector backward.  VPTR_ATTN16_FWD1=1: mode 1 with the first-generation
+  return e ? atoi(e) : 1;                      // forward.  An explicit VPTR_ATTN_MFMA=0 / 2 (vector / LDS-staged MFMA kernels everywhere)
+}                                              // turns these kernels off
 // Measured at the K64 shapes (tools/attn_bench.py, P16 outputs, dropout 0.1; copying the bytes of a forward call: 19 us):
-//   forward                       24-25 us   (fp32 vector kernels 35-37)
+//   forward,  first generation    24-25 us   (fp32 vector kernels 35-37)
+//   forward,  second generation   20 / 23 us (window / temporal)
 //   backward, first generation    80 / 73 us (window with bias-table gradient / temporal; vector kernels 95 / 66): bound by its 168
 //                                 narrow memory instructions per (problem, head), see above
 //   backward, second generation   49 / 47 us (window without a table gradient 42; with the table gradient through atomics instead of
@@ -717,9 +811,35 @@ static dim3 a16_grid(const A16Geom& g, const bool table_grad) {
 static bool a16_full(const A16Geom& g) { return g.Lq == 16 && g.Lk == 16 && !g.causal; }
 int vptr_attn16_fwd(const float* q, const float* k, const float* v, const float* table, const int64_t* rel_index, float* o, const A16Geom& g, float p,
                     const uint64_t* seed_dev, uint32_t site, int p16, hipStream_t st) {
+  const bool full = a16_full(g);
+  const uintptr_t fbits = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(o);
+  if (a16_mode() == 1 && g.C % 4 == 0 && (fbits & 15) == 0 && !getenv("VPTR_ATTN16_FWD1")) {   // second generation
+    const int span = g.hd + ((g.hd & 3) ? 2 : 0);
+    const int nb32 = (span + 31) / 32, nb16 = (span + 15) / 16;
+    const int rows = ((g.Lq > g.Lk ? g.Lq : g.Lk) + 3) & ~3;
+    const int groups = (g.nh + 3) / 4;
+    const size_t lds = (size_t)4 * 2 * rows * nb16 * 32;
+    int gx = 256 * 3 / groups;
+    if (gx < 1) gx = 1;
+    if (g.nprob < gx) gx = g.nprob;
+    const dim3 grid(gx, groups), block(256);
+#define A16F2(A, B)                                                                                                                  \
+  do {                                                                                                                               \
+    if (full) attn16_fwd2_kernel<A, B, true><<<grid, block, lds, st>>>(q, k, v, table, rel_index, o, g, p, seed_dev, site, p16, rows);   \
+    else attn16_fwd2_kernel<A, B, false><<<grid, block, lds, st>>>(q, k, v, table, rel_index, o, g, p, seed_dev, site, p16, rows);       \
+  } while (0)
+    if (nb32 == 1 && nb16 == 1) A16F2(1, 1);
+    else if (nb32 == 1) A16F2(1, 2);
+    else if (nb32 == 2 && nb16 == 3) A16F2(2, 3);
+    else if (nb32 == 2) A16F2(2, 4);
+    else if (nb16 == 5) A16F2(3, 5);
+    else if (nb32 == 3) A16F2(3, 6);
+    else A16F2(4, 7);
+#undef A16F2
+    return 0;
+  }
   const int nb32 = (g.hd + 31) / 32, nb16 = (g.hd + 15) / 16;
   const dim3 grid = a16_grid(g, false), block(256);
-  const bool full = a16_full(g);
 #define A16F(A, B)                                                                                                        \
   do {                                                                                                                    \
     if (full) attn16_fwd_kernel<A, B, true><<<grid, block, 0, st>>>(q, k, v, table, rel_index, o, g, p, seed_dev, site, p16);   \
