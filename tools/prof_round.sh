@@ -50,7 +50,7 @@ try:
     with open(OUT + "/%s_rccl_world1_kernel_stats.md" % R, "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --force-exchange --steps 5 --warmup 2 ...  (ONE-rank RCCL group, the step through the\n")
         f.write("# multi-rank code path: 4 chunked weight-gradient launches, async all-reduces of the 473.5 MB slab in <= 64 MB pieces; 7 steps traced)\n")
-        f.write("# RCCL / c10d kernels in the trace: %s\n\n" % ([short(r["Name"])[:60] for r in rr if "ccl" in r["Name"].lower() or "nccl" in r["Name"].lower()] or "none (in-place all-reduce on one rank launches no kernel)"))
+        f.write("# RCCL / c10d kernels in the trace: %s\n\n" % ([short(r["Name"])[:60] for r in rr if ("nccl" in r["Name"].lower() or "rccl" in r["Name"].lower()) and "rocclr" not in r["Name"].lower()] or "none (in-place all-reduce on one rank launches no kernel)"))
         f.write("| kernel | calls | total ms | avg us |\n|---|---|---|---|\n")
         for r in rr[:25]:
             f.write("| %s | %s | %.3f | %.1f |\n" % (short(r["Name"])[:70], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3))
