@@ -205,6 +205,21 @@ int vptr_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 int vptr_layernorm_bwd(const float* dy, const float* dy2, const float* x, const float* gamma, const float* mean,
                        const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int C, const float* dx_add,
                        vptr_stream_t stream);
+/* The same with the parameter gradients DEFERRED: dx is written, the workgroups' gamma / beta sums go to
+ * partials[vptr_layernorm_bwd_partials(rows, C)][2][C] (caller-owned, 16-byte aligned) instead of 2 C atomics per workgroup;
+ * one vptr_partial_reduce launch at the end of the backward pass adds the partial rows of EVERY deferred call into their
+ * destinations.  vptr_layernorm_bwd_partials returns 0 for geometries without a deferred variant (use vptr_layernorm_bwd). */
+int vptr_layernorm_bwd_deferred(const float* dy, const float* dy2, const float* x, const float* gamma, const float* mean,
+                                const float* rstd, float* dx, int rows, int C, const float* dx_add, float* partials,
+                                vptr_stream_t stream);
+int vptr_layernorm_bwd_partials(int rows, int C);   /* a plain number, not an error code */
+typedef struct vptr_reduce_entry {
+  const float* part;   /* [nparts][2][C] */
+  float* dst0;         /* [C] += sum over p of part[p][0][:] */
+  float* dst1;         /* [C] += sum over p of part[p][1][:] */
+  int nparts, C;
+} vptr_reduce_entry;
+int vptr_partial_reduce(const vptr_reduce_entry* table_dev, int count, int max_C, vptr_stream_t stream);
 
 /* out[(row / div) % mod, :] += src[row, :]   (gradient of a row-broadcast table; out must be zeroed by the caller) */
 int vptr_rowmod_sum(const float* src, float* out, int rows, int C, int div, int mod, vptr_stream_t stream);

@@ -383,6 +383,45 @@ def test_temporal_attention(ops, dev, attn_mode, Tq, Tk, causal, N, HW, C):
         assert rel(a.grad, c.grad) < 1e-4
 
 
+@pytest.mark.parametrize("nh,C", [(6, 48), (2, 132), (5, 80)])
+def test_attention_partial_head_groups(ops, dev, nh, C):
+    """head counts that are not a multiple of the 4 heads of an attn16 workgroup (idle waves must not store), head widths that put
+    every other head on an unaligned quad (hd = 66, 16) or none (hd = 8), through the default kernels, both attention kinds"""
+    B, H, W, ws = 2, 8, 8, 4
+    L = ws * ws
+    q, k, v = rn((B * H * W, C), 70, 0.5), rn((B * H * W, C), 71, 0.5), rn((B * H * W, C), 72)
+    table, idx, go = rn(((2 * ws - 1) ** 2, nh), 73, 0.5), O.rpe_index(ws), rn((B * H * W, C), 74)
+    ins = [t.double().clone().requires_grad_(True) for t in (q, k, v, table)]
+
+    def part(t):
+        return O.win_partition(t.reshape(B, H, W, C), ws)
+    bias = ins[3][idx.reshape(-1)].reshape(L, L, nh).permute(2, 0, 1)
+    o = O._attend(O._heads(part(ins[0]), nh), O._heads(part(ins[1]), nh), O._heads(part(ins[2]), nh), bias)
+    o = O.win_reverse(o, B, H, W, ws).reshape(B * H * W, C)
+    (o * go.double()).sum().backward()
+    ds = [t.to(dev).requires_grad_(True) for t in (q, k, v, table)]
+    od = ops.window_attention(ds[0], ds[1], ds[2], ds[3], idx.to(dev), B, H, W, nh, ws)
+    (od * go.to(dev)).sum().backward()
+    assert rel(od, o) < TOLA
+    for a, c in zip(ds, ins):
+        assert rel(a.grad, c.grad) < 1e-4
+    N, T, HW = 2, 7, 9
+    q, k, v, go = rn((N * T * HW, C), 75, 0.5), rn((N * T * HW, C), 76, 0.5), rn((N * T * HW, C), 77), rn((N * T * HW, C), 78)
+    ins = [t.double().clone().requires_grad_(True) for t in (q, k, v)]
+
+    def seq(t):
+        return t.reshape(N, T, HW, C).permute(0, 2, 1, 3).reshape(N * HW, T, C)
+    o = O._attend(O._heads(seq(ins[0]), nh), O._heads(seq(ins[1]), nh), O._heads(seq(ins[2]), nh), None, True)
+    o = o.reshape(N, HW, T, C).permute(0, 2, 1, 3).reshape(N * T * HW, C)
+    (o * go.double()).sum().backward()
+    ds = [t.to(dev).requires_grad_(True) for t in (q, k, v)]
+    od = ops.temporal_attention(ds[0], ds[1], ds[2], N, T, T, HW, nh, True)
+    (od * go.to(dev)).sum().backward()
+    assert rel(od, o) < TOLA
+    for a, c in zip(ds, ins):
+        assert rel(a.grad, c.grad) < 1e-4
+
+
 def _proj_ref(ops, xq, xk, xv, Ws, bs, nh, attend):
     """composition of the separate nodes: three linears (alpha on q) + the attention core"""
     C = Ws[0].shape[0]

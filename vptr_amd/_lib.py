@@ -46,6 +46,11 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class ReduceEntry(ctypes.Structure):
+    """Mirror of `vptr_reduce_entry` (include/vptr_hip.h)."""
+    _fields_ = [("part", c_void_p), ("dst0", c_void_p), ("dst1", c_void_p), ("nparts", c_int), ("C", c_int)]
+
+
 class WPlaneEntry(ctypes.Structure):
     """Mirror of `vptr_wplane_entry` (include/vptr_hip.h)."""
     _fields_ = [("W", c_void_p), ("Wp", c_void_p), ("WT", c_void_p), ("ldw", c_int64), ("N", c_int), ("K", c_int)]
@@ -62,6 +67,9 @@ SIGNATURES = {
     "vptr_gemm_grouped": [ctypes.POINTER(GemmDesc), P, P, I, I, P],
     "vptr_layernorm_fwd": [P, P, P, P, P, P, I, I, P, P, I, I, F, I, P],
     "vptr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, I, P, P],
+    "vptr_layernorm_bwd_deferred": [P, P, P, P, P, P, P, I, I, P, P, P],
+    "vptr_layernorm_bwd_partials": [I, I],
+    "vptr_partial_reduce": [P, I, I, P],
     "vptr_rowmod_sum": [P, P, I, I, I, I, P],
     "vptr_colsum": [P, P, I, I, P],
     "vptr_window_copy": [P, P, I, I, I, I, I, I, I, I, P],

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_fused_kernel(const float* __re
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            float* __restrict__ dx_, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int rows, int C, int rpb,
-                                                           const float* __restrict__ dx_add_) {
+                                                           const float* __restrict__ dx_add_, float* __restrict__ part) {
   __shared__ float4 red[NW][2][NC4 * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int C4 = C >> 2;
@@ -253,26 +253,42 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_fused_kernel(const float* __re
       sg += rf[w * WS + i];
       sb += rf[w * WS + PS + i];
     }
-    unsafeAtomicAdd(dgamma + i, sg);
-    unsafeAtomicAdd(dbeta + i, sb);
+    if (part) {   // deferred: this workgroup's sums as one row of [gridDim.x][2][C]; vptr_partial_reduce adds the rows later
+      part[((int64_t)blockIdx.x * 2) * C + i] = sg;
+      part[((int64_t)blockIdx.x * 2 + 1) * C + i] = sb;
+    } else {
+      unsafeAtomicAdd(dgamma + i, sg);
+      unsafeAtomicAdd(dbeta + i, sb);
+    }
   }
 }
 
-extern "C" int vptr_layernorm_bwd(const float* dy, const float* dy2, const float* x, const float* gamma, const float* mean,
-                                  const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int C,
-                                  const float* dx_add, vptr_stream_t stream) {
+// rows of partial sums a deferred backward call writes (0: this geometry has no deferred variant)
+extern "C" int vptr_layernorm_bwd_partials(int rows, int C) {
+  if (rows < 4096 || C % 4 != 0 || C <= 256 || C > 768) return 0;
+  return cdiv(rows, 32);
+}
+static int layernorm_bwd_impl(const float* dy, const float* dy2, const float* x, const float* gamma, const float* mean,
+                              const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int C,
+                              const float* dx_add, float* partials, hipStream_t st) {
   VPTR_CHECK(rows > 0 && C > 0, "layernorm_bwd: empty input");
-  hipStream_t st = (hipStream_t)stream;
+  if (partials) {
+    // deferred parameter gradients: no atomics, so more and shorter workgroups (32 rows each instead of 64) cost nothing
+    VPTR_CHECK(dx && vptr_layernorm_bwd_partials(rows, C) > 0, "layernorm_bwd: no deferred variant for rows %d, C %d", rows, C);
+    ln_bwd_fused_kernel<3, 8><<<cdiv(rows, 32), 512, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, nullptr, nullptr, rows, C, 32, dx_add, partials);
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
   if (dx && dgamma && dbeta && C % 4 == 0 && C <= 1024) {
     // fewer, longer workgroups: the per-column atomics at the end contend across workgroups.  Big inputs: 8 waves x 8 rows each = 64 rows
     // per workgroup (half the atomics of 4 waves x 8 rows at the same number of waves in flight: -0.25 ms per step; 16 waves or fewer rows lose)
     const bool big = rows >= 4096;
     const int rpb = big ? 64 : 4;
     const int nb = cdiv(rows, rpb);
-    if (C <= 256) ln_bwd_fused_kernel<1, 4><<<cdiv(rows, big ? 32 : 4), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, big ? 32 : 4, dx_add);
-    else if (C <= 768 && big) ln_bwd_fused_kernel<3, 8><<<nb, 512, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb, dx_add);
-    else if (C <= 768) ln_bwd_fused_kernel<3, 4><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb, dx_add);
-    else ln_bwd_fused_kernel<4, 4><<<cdiv(rows, big ? 32 : 4), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, big ? 32 : 4, dx_add);
+    if (C <= 256) ln_bwd_fused_kernel<1, 4><<<cdiv(rows, big ? 32 : 4), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, big ? 32 : 4, dx_add, nullptr);
+    else if (C <= 768 && big) ln_bwd_fused_kernel<3, 8><<<nb, 512, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb, dx_add, nullptr);
+    else if (C <= 768) ln_bwd_fused_kernel<3, 4><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb, dx_add, nullptr);
+    else ln_bwd_fused_kernel<4, 4><<<cdiv(rows, big ? 32 : 4), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, big ? 32 : 4, dx_add, nullptr);
     VPTR_LAUNCH_CHECK();
     return 0;
   }
@@ -282,6 +298,57 @@ extern "C" int vptr_layernorm_bwd(const float* dy, const float* dy2, const float
     dim3 grid(cdiv(C, 256), cdiv(rows, rpb));
     ln_bwd_param_kernel<<<grid, 256, 0, st>>>(dy, dy2, x, mean, rstd, dgamma, dbeta, rows, C, rpb);
   }
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vptr_layernorm_bwd(const float* dy, const float* dy2, const float* x, const float* gamma, const float* mean,
+                                  const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int C,
+                                  const float* dx_add, vptr_stream_t stream) {
+  return layernorm_bwd_impl(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, dx_add, nullptr, (hipStream_t)stream);
+}
+extern "C" int vptr_layernorm_bwd_deferred(const float* dy, const float* dy2, const float* x, const float* gamma, const float* mean,
+                                           const float* rstd, float* dx, int rows, int C, const float* dx_add, float* partials,
+                                           vptr_stream_t stream) {
+  VPTR_CHECK(partials && (reinterpret_cast<uintptr_t>(partials) & 15) == 0, "layernorm_bwd_deferred: needs a 16-byte aligned partial-sum buffer");
+  return layernorm_bwd_impl(dy, dy2, x, gamma, mean, rstd, dx, nullptr, nullptr, rows, C, dx_add, partials, (hipStream_t)stream);
+}
+// Deferred parameter-gradient sums of a whole backward pass in ONE launch: entry e adds the nparts rows of part[nparts][2][C] into
+// dst0[C] (row 0 of each pair) and dst1[C] (row 1).  The final add is an atomic: two entries may name the same destination (a module
+// applied twice in one forward).  Workgroup = 64 columns x 4 row lanes.
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const vptr_reduce_entry* __restrict__ tab) {
+  __shared__ float red[2][4][64];
+  const vptr_reduce_entry e = tab[blockIdx.y];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < e.C) {
+    int p = q;
+    for (; p + 12 < e.nparts; p += 16) {
+      float t0[4], t1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        t0[u] = e.part[((int64_t)(p + 4 * u) * 2) * e.C + c];
+        t1[u] = e.part[((int64_t)(p + 4 * u) * 2 + 1) * e.C + c];
+      }
+      a0 += (t0[0] + t0[1]) + (t0[2] + t0[3]);
+      a1 += (t1[0] + t1[1]) + (t1[2] + t1[3]);
+    }
+    for (; p < e.nparts; p += 4) {
+      a0 += e.part[((int64_t)p * 2) * e.C + c];
+      a1 += e.part[((int64_t)p * 2 + 1) * e.C + c];
+    }
+  }
+  red[0][q][threadIdx.x & 63] = a0;
+  red[1][q][threadIdx.x & 63] = a1;
+  __syncthreads();
+  if (q == 0 && c < e.C) {
+    const int l = threadIdx.x & 63;
+    unsafeAtomicAdd(e.dst0 + c, (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]));
+    unsafeAtomicAdd(e.dst1 + c, (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]));
+  }
+}
+extern "C" int vptr_partial_reduce(const vptr_reduce_entry* table_dev, int count, int max_C, vptr_stream_t stream) {
+  VPTR_CHECK(table_dev && count > 0 && max_C > 0, "partial_reduce: bad arguments");
+  partial_reduce_kernel<<<dim3(cdiv(max_C, 64), count), 256, 0, (hipStream_t)stream>>>(table_dev);
   VPTR_LAUNCH_CHECK();
   return 0;
 }

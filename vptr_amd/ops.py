@@ -30,6 +30,9 @@ class _Config:
     group_wgrads = True
     # plain parameters (no FlatAdamW slab) join the grouped launch through their own .grad (ops._loose_grad_for); 0 = A/B switch
     group_loose_wgrads = os.environ.get("VPTR_LOOSE_WGRADS", "1") != "0"
+    # LayerNorm(C) gamma / beta gradients with an in-place destination: per-workgroup partial sums now, ONE reduction launch at the end
+    # of the backward pass (ops.defer_partial_reduce) instead of 2 C atomics per workgroup and call; 0 = A/B switch
+    defer_ln_param_grads = os.environ.get("VPTR_DEFER_LN", "1") != "0"
     # grouped token-major weight gradients: transposed-store orientation for dW whose row count leaves eighth-full tiles; 0 = A/B switch
     wgrad_flip = os.environ.get("VPTR_WGRAD_FLIP", "1") != "0"
     # partly filled last row tiles as separate problems launched after all full tiles (equal-duration tiles stay in step); 0 = A/B switch
@@ -426,6 +429,35 @@ def defer_wgrad(g, x, dW, N, K, M, db=None, alpha=1.0, p16=False):
 def discard_wgrads():
     """drop recorded weight gradients that were never launched (a backward pass that raised); called by FlatAdamW.zero_grad"""
     del _wgrad_q[:]
+    del _reduce_q[:]
+
+
+# ---- deferred partial-sum reductions (parameter gradients of the LayerNorms) -----------------------------------------------
+_reduce_q = []
+
+
+def defer_partial_reduce(part, dst0, dst1, nparts, C):
+    """record dst0[C] += sum_p part[p][0][:], dst1[C] += sum_p part[p][1][:]; every record of a backward pass is served by one
+    vptr_partial_reduce launch at its end (before the grouped weight gradients: a data-parallel step sends gradient ranges out as
+    soon as their weight-gradient chunk is done)."""
+    _reduce_q.append((part, dst0, dst1, int(nparts), int(C)))
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_auto_flush_wgrads)
+    except RuntimeError:  # not inside a backward pass: the caller flushes explicitly (flush_wgrads)
+        pass
+
+
+def flush_partial_reduces():
+    if not _reduce_q:
+        return
+    items = list(_reduce_q)
+    del _reduce_q[:]
+    tab = (_lib.ReduceEntry * len(items))()
+    for i, (part, d0, d1, nparts, C) in enumerate(items):
+        tab[i].part, tab[i].dst0, tab[i].dst1, tab[i].nparts, tab[i].C = ptr(part), ptr(d0), ptr(d1), nparts, C
+    dev = items[0][0].device
+    raw = _to_device_async(bytes(tab), dev)
+    check(lib.vptr_partial_reduce(ptr(raw), len(items), max(it[4] for it in items), stream()), "vptr_partial_reduce")
 
 
 _wgrad_hold = [False]  # set by hold_wgrads(): the end-of-backward callback leaves the queue to an explicit chunked flush
@@ -482,6 +514,7 @@ def join_wgrad_stream():
 
 def _auto_flush_wgrads():
     if not _wgrad_hold[0]:
+        flush_partial_reduces()
         if config.wgrad_async and _wgrad_q:
             _flush_wgrads_side()
         else:
@@ -613,6 +646,7 @@ def flush_wgrads(chunks=1, on_chunk=None):
     equal work; after each launch `on_chunk(first_dW_ptr)` is called with the lowest destination address of the NEXT chunk
     (None after the last): everything below it is final, so its gradient range can go out to the other ranks while the next
     chunk computes."""
+    flush_partial_reduces()
     if not _wgrad_q:
         if on_chunk is not None:
             on_chunk(None)
@@ -1032,12 +1066,21 @@ class _LayerNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         sg, sb = flat_grad_for(gamma), flat_grad_for(ctx.beta_ref)
         in_slab = sg is not None and sb is not None
-        dgamma = sg if in_slab else torch.zeros_like(gamma)
-        dbeta = sb if in_slab else torch.zeros_like(gamma)
-        check(lib.vptr_layernorm_bwd(ptr(k1), ptr(k2), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma),
-                                     ptr(dbeta), rows, C, ptr(dres), stream()), "vptr_layernorm_bwd")
-        if in_slab:
+        nparts = lib.vptr_layernorm_bwd_partials(rows, C) if (in_slab and config.defer_ln_param_grads) else 0
+        if nparts > 0:
+            # in-place destination: per-workgroup partial sums now, one reduction launch for all LayerNorms at the end of backward
+            part = torch.empty((nparts, 2, C), device=x.device, dtype=torch.float32)
+            check(lib.vptr_layernorm_bwd_deferred(ptr(k1), ptr(k2), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), rows, C,
+                                                  ptr(dres), ptr(part), stream()), "vptr_layernorm_bwd_deferred")
+            defer_partial_reduce(part, sg, sb, nparts, C)
             dgamma = dbeta = None
+        else:
+            dgamma = sg if in_slab else torch.zeros_like(gamma)
+            dbeta = sb if in_slab else torch.zeros_like(gamma)
+            check(lib.vptr_layernorm_bwd(ptr(k1), ptr(k2), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma),
+                                         ptr(dbeta), rows, C, ptr(dres), stream()), "vptr_layernorm_bwd")
+            if in_slab:
+                dgamma = dbeta = None
         dtab = None
         if has_tab and ctx.needs_input_grad[3] and dy2 is not None:
             dst = grad_dest_for(ctx.tab_ref) if ctx.tab_ref is not None else None
