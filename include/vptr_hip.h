@@ -315,6 +315,14 @@ int vptr_norm_act_bwd(const float* dy, const float* x, const float* mean, const 
                       float* dx, float* dw, float* db, float* scratch, int rows, int F, int HW, int per_col, int act,
                       int const_stats, float dropout_p, const uint64_t* seed_dev, uint32_t site, const float* rowscale,
                       int rs_div, int rs_mod, int p16 /* != 0: dx is written in the P16 plane format */, vptr_stream_t stream);
+/* The LayerNorm((F,H,W)) mode (per_col = 0) with the affine gradients DEFERRED like vptr_layernorm_bwd_deferred: dx written, the
+ * frame chunks' sums to partials[vptr_norm_act_bwd_partials(rows, F, HW, 0)][2][HW * F] (rows of dw / db), added into their
+ * destinations by the backward pass's vptr_partial_reduce launch.  Without atomics the frames are cut into more chunks. */
+int vptr_norm_act_bwd_deferred(const float* dy, const float* x, const float* mean, const float* rstd, const float* w, const float* b,
+                               float* dx, float* scratch, int rows, int F, int HW, int act, int const_stats, float dropout_p,
+                               const uint64_t* seed_dev, uint32_t site, const float* rowscale, int rs_div, int rs_mod, int p16,
+                               float* partials, vptr_stream_t stream);
+int vptr_norm_act_bwd_partials(int rows, int F, int HW, int per_col);   /* a plain number (0: use vptr_norm_act_bwd) */
 /* depthwise 3x3, pad 1 (VidHRFormer_modules.py:404-409,433); w given tap-major [9, F]. */
 /* frame_stats (may be NULL): [frames][2] zeroed buffer that receives each frame's sum / sum of squares of y (see
  * vptr_norm_act_fwd raw_stats); needs W even and (W/2)*(F/4) % 64 == 0 */

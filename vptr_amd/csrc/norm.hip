@@ -710,7 +710,8 @@ __global__ __launch_bounds__(256) void norm_act_bwd_frame_affine(const float* __
                                                                  float* __restrict__ fsum /* [gridDim.x, frames, 2] partials */, int E4, int F,
                                                                  int HW, int act, float p, const uint64_t* seed_dev,
                                                                  uint32_t site, int frames, int fpb,
-                                                                 const float* __restrict__ rowscale, int rs_div, int rs_mod) {
+                                                                 const float* __restrict__ rowscale, int rs_div, int rs_mod,
+                                                                 float* __restrict__ part /* [gridDim.y][2][4 * E4] or null */) {
   __shared__ float sred[3][64][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e_raw = blockIdx.x * 64 + lane;
@@ -762,6 +763,21 @@ __global__ __launch_bounds__(256) void norm_act_bwd_frame_affine(const float* __
   }
   __syncthreads();
   if (wave > 0 || !live) return;
+  if (part) {   // deferred: this frame chunk's sums as one row pair of [gridDim.y][2][E]; vptr_partial_reduce adds them later
+    float4 ow, ob;
+    ow.x = aw[0] + sred[0][lane][0] + sred[1][lane][0] + sred[2][lane][0];
+    ow.y = aw[1] + sred[0][lane][1] + sred[1][lane][1] + sred[2][lane][1];
+    ow.z = aw[2] + sred[0][lane][2] + sred[1][lane][2] + sred[2][lane][2];
+    ow.w = aw[3] + sred[0][lane][3] + sred[1][lane][3] + sred[2][lane][3];
+    ob.x = ab[0] + sred[0][lane][4] + sred[1][lane][4] + sred[2][lane][4];
+    ob.y = ab[1] + sred[0][lane][5] + sred[1][lane][5] + sred[2][lane][5];
+    ob.z = ab[2] + sred[0][lane][6] + sred[1][lane][6] + sred[2][lane][6];
+    ob.w = ab[3] + sred[0][lane][7] + sred[1][lane][7] + sred[2][lane][7];
+    float4* pw = reinterpret_cast<float4*>(part + ((int64_t)blockIdx.y * 2) * 4 * E4) + e;
+    pw[0] = ow;
+    pw[E4] = ob;
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     unsafeAtomicAdd(dw + (int64_t)e * 4 + q, aw[q] + sred[0][lane][q] + sred[1][lane][q] + sred[2][lane][q]);
@@ -879,11 +895,26 @@ __global__ void zero_fill_kernel(float* __restrict__ p, int n) {
   if (i < n) p[i] = 0.f;
 }
 
-extern "C" int vptr_norm_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
-                                 const float* b, float* dx, float* dw, float* db, float* scratch, int rows, int F, int HW,
-                                 int per_col, int act, int const_stats, float dropout_p, const uint64_t* seed_dev,
-                                 uint32_t site, const float* rowscale, int rs_div, int rs_mod, int p16, vptr_stream_t stream) {
-  VPTR_CHECK(rows > 0 && F > 0 && HW >= 1 && scratch && dx && dw && db, "norm_act_bwd: bad arguments");
+// frame chunks (= rows of partial sums [chunks][2][HW * F]) of a deferred LayerNorm((F,H,W)) backward call; 0: no deferred variant
+extern "C" int vptr_norm_act_bwd_partials(int rows, int F, int HW, int per_col) {
+  if (per_col || HW < 1 || rows % HW != 0 || F % 4 != 0) return 0;
+  const int frames = rows / HW;
+  if (frames < 64) return 0;
+  static int big_split = -1, small_split = -1;
+  if (big_split < 0) {
+    const char* e = getenv("VPTR_NORM_SPLIT");   // "big,small" frame chunks (experiments)
+    big_split = 4; small_split = 16;
+    if (e) (void)sscanf(e, "%d,%d", &big_split, &small_split);
+  }
+  const int want = (int64_t)HW * F >= 65536 ? big_split : small_split;
+  const int fpb = (frames + want - 1) / want;
+  return (frames + fpb - 1) / fpb;   // chunks of fpb frames (<= want)
+}
+static int norm_act_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
+                             const float* b, float* dx, float* dw, float* db, float* scratch, int rows, int F, int HW,
+                             int per_col, int act, int const_stats, float dropout_p, const uint64_t* seed_dev,
+                             uint32_t site, const float* rowscale, int rs_div, int rs_mod, int p16, float* partials, vptr_stream_t stream) {
+  VPTR_CHECK(rows > 0 && F > 0 && HW >= 1 && scratch && dx && (partials || (dw && db)), "norm_act_bwd: bad arguments");
   if (p16) VPTR_CHECK(F % 16 == 0 && (reinterpret_cast<uintptr_t>(dx) & 63) == 0, "norm_act_bwd: a P16 dx needs F %% 16 == 0 and a 64-byte aligned dx");
   const bool vec4 = F % 4 == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
                                      reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(mean) |
@@ -912,12 +943,16 @@ extern "C" int vptr_norm_act_bwd(const float* dy, const float* x, const float* m
     const int frames = rows / HW;
     VPTR_CHECK(F % 4 == 0, "norm_act_bwd: F must be a multiple of 4");
     const int E4 = HW * F / 4;
-    const int fpb = frames >= 64 ? (frames + 3) / 4 : frames;
+    const int ysplit = partials ? vptr_norm_act_bwd_partials(rows, F, HW, 0) : 0;
+    if (partials) VPTR_CHECK(ysplit > 0 && (reinterpret_cast<uintptr_t>(partials) & 15) == 0, "norm_act_bwd: no deferred variant for this geometry");
+    // deferred: no atomics, so the frames are cut into more chunks (more waves in flight, 2 - 5 frames per wave instead of 10)
+    const int fpb = partials ? (frames + ysplit - 1) / ysplit : (frames >= 64 ? (frames + 3) / 4 : frames);
+    if (partials) VPTR_CHECK(cdiv(frames, fpb) == ysplit, "norm_act_bwd: frames %d do not split into %d chunks", frames, ysplit);   // (holds by construction)
     const int nparts = cdiv(E4, 64);  // scratch: [2*frames] sums followed by [nparts, frames, 2] per-wave partials
     float* part = scratch + 2 * frames;
     norm_act_bwd_frame_affine<<<dim3(nparts, cdiv(frames, fpb)), 256, 0, st>>>(dy, x, mean, rstd, w, b, dw, db, part, E4, F, HW, act,
                                                                                      dropout_p, seed_dev, site, frames, fpb, rowscale,
-                                                                                     rs_div, rs_mod);
+                                                                                     rs_div, rs_mod, partials);
     norm_act_bwd_frame_final<<<frames, 64, 0, st>>>(part, scratch, nparts, frames);
     if (vec4)
       norm_act_bwd_dx4_kernel<false><<<blocks4, 256, 0, st>>>(reinterpret_cast<const float4*>(dy), reinterpret_cast<const float4*>(x), mean, rstd, w, b,
@@ -929,6 +964,21 @@ extern "C" int vptr_norm_act_bwd(const float* dy, const float* x, const float* m
   }
   VPTR_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int vptr_norm_act_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
+                                 const float* b, float* dx, float* dw, float* db, float* scratch, int rows, int F, int HW,
+                                 int per_col, int act, int const_stats, float dropout_p, const uint64_t* seed_dev,
+                                 uint32_t site, const float* rowscale, int rs_div, int rs_mod, int p16, vptr_stream_t stream) {
+  return norm_act_bwd_impl(dy, x, mean, rstd, w, b, dx, dw, db, scratch, rows, F, HW, per_col, act, const_stats, dropout_p, seed_dev, site,
+                           rowscale, rs_div, rs_mod, p16, nullptr, stream);
+}
+extern "C" int vptr_norm_act_bwd_deferred(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
+                                          const float* b, float* dx, float* scratch, int rows, int F, int HW, int act, int const_stats,
+                                          float dropout_p, const uint64_t* seed_dev, uint32_t site, const float* rowscale, int rs_div,
+                                          int rs_mod, int p16, float* partials, vptr_stream_t stream) {
+  VPTR_CHECK(partials != nullptr, "norm_act_bwd_deferred: null partial-sum buffer");
+  return norm_act_bwd_impl(dy, x, mean, rstd, w, b, dx, nullptr, nullptr, scratch, rows, F, HW, 0, act, const_stats, dropout_p, seed_dev, site,
+                           rowscale, rs_div, rs_mod, p16, partials, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -1494,10 +1494,19 @@ class _NormActFn(torch.autograd.Function):
         dw, db = (sw, sb) if in_slab else (torch.zeros_like(w), torch.zeros_like(b))
         frames = rows // HW
         scratch = torch.empty((max(2 * F, 2 * frames * (1 + 4 * ((HW * F // 4 + 255) // 256))),), device=x.device, dtype=torch.float32)
-        check(lib.vptr_norm_act_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(b), ptr(dx), ptr(dw), ptr(db),
-                                    ptr(scratch), rows, F, HW, int(per_col), act, int(const_stats), p,
-                                    ptr(ctx.seed), site, ptr(rowscale), rs_div, rs_mod, int(dx_p16),
-                                    stream()), "vptr_norm_act_bwd")
+        nparts = lib.vptr_norm_act_bwd_partials(rows, F, HW, int(per_col)) if (in_slab and config.defer_ln_param_grads) else 0
+        if nparts > 0:
+            # affine gradients with an in-place destination: per-chunk partial sums, added by the backward pass's one reduction launch
+            part = torch.empty((nparts, 2, HW * F), device=x.device, dtype=torch.float32)
+            check(lib.vptr_norm_act_bwd_deferred(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(b), ptr(dx), ptr(scratch), rows, F, HW,
+                                                 act, int(const_stats), p, ptr(ctx.seed), site, ptr(rowscale), rs_div, rs_mod, int(dx_p16),
+                                                 ptr(part), stream()), "vptr_norm_act_bwd_deferred")
+            defer_partial_reduce(part, sw, sb, nparts, HW * F)
+        else:
+            check(lib.vptr_norm_act_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(b), ptr(dx), ptr(dw), ptr(db),
+                                        ptr(scratch), rows, F, HW, int(per_col), act, int(const_stats), p,
+                                        ptr(ctx.seed), site, ptr(rowscale), rs_div, rs_mod, int(dx_p16),
+                                        stream()), "vptr_norm_act_bwd")
         dres = dy if has_res else None
         if in_slab:
             dw = db = None
