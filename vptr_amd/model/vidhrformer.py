@@ -241,6 +241,11 @@ class MlpDWBN(nn.Module):
         return ops.norm_act(h, norm.weight, norm.bias, "bn", HW, self.training, norm.running_mean, norm.running_var,
                             eps=norm.eps, momentum=norm.momentum, num_batches_tracked=nbt, **kw)
 
+    def p16_in_ok(self):
+        """can forward_tokens take its input as a P16 tensor? (its own widths decide, not the block's: hidden_features is a
+        constructor argument of its own)"""
+        return ops.p16_ok(self.fc1.weight.shape[1], self.fc1.weight.shape[0], self.out_features)
+
     def forward_tokens(self, u, residual, g, site, rowscale=None, rs_div=1, rs_mod=1, x_p16=False):
         """x_p16: u is a P16 tensor.  With P16-eligible widths the tensors that only connect a normalisation to a 1x1 convolution
         never exist as fp32: norm2 writes fc2's input as P16, and the backward passes of norm3 / norm1 hand fc2 / fc1 their
@@ -319,8 +324,9 @@ class VidHRFormerBlockEnc(nn.Module):
         u, xr = ops.layernorm(x, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps, passthrough=True, out_p16=Pw)
         x = self.SLMHSA.forward_tokens(u, u, xr, g, lw_pos, s + 0, rowscale=dp, rs_div=per_n, rs_mod=g.N, x_p16=Pw)
         dp = _droppath_scale(self.drop_path_p, self.training, g.N, x.device)
-        u, xr = ops.layernorm(x, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps, passthrough=True, out_p16=P)
-        x = self.SpatialFFN.forward_tokens(u, xr, g, s + 1, rowscale=dp, rs_div=per_n, rs_mod=g.N, x_p16=P)
+        u, xr = ops.layernorm(x, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps, passthrough=True,
+                              out_p16=P and self.SpatialFFN.p16_in_ok())
+        x = self.SpatialFFN.forward_tokens(u, xr, g, s + 1, rowscale=dp, rs_div=per_n, rs_mod=g.N, x_p16=P and self.SpatialFFN.p16_in_ok())
         u, uq, xr = ops.layernorm(x, self.norm3.weight, self.norm3.bias, tab=tpos, tab_div=HW, tab_mod=g.T, eps=self.norm3.eps,
                                   passthrough=True, out_p16=P)
         x = _mha_tokens(self.temporal_MHSA, uq, uq, u, xr, g.N, g.T, g.T, HW, self.far, p, s + 3, out_dropout=p, out_site=s + 4,
@@ -400,8 +406,9 @@ class VidHRFormerBlockDecNAR(nn.Module):
                                   passthrough=True, out_p16=Pw)
         x = self.SLMHSA.forward_tokens(tq, t, xr, g, lw_pos, s + 0, rowscale=dp, rs_div=per_n, rs_mod=g.N, x_p16=Pw)
         dp = _droppath_scale(self.drop_path_p, self.training, g.N, tgt.device)
-        u, xr = ops.layernorm(x, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps, passthrough=True, out_p16=P)
-        x = self.SpatialFFN.forward_tokens(u, xr, g, s + 1, rowscale=dp, rs_div=per_n, rs_mod=g.N, x_p16=P)
+        u, xr = ops.layernorm(x, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps, passthrough=True,
+                              out_p16=P and self.SpatialFFN.p16_in_ok())
+        x = self.SpatialFFN.forward_tokens(u, xr, g, s + 1, rowscale=dp, rs_div=per_n, rs_mod=g.N, x_p16=P and self.SpatialFFN.p16_in_ok())
         u, uq, xr = ops.layernorm(x, self.norm3.weight, self.norm3.bias, tab=tpos_f, tab_div=HW, tab_mod=T2, eps=self.norm3.eps,
                                   passthrough=True, out_p16=P)
         x = _mha_tokens(self.temporal_MHSA, uq, uq, u, xr, g.N, T2, T2, HW, False, p, s + 3, out_dropout=p, out_site=s + 4,
@@ -431,8 +438,9 @@ class VidHRFormerBlockDecNAR(nn.Module):
             x = _mha_tokens(self.EncDecAttn, uq, mem_k, mem, xr, g.N, T2, T1, HW, False, p, s + 7, rowscale=dpt, rs_div=HW, rs_mod=T2,
                             x_p16=P, kv_acc=kv_acc)
         dp = _droppath_scale(self.drop_path_p, self.training, g.N, tgt.device)
-        u, xr = ops.layernorm(x, self.norm6.weight, self.norm6.bias, eps=self.norm6.eps, passthrough=True, out_p16=P)
-        return self.SpatialFFN1.forward_tokens(u, xr, g, s + 8, rowscale=dp, rs_div=per_n, rs_mod=g.N, x_p16=P)
+        P1 = P and self.SpatialFFN1.p16_in_ok()
+        u, xr = ops.layernorm(x, self.norm6.weight, self.norm6.bias, eps=self.norm6.eps, passthrough=True, out_p16=P1)
+        return self.SpatialFFN1.forward_tokens(u, xr, g, s + 8, rowscale=dp, rs_div=per_n, rs_mod=g.N, x_p16=P1)
 
 
 class VidHRformerDecoderNAR(nn.Module):
