@@ -230,3 +230,23 @@ def test_frame_stats_from_producers(ops, dev):
         bb.grad = None
     for a, r in zip(outs[0], outs[1]):
         assert rel(a, r) < 1e-5
+
+
+def test_frame_stats_large_mean_guard(ops, dev):
+    """|mean| >> std in a LayerNorm((F,H,W)) input whose statistics come from its producer's single-pass sums: E[x^2] - mean^2 has lost
+    its bits, the normalise kernel must notice (var < 1e-3 E[x^2]) and recompute the frame's variance around the mean"""
+    frames, HW, C, F_ = 4, 64, 64, 528
+    rows = frames * HW
+    x, W = rn((rows, C), 30), rn((F_, C), 31, 0.002)
+    b = torch.full((F_,), 40.0)                         # fc1 output = 40 +- ~0.02: E[x^2] / var ~ 4e6
+    nw, nb = rn((HW, F_), 36).abs() + 0.5, rn((HW, F_), 37, 0.1)
+    x, W, b, nw, nb = (t.to(dev) for t in (x, W, b, nw, nb))
+    assert ops.frame_stats_ok(rows, HW, F_)
+    st = ops.frame_stats_buffer(frames, dev)
+    y = ops.linear(x, W, b, frame_stats=st, frame_rows=HW)
+    a = ops.norm_act(y, nw, nb, "ln", HW, True, raw_stats=st)
+    yd = y.double().reshape(frames, HW * F_)
+    xh = (yd - yd.mean(1, keepdim=True)) / torch.sqrt(yd.var(1, unbiased=False, keepdim=True) + 1e-5)
+    z = xh.reshape(rows, F_) * nw.double().repeat(frames, 1) + nb.double().repeat(frames, 1)
+    ref = 0.5 * z * (1.0 + torch.erf(z / 2 ** 0.5))
+    assert float((a.double() - ref).norm() / ref.norm()) < 1e-4

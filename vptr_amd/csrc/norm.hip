@@ -588,7 +588,8 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const float* __restri
                                                            uint32_t site, const float* __restrict__ rowscale, int rs_div,
                                                            int rs_mod, const float* __restrict__ residual, int p16,
                                                            const float* __restrict__ raw_stats, float* __restrict__ mean_out,
-                                                           float* __restrict__ rstd_out, float eps) {
+                                                           float* __restrict__ rstd_out, float eps, int guard) {
+  __shared__ float gred[16];
   const int64_t total = (int64_t)rows * F4;
   uint64_t seed = 0;
   if (p > 0.f) seed = *seed_dev;
@@ -607,7 +608,25 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const float* __restri
       float m, r;
       if (raw_stats) {   // per-frame sum / sum of squares accumulated by the PRODUCER's epilogue (vptr_gemm frame_stats, vptr_dwconv3x3_fwd)
         m = raw_stats[2 * f] * inv_n;
-        r = rsqrtf(fmaxf(raw_stats[2 * f + 1] * inv_n - m * m, 0.f) + eps);
+        const float e2 = raw_stats[2 * f + 1] * inv_n;
+        float var = fmaxf(e2 - m * m, 0.f);
+        // E[x^2] - mean^2 from fp32 sums loses log2(E[x^2] / var) bits.  |mean| > ~30 std: recompute the frame's variance around its
+        // mean (exact two-pass; this workgroup reads the whole frame -- every workgroup of the frame finds the same value).  guard:
+        // a workgroup iteration lies inside ONE frame (HW * F4 % 256 == 0, checked by the launcher), so the branch is uniform.
+        if (guard && var < 1e-3f * e2) {
+          const float4* xf = reinterpret_cast<const float4*>(x) + (int64_t)f * HW * F4;
+          float sq = 0.f, s1 = 0.f;   // around the approximate mean m: both sums are small, nothing cancels
+          for (int j = threadIdx.x; j < HW * F4; j += 256) {
+            const float4 t = xf[j];
+            const float a = t.x - m, b2 = t.y - m, c = t.z - m, d = t.w - m;
+            s1 += (a + b2) + (c + d);
+            sq += (a * a + b2 * b2) + (c * c + d * d);
+          }
+          const float dm = block_sum(s1, gred) * inv_n;   // the mean of 135 k fp32 atomics is itself off by a fraction of such a std
+          var = fmaxf(block_sum(sq, gred) * inv_n - dm * dm, 0.f);
+          m += dm;
+        }
+        r = rsqrtf(var + eps);
         if (hw == 0 && c4 == 0) { mean_out[f] = m; rstd_out[f] = r; }   // kept for the backward pass
       } else {
         m = mean[f];
@@ -654,8 +673,9 @@ extern "C" int vptr_norm_act_fwd(const float* x, float* mean, float* rstd, const
   const int blocks = (int)hmin64((total + 255) / 256, 8192);
   hipStream_t st = (hipStream_t)stream;
   if (rowscale) VPTR_CHECK(rs_div >= 1 && rs_mod >= 1, "norm_act_fwd: rowscale needs rs_div, rs_mod >= 1");
-  if (per_col) norm_act_fwd_kernel<true><<<blocks, 256, 0, st>>>(x, mean, rstd, w, b, y, rows, F / 4, HW, act, dropout_p, seed_dev, site, rowscale, rs_div, rs_mod, residual, p16, nullptr, nullptr, nullptr, eps);
-  else norm_act_fwd_kernel<false><<<blocks, 256, 0, st>>>(x, raw_stats ? nullptr : mean, raw_stats ? nullptr : rstd, w, b, y, rows, F / 4, HW, act, dropout_p, seed_dev, site, rowscale, rs_div, rs_mod, residual, p16, raw_stats, mean, rstd, eps);
+  if (per_col) norm_act_fwd_kernel<true><<<blocks, 256, 0, st>>>(x, mean, rstd, w, b, y, rows, F / 4, HW, act, dropout_p, seed_dev, site, rowscale, rs_div, rs_mod, residual, p16, nullptr, nullptr, nullptr, eps, 0);
+  else norm_act_fwd_kernel<false><<<blocks, 256, 0, st>>>(x, raw_stats ? nullptr : mean, raw_stats ? nullptr : rstd, w, b, y, rows, F / 4, HW, act, dropout_p, seed_dev, site, rowscale, rs_div, rs_mod, residual, p16, raw_stats, mean, rstd, eps,
+                                                          (int)(raw_stats && ((int64_t)HW * (F / 4)) % 256 == 0 && total % 256 == 0));
   VPTR_LAUNCH_CHECK();
   return 0;
 }
