@@ -219,7 +219,10 @@ typedef struct vptr_reduce_entry {
   float* dst1;         /* [C] += sum over p of part[p][1][:] */
   int nparts, C;
 } vptr_reduce_entry;
-int vptr_partial_reduce(const vptr_reduce_entry* table_dev, int count, int max_C, vptr_stream_t stream);
+/* unique_dst != 0: no two entries name overlapping destinations -> plain read-add-write (16 bytes wide where the destination
+ * is aligned) instead of one atomic per element (13 M atomics for the K64 step's LayerNorm((F,H,W)) affines) */
+int vptr_partial_reduce(const vptr_reduce_entry* table_dev, int count, int max_C /* of the entries (every C % 4 == 0, 16-byte aligned parts) */,
+                        int unique_dst, vptr_stream_t stream);
 
 /* out[(row / div) % mod, :] += src[row, :]   (gradient of a row-broadcast table; out must be zeroed by the caller) */
 int vptr_rowmod_sum(const float* src, float* out, int rows, int C, int div, int mod, vptr_stream_t stream);

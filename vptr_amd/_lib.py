@@ -69,7 +69,7 @@ SIGNATURES = {
     "vptr_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, I, P, P],
     "vptr_layernorm_bwd_deferred": [P, P, P, P, P, P, P, I, I, P, P, P],
     "vptr_layernorm_bwd_partials": [I, I],
-    "vptr_partial_reduce": [P, I, I, P],
+    "vptr_partial_reduce": [P, I, I, I, P],
     "vptr_rowmod_sum": [P, P, I, I, I, I, P],
     "vptr_colsum": [P, P, I, I, P],
     "vptr_window_copy": [P, P, I, I, I, I, I, I, I, I, P],

@@ -314,41 +314,64 @@ extern "C" int vptr_layernorm_bwd_deferred(const float* dy, const float* dy2, co
 }
 // Deferred parameter-gradient sums of a whole backward pass in ONE launch: entry e adds the nparts rows of part[nparts][2][C] into
 // dst0[C] (row 0 of each pair) and dst1[C] (row 1).  The final add is an atomic: two entries may name the same destination (a module
-// applied twice in one forward).  Workgroup = 64 columns x 4 row lanes.
-__global__ __launch_bounds__(256) void partial_reduce_kernel(const vptr_reduce_entry* __restrict__ tab) {
-  __shared__ float red[2][4][64];
+// applied twice in one forward).  Workgroup = 64 float4 columns x 16 row lanes.
+__global__ __launch_bounds__(1024) void partial_reduce_kernel(const vptr_reduce_entry* __restrict__ tab, const int unique_dst) {
+  __shared__ float4 red[2][16][64];
   const vptr_reduce_entry e = tab[blockIdx.y];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-  float a0 = 0.f, a1 = 0.f;
-  if (c < e.C) {
+  const int C4 = e.C >> 2;                      // C % 4 == 0 (checked on the host side of the table)
+  const int l = threadIdx.x & 63, q = threadIdx.x >> 6, c4 = blockIdx.x * 64 + l;
+  if (blockIdx.x * 64 >= C4) return;            // (workgroup-uniform: the grid is sized for the widest entry)
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  if (c4 < C4) {
+    const float4* part = reinterpret_cast<const float4*>(e.part);
     int p = q;
-    for (; p + 12 < e.nparts; p += 16) {
-      float t0[4], t1[4];
+    for (; p + 48 < e.nparts; p += 64) {        // 8 independent 16-byte loads in flight
+      float4 t0[4], t1[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        t0[u] = e.part[((int64_t)(p + 4 * u) * 2) * e.C + c];
-        t1[u] = e.part[((int64_t)(p + 4 * u) * 2 + 1) * e.C + c];
+        t0[u] = part[((int64_t)(p + 16 * u) * 2) * C4 + c4];
+        t1[u] = part[((int64_t)(p + 16 * u) * 2 + 1) * C4 + c4];
       }
-      a0 += (t0[0] + t0[1]) + (t0[2] + t0[3]);
-      a1 += (t1[0] + t1[1]) + (t1[2] + t1[3]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a0.x += t0[u].x; a0.y += t0[u].y; a0.z += t0[u].z; a0.w += t0[u].w;
+        a1.x += t1[u].x; a1.y += t1[u].y; a1.z += t1[u].z; a1.w += t1[u].w;
+      }
     }
-    for (; p < e.nparts; p += 4) {
-      a0 += e.part[((int64_t)p * 2) * e.C + c];
-      a1 += e.part[((int64_t)p * 2 + 1) * e.C + c];
+    for (; p < e.nparts; p += 16) {
+      const float4 t0 = part[((int64_t)p * 2) * C4 + c4], t1 = part[((int64_t)p * 2 + 1) * C4 + c4];
+      a0.x += t0.x; a0.y += t0.y; a0.z += t0.z; a0.w += t0.w;
+      a1.x += t1.x; a1.y += t1.y; a1.z += t1.z; a1.w += t1.w;
     }
   }
-  red[0][q][threadIdx.x & 63] = a0;
-  red[1][q][threadIdx.x & 63] = a1;
+  red[0][q][l] = a0;
+  red[1][q][l] = a1;
   __syncthreads();
-  if (q == 0 && c < e.C) {
-    const int l = threadIdx.x & 63;
-    unsafeAtomicAdd(e.dst0 + c, (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]));
-    unsafeAtomicAdd(e.dst1 + c, (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]));
+  if (q < 2 && c4 < C4) {                       // row lane 0 finishes dst0, row lane 1 dst1
+    float4 sum = red[q][0][l];
+#pragma unroll
+    for (int u = 1; u < 16; ++u) {
+      const float4 t = red[q][u][l];
+      sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+    }
+    float* dst = (q ? e.dst1 : e.dst0) + (int64_t)c4 * 4;
+    if (unique_dst) {   // no other entry of this launch (and nothing else in flight) writes this destination: plain read-add-write
+      if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        float4 d = *reinterpret_cast<float4*>(dst);
+        d.x += sum.x; d.y += sum.y; d.z += sum.z; d.w += sum.w;
+        *reinterpret_cast<float4*>(dst) = d;
+      } else {
+        dst[0] += sum.x; dst[1] += sum.y; dst[2] += sum.z; dst[3] += sum.w;
+      }
+    } else {
+      unsafeAtomicAdd(dst + 0, sum.x); unsafeAtomicAdd(dst + 1, sum.y);
+      unsafeAtomicAdd(dst + 2, sum.z); unsafeAtomicAdd(dst + 3, sum.w);
+    }
   }
 }
-extern "C" int vptr_partial_reduce(const vptr_reduce_entry* table_dev, int count, int max_C, vptr_stream_t stream) {
-  VPTR_CHECK(table_dev && count > 0 && max_C > 0, "partial_reduce: bad arguments");
-  partial_reduce_kernel<<<dim3(cdiv(max_C, 64), count), 256, 0, (hipStream_t)stream>>>(table_dev);
+extern "C" int vptr_partial_reduce(const vptr_reduce_entry* table_dev, int count, int max_C, int unique_dst, vptr_stream_t stream) {
+  VPTR_CHECK(table_dev && count > 0 && max_C > 0 && max_C % 4 == 0, "partial_reduce: bad arguments (every C must be a multiple of 4)");
+  partial_reduce_kernel<<<dim3(cdiv(max_C / 4, 64), count), 1024, 0, (hipStream_t)stream>>>(table_dev, unique_dst);
   VPTR_LAUNCH_CHECK();
   return 0;
 }

@@ -452,12 +452,25 @@ def flush_partial_reduces():
         return
     items = list(_reduce_q)
     del _reduce_q[:]
+    # one table, one upload; entries sorted by width and launched per width class (the grid is sized for the widest entry of a launch:
+    # the 528-wide LayerNorm rows must not ride on the grid of the 135 168-wide LayerNorm((F,H,W)) rows)
+    items.sort(key=lambda it: it[4])
     tab = (_lib.ReduceEntry * len(items))()
     for i, (part, d0, d1, nparts, C) in enumerate(items):
         tab[i].part, tab[i].dst0, tab[i].dst1, tab[i].nparts, tab[i].C = ptr(part), ptr(d0), ptr(d1), nparts, C
     dev = items[0][0].device
     raw = _to_device_async(bytes(tab), dev)
-    check(lib.vptr_partial_reduce(ptr(raw), len(items), max(it[4] for it in items), stream()), "vptr_partial_reduce")
+    esz = ctypes.sizeof(_lib.ReduceEntry)
+    lo = 0
+    while lo < len(items):
+        hi = lo
+        while hi < len(items) and items[hi][4] <= 4 * items[lo][4]:
+            hi += 1
+        dsts = [it[k].data_ptr() for it in items[lo:hi] for k in (1, 2)]
+        unique = len(set(dsts)) == len(dsts)   # a module applied twice in one forward: atomics
+        check(lib.vptr_partial_reduce(ctypes.c_void_p(raw.data_ptr() + lo * esz), hi - lo, items[hi - 1][4], int(unique), stream()),
+              "vptr_partial_reduce")
+        lo = hi
 
 
 _wgrad_hold = [False]  # set by hold_wgrads(): the end-of-backward callback leaves the queue to an explicit chunked flush
