@@ -390,9 +390,23 @@ __global__ __launch_bounds__(256) void rowmod_sum_kernel(const float* __restrict
   const int nper = (rows + period - 1) / period;
   const int p0 = blockIdx.z * groups_per_block, p1 = min(nper, p0 + groups_per_block);
   float a = 0.f;
-  for (int p = p0; p < p1; ++p) {
+  int p = p0;
+  if (div == 1) {   // one row per period: the periods are the independent loads
+    for (; p + 3 < p1 && (p + 3) * period + j < rows; p += 4) {
+      const float v0 = src[(int64_t)(p * period + j) * C + c], v1 = src[(int64_t)((p + 1) * period + j) * C + c];
+      const float v2 = src[(int64_t)((p + 2) * period + j) * C + c], v3 = src[(int64_t)((p + 3) * period + j) * C + c];
+      a += (v0 + v1) + (v2 + v3);
+    }
+  }
+  for (; p < p1; ++p) {
     const int rbase = p * period + j * div;
-    for (int d = 0; d < div; ++d) {
+    int d = 0;
+    for (; d + 3 < div && rbase + d + 3 < rows; d += 4) {   // four independent loads in flight
+      const float v0 = src[(int64_t)(rbase + d) * C + c], v1 = src[(int64_t)(rbase + d + 1) * C + c];
+      const float v2 = src[(int64_t)(rbase + d + 2) * C + c], v3 = src[(int64_t)(rbase + d + 3) * C + c];
+      a += (v0 + v1) + (v2 + v3);
+    }
+    for (; d < div; ++d) {
       const int r = rbase + d;
       if (r < rows) a += src[(int64_t)r * C + c];
     }
@@ -520,13 +534,22 @@ __global__ __launch_bounds__(256) void colstats_final_kernel(const float* __rest
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= F) return;
   float n = 0.f, mu = 0.f, m2 = 0.f;
-  for (int k = 0; k < nchunk; ++k) {
-    const float nb = (float)min(256, rows - k * 256);
-    const float mb = scratch[((int64_t)k * F + c) * 2 + 0], m2b = scratch[((int64_t)k * F + c) * 2 + 1];
-    const float d = mb - mu, nt = n + nb;
-    mu += d * nb / nt;
-    m2 += m2b + d * d * n * nb / nt;
-    n = nt;
+  const float2* sc2 = reinterpret_cast<const float2*>(scratch);
+  for (int k0 = 0; k0 < nchunk; k0 += 8) {   // 8 chunk records in flight, then the (sequential) Chan merges: the merge chain no longer
+    float2 rec[8];                            // waits out a load round trip per chunk (40 chunks: 15 us -> a few)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rec[u] = sc2[(int64_t)min(k0 + u, nchunk - 1) * F + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u;
+      if (k < nchunk) {
+        const float nb = (float)min(256, rows - k * 256);
+        const float d = rec[u].x - mu, nt = n + nb;
+        mu += d * nb / nt;
+        m2 += rec[u].y + d * d * n * nb / nt;
+        n = nt;
+      }
+    }
   }
   mean[c] = mu;
   var[c] = m2 / n;
