@@ -214,9 +214,9 @@ int vptr_layernorm_bwd_deferred(const float* dy, const float* dy2, const float* 
                                 vptr_stream_t stream);
 int vptr_layernorm_bwd_partials(int rows, int C);   /* a plain number, not an error code */
 typedef struct vptr_reduce_entry {
-  const float* part;   /* [nparts][2][C] */
+  const float* part;   /* [nparts][2][C]; with dst1 == null [nparts][C] */
   float* dst0;         /* [C] += sum over p of part[p][0][:] */
-  float* dst1;         /* [C] += sum over p of part[p][1][:] */
+  float* dst1;         /* [C] += sum over p of part[p][1][:], or null */
   int nparts, C;
 } vptr_reduce_entry;
 /* unique_dst != 0: no two entries name overlapping destinations -> plain read-add-write (16 bytes wide where the destination
@@ -398,6 +398,9 @@ int vptr_bnrelu_bwd_fused(const float* dy, const float* y, const float* scale, c
  * GEMMs (autograd of ResNetAutoEncoder.py:33-48,74-88,138,151 and of the PatchGAN convs VPTR_modules.py:70-91). */
 int vptr_im2col_nhwc(const float* x, float* out, int B, int IH, int IW, int C, int OH, int OW, int KH, int KW, int stride,
                      int pad, int pad_mode, vptr_stream_t stream);
+/* the same matrix as a P16 tensor (C % 16 == 0): token-major B operand of vptr_gemm_grouped (VPTR_B_P16T) */
+int vptr_im2col_nhwc_p16(const float* x, float* out_p16, int B, int IH, int IW, int C, int OH, int OW, int KH, int KW,
+                         int stride, int pad, int pad_mode, vptr_stream_t stream);
 /* adjoint of reflection padding: dxpad [B, H+2p, W+2p, C] (gradient w.r.t. the padded image, e.g. from the gather-form
  * transposed convolution with pad 0) -> dx [B, H, W, C], each border contribution folded back onto the pixel it mirrors
  * (nn.ReflectionPad2d of ResnetBlock, ResNetAutoEncoder.py:127-151). */

@@ -107,6 +107,7 @@ SIGNATURES = {
     "vptr_bnrelu_bwd_params": [P, P, P, P, P, P, L, I, P],
     "vptr_bnrelu_bwd_fused": [P, P, P, P, P, P, P, P, L, I, P],
     "vptr_im2col_nhwc": [P, P, I, I, I, I, I, I, I, I, I, I, I, P],
+    "vptr_im2col_nhwc_p16": [P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     "vptr_reflect_fold": [P, P, I, I, I, I, I, P],
     "vptr_conv7_in_bwd_weight": [P, P, P, I, I, I, I, I, P],
     "vptr_mse_gdl_fwd": [P, P, P, P, P, I, I, I, P],

@@ -677,6 +677,42 @@ __global__ __launch_bounds__(256) void im2col_nhwc_kernel(const float* __restric
     reinterpret_cast<float4*>(out)[i] = v;
   }
 }
+// the same patch matrix in the P16 operand format (C % 16 == 0): the B operand of the decoder's weight-gradient problems on the
+// token-major P16 kernel
+__global__ __launch_bounds__(256) void im2col_nhwc_p16_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int IH,
+                                                              int IW, int C4, int OH, int OW, int KH, int KW, int stride, int pad,
+                                                              int pad_mode) {
+  const int64_t total = (int64_t)B * OH * OW * KH * KW * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    int64_t t = i / C4;
+    const int kx = (int)(t % KW); t /= KW;
+    const int ky = (int)(t % KH); t /= KH;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const int b = (int)(t / OH);
+    int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool ok = true;
+    if (pad_mode == VPTR_PAD_REFLECT) { iy = reflect_idx(iy, IH); ix = reflect_idx(ix, IW); }
+    else ok = iy >= 0 && iy < IH && ix >= 0 && ix < IW;
+    if (ok) v = reinterpret_cast<const float4*>(x)[(((int64_t)b * IH + iy) * IW + ix) * C4 + c4];
+    vptr_p16_store4(reinterpret_cast<unsigned char*>(out), i * 4, v);   // flat element index = ((pixel * taps + tap) * C + c): rows of taps * C
+  }
+}
+extern "C" int vptr_im2col_nhwc_p16(const float* x, float* out_p16, int B, int IH, int IW, int C, int OH, int OW, int KH, int KW,
+                                    int stride, int pad, int pad_mode, vptr_stream_t stream) {
+  VPTR_CHECK(B > 0 && IH > 0 && IW > 0 && C > 0 && C % 16 == 0 && OH > 0 && OW > 0 && KH > 0 && KW > 0 && stride >= 1,
+             "im2col_nhwc_p16: bad arguments (C must be a multiple of 16)");
+  VPTR_CHECK(pad_mode == VPTR_PAD_ZERO || pad_mode == VPTR_PAD_REFLECT, "im2col_nhwc_p16: pad_mode must be zero or reflect");
+  if (pad_mode == VPTR_PAD_REFLECT) VPTR_CHECK(pad < IH && pad < IW, "im2col_nhwc_p16: reflect padding needs pad < H, W");
+  VPTR_CHECK((reinterpret_cast<uintptr_t>(out_p16) & 63) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "im2col_nhwc_p16: unaligned buffers");
+  const int64_t total = (int64_t)B * OH * OW * KH * KW * (C / 4);
+  const int blocks = (int)hmin64((total + 255) / 256, 16384);
+  im2col_nhwc_p16_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(x, out_p16, B, IH, IW, C / 4, OH, OW, KH, KW, stride, pad, pad_mode);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
 extern "C" int vptr_im2col_nhwc(const float* x, float* out, int B, int IH, int IW, int C, int OH, int OW, int KH, int KW,
                                 int stride, int pad, int pad_mode, vptr_stream_t stream) {
   VPTR_CHECK(B > 0 && IH > 0 && IW > 0 && C > 0 && C % 4 == 0 && OH > 0 && OW > 0 && KH > 0 && KW > 0 && stride >= 1,

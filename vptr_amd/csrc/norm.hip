@@ -321,6 +321,7 @@ __global__ __launch_bounds__(1024) void partial_reduce_kernel(const vptr_reduce_
   const int C4 = e.C >> 2;                      // C % 4 == 0 (checked on the host side of the table)
   const int l = threadIdx.x & 63, q = threadIdx.x >> 6, c4 = blockIdx.x * 64 + l;
   if (blockIdx.x * 64 >= C4) return;            // (workgroup-uniform: the grid is sized for the widest entry)
+  const int rpp = e.dst1 ? 2 : 1;               // rows per part: [nparts][2][C] with two destinations, [nparts][1][C] with one
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
   if (c4 < C4) {
     const float4* part = reinterpret_cast<const float4*>(e.part);
@@ -329,8 +330,8 @@ __global__ __launch_bounds__(1024) void partial_reduce_kernel(const vptr_reduce_
       float4 t0[4], t1[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        t0[u] = part[((int64_t)(p + 16 * u) * 2) * C4 + c4];
-        t1[u] = part[((int64_t)(p + 16 * u) * 2 + 1) * C4 + c4];
+        t0[u] = part[((int64_t)(p + 16 * u) * rpp) * C4 + c4];
+        t1[u] = part[((int64_t)(p + 16 * u) * rpp + rpp - 1) * C4 + c4];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(1024) void partial_reduce_kernel(const vptr_reduce_
       }
     }
     for (; p < e.nparts; p += 16) {
-      const float4 t0 = part[((int64_t)p * 2) * C4 + c4], t1 = part[((int64_t)p * 2 + 1) * C4 + c4];
+      const float4 t0 = part[((int64_t)p * rpp) * C4 + c4], t1 = part[((int64_t)p * rpp + rpp - 1) * C4 + c4];
       a0.x += t0.x; a0.y += t0.y; a0.z += t0.z; a0.w += t0.w;
       a1.x += t1.x; a1.y += t1.y; a1.z += t1.z; a1.w += t1.w;
     }
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(1024) void partial_reduce_kernel(const vptr_reduce_
   red[0][q][l] = a0;
   red[1][q][l] = a1;
   __syncthreads();
-  if (q < 2 && c4 < C4) {                       // row lane 0 finishes dst0, row lane 1 dst1
+  if (q < rpp && c4 < C4) {                     // row lane 0 finishes dst0, row lane 1 dst1
     float4 sum = red[q][0][l];
 #pragma unroll
     for (int u = 1; u < 16; ++u) {

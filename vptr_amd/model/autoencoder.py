@@ -273,6 +273,7 @@ class _DecoderFn(torch.autograd.Function):
             check(lib.vptr_conv7_out_bwd_weight_ws(ptr(dout), ptr(out), ptr(acts[-1]), ptr(dw7), ptr(db7), B, cin, h, w, cimg,
                                                    dec.out_act, ptr(wsp), wsp.numel(), stream()), "vptr_conv7_out_bwd_weight_ws")
             wgrads[id(conv.weight)], wgrads[id(conv.bias)] = dw7, db7
+        convt_jobs = []
         for i in reversed(range(n_up)):
             ih, iw, ic, oh, ow, oc = geoms[i]
             gm = torch.empty_like(g)
@@ -293,20 +294,28 @@ class _DecoderFn(torch.autograd.Function):
                                                      ptr(dbw), ptr(dbb), B * oh * ow, oc, stream()), "vptr_bnrelu_bwd_params")
                     wgrads[id(bn.weight)], wgrads[id(bn.bias)] = dbw, dbb
             if want_w and convt.weight.requires_grad:
-                # dW[ci][co][ky][kx] = sum_pix x[pix][ci] * gm[(iy*2-1+ky, ix*2-1+kx)][co]: im2col of gm (3x3, s2, p1) and one
-                # split-K GEMM  D[ci][(ky,kx,co)] = x^T . P  with both operands k-strided
+                # dW[ci][co][ky][kx] = sum_pix x[pix][ci] * gm[(iy*2-1+ky, ix*2-1+kx)][co]: im2col of gm (3x3, s2, p1) and
+                # D[ci][(ky,kx,co)] = x^T . P
                 xin = ctx.x0 if i == 0 else acts[i - 1]
-                P = torch.empty((B * ih * iw, 9 * oc), device=dout.device, dtype=torch.float32)
-                check(lib.vptr_im2col_nhwc(ptr(gm), ptr(P), B, oh, ow, oc, ih, iw, 3, 3, 2, 1, 0, stream()), "vptr_im2col_nhwc")
-                D = torch.zeros((ic, 9 * oc), device=dout.device, dtype=torch.float32)
-                tiles = ((ic + 127) // 128) * ((9 * oc + 175) // 176)
-                ops.gemm_raw(xin, P, D, ic, 9 * oc, B * ih * iw, 1, 1, atomic=True, split_k=ops._split_k_for(tiles, B * ih * iw))
-                wgrads[id(convt.weight)] = D.view(ic, 3, 3, oc).permute(0, 3, 1, 2).contiguous()
+                if ops.p16_ok(ic, oc) and os.environ.get("VPTR_DEC_WGRAD_P16", "1") != "0":
+                    # all layers together at the end: token-range sub-problems in one launch of the token-major P16 kernel
+                    convt_jobs.append((convt, (xin, gm, B, ih, iw, ic, oh, ow, oc)))
+                else:
+                    P = torch.empty((B * ih * iw, 9 * oc), device=dout.device, dtype=torch.float32)
+                    check(lib.vptr_im2col_nhwc(ptr(gm), ptr(P), B, oh, ow, oc, ih, iw, 3, 3, 2, 1, 0, stream()), "vptr_im2col_nhwc")
+                    D = torch.zeros((ic, 9 * oc), device=dout.device, dtype=torch.float32)
+                    tiles = ((ic + 127) // 128) * ((9 * oc + 175) // 176)
+                    ops.gemm_raw(xin, P, D, ic, 9 * oc, B * ih * iw, 1, 1, atomic=True, split_k=ops._split_k_for(tiles, B * ih * iw))
+                    wgrads[id(convt.weight)] = D.view(ic, 3, 3, oc).permute(0, 3, 1, 2).contiguous()
             # dgrad of ConvTranspose2d(3x3, s2, p1, op1) = Conv2d(3x3, s2, p1) of the output gradient with
             # B[ci][(ky,kx,co)] = W[ci][co][ky][kx]
             wt = m[3 * i].weight
             Bm = ops.conv_weight_as_gemm_b(wt, False)  # = wt.permute(0, 2, 3, 1).reshape(Cin, -1), cached
             g = ops.conv_nhwc(gm, Bm, B, oh, ow, oc, ih, iw, 3, 3, 2, 1, "zero", False, ic)
+        if convt_jobs:
+            for (convt, job), D in zip(convt_jobs, ops.convt_weight_grads([j for _, j in convt_jobs])):
+                ic, oc = job[5], job[8]
+                wgrads[id(convt.weight)] = D.view(ic, 3, 3, oc).permute(0, 3, 1, 2).contiguous()
         h0, w0, c0 = geoms[0][0], geoms[0][1], geoms[0][2]
         dfeat = torch.empty((B, c0, h0, w0), device=dout.device, dtype=torch.float32)
         check(lib.vptr_tokens_to_nchw(ptr(g), ptr(dfeat), B, c0, h0 * w0, 0, stream()), "vptr_tokens_to_nchw")

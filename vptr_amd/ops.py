@@ -591,7 +591,7 @@ def _to_device_async(host_bytes, dev):
     return out
 
 
-def _launch_wgrad_group(its):
+def _launch_wgrad_group(its, atomic=1):
     groups = {}
     for it in its:
         p16 = it[9]
@@ -630,7 +630,7 @@ def _launch_wgrad_group(its):
         total = 0
         for i, (ap, bp, dp, rp, lda, ldb, ldd, rows_, cols_, M, alpha, flip) in enumerate(subs):
             d = descs[i]
-            d.precision, d.split_k, d.atomic, d.alpha = prec, 1, 1, alpha
+            d.precision, d.split_k, d.atomic, d.alpha = prec, 1, int(atomic), alpha
             d.A, d.B, d.D, d.a_rowsum = ap, bp, dp, (rp or None)
             d.lda, d.ldb, d.ldd = lda, ldb, ldd
             d.M, d.N, d.K = rows_, cols_, M
@@ -650,6 +650,41 @@ def _launch_wgrad_group(its):
         if prof is not None:
             e1.record()
             prof.append(((cols // 16, prec, 6 if p16 else 1, 4 if p16 else 1, "grouped"), flops, e0, e1))
+
+
+def convt_weight_grads(layers, tokens_per_split=2560):
+    """Weight gradients of ConvTranspose2d(3x3, s2, p1, op1) layers, D[ci][(ky, kx, co)] = sum_pix x[pix][ci] * P[pix][(ky, kx, co)] with
+    P = im2col (3x3, s2, p1) of the output gradient, on the token-major P16 kernel of the grouped weight-gradient launch.  Alone such
+    a problem is 4 - 70 output tiles over up to 164 k tokens, so every layer is cut into token ranges of `tokens_per_split`; all ranges
+    of all layers run as ONE grouped launch (plain stores into per-range buffers), one vptr_partial_reduce launch adds them up.
+    layers: (x [pix, ci] fp32, g [B * oh * ow, co] fp32, B, ih, iw, ci, oh, ow, co); returns the D tensors [ci, 9 * co]."""
+    items, keep, outs, red = [], [], [], []
+    for (x, g, B, ih, iw, ci, oh, ow, co) in layers:
+        pix = B * ih * iw
+        P = torch.empty((pix, 9 * co), device=g.device, dtype=torch.float32)      # P16
+        check(lib.vptr_im2col_nhwc_p16(ptr(g), ptr(P), B, oh, ow, co, ih, iw, 3, 3, 2, 1, 0, stream()), "vptr_im2col_nhwc_p16")
+        xs = to_p16(x)
+        S = max(1, pix // int(tokens_per_split))
+        step = (pix + S - 1) // S
+        step = (step + 31) // 32 * 32                                              # whole 32-token steps per range
+        S = (pix + step - 1) // step
+        part = torch.empty((S, ci, 9 * co), device=g.device, dtype=torch.float32)
+        for k in range(S):
+            r0, r1 = k * step, min(pix, (k + 1) * step)
+            items.append((xs[r0:r1], P[r0:r1], part[k], ci, 9 * co, r1 - r0, config.gemm_precision, None, 1.0, True))
+        D = torch.zeros((ci, 9 * co), device=g.device, dtype=torch.float32)
+        red.append((part, D, S, ci * 9 * co))
+        keep += [P, xs, part]
+        outs.append(D)
+    _launch_wgrad_group(items, atomic=0)
+    tab = (_lib.ReduceEntry * len(red))()
+    for i, (part, D, S, C) in enumerate(red):
+        tab[i].part, tab[i].dst0, tab[i].dst1, tab[i].nparts, tab[i].C = ptr(part), ptr(D), None, S, C
+    raw = _to_device_async(bytes(tab), outs[0].device)
+    esz = ctypes.sizeof(_lib.ReduceEntry)
+    for i, (part, D, S, C) in enumerate(red):   # one launch per layer: the widths differ by 4x
+        check(lib.vptr_partial_reduce(ctypes.c_void_p(raw.data_ptr() + i * esz), 1, C, 1, stream()), "vptr_partial_reduce")
+    return outs
 
 
 def flush_wgrads(chunks=1, on_chunk=None):
