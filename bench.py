@@ -154,14 +154,14 @@ def gemm_roofline(trainer, past, fut, precision):
         nfn, prec, am, bm = key[:4]
         if am == 5:
             return "vptr_gemm_p16_kernel<%d, %d>" % (key[5], key[6])
-        if am == 6:
-            return "vptr_wgrad_p16_kernel<2>"
+        if am == 6:   # the end-of-backward launch into the gradient slab / the plain-store launches of token-range sub-problems
+            return "vptr_wgrad_p16_kernel<2, 1>" if (len(key) > 4 and key[4] == "grouped_split") else "vptr_wgrad_p16_kernel<2, 0>"
         if am == 3:
             return "vptr_conv_planes_kernel<true>"
         base = "vptr_gemm_grouped_kernel" if (len(key) > 4 and key[4] == "grouped") else ("vptr_gemm_kernel_p" if (len(key) > 5 and key[5] == "p") else "vptr_gemm_kernel")
         return "%s<%d, %d, %d, %d>" % (base, nfn, prec, am, bm)
     kname = kernel_name(dom[0])
-    fam = kname.split("<")[0] if "_p16_kernel" in kname else kname   # the PMC file keeps the P16 instantiations as one family
+    fam = kname.split("<")[0] if "vptr_gemm_p16_kernel" in kname else kname   # the PMC file keeps the nt P16 instantiations as one family
     peak = MFMA_PEAK_TFLOPS
     ach = fl / (ms * 1e-3) / 1e12
     # HBM-side bytes per launch of that kernel: PMC counters cannot be read in-process, so this is the committed rocprofv3

@@ -23,8 +23,7 @@ OUT = "gpurun_out/" + R
 def short(n): return n.split("(")[0].replace("void ", "")
 def fam(n):   # PMC tables: the instantiations of the P16 kernels as one family (bench.py looks the dominant kernel up by this name)
     s = short(n)
-    for base in ("vptr_gemm_p16_kernel", "vptr_wgrad_p16_kernel"):
-        if s.startswith(base): return base
+    if s.startswith("vptr_gemm_p16_kernel"): return "vptr_gemm_p16_kernel"   # (the two wgrad instantiations stay separate rows: slab launch / sub-problem launches)
     return s
 # ---- (1) kernel stats
 rows = list(csv.DictReader(open(OUT + "/stats/b_kernel_stats.csv")))

@@ -294,7 +294,9 @@ __device__ __forceinline__ bf16x8 p16_tr_frag(const unsigned char* st, const int
   return __builtin_bit_cast(bf16x8, c);
 }
 
-template <int NSTAGE>   // 2: two workgroups per CU; 3: one workgroup per CU with the DMA two K-steps ahead (experiment, VPTR_WGRAD_STAGES=3)
+// TAG only names the launch for the profiler: 0 = the end-of-backward launch into the gradient slab (atomic adds), 1 = plain-store launches
+// of token-range sub-problems (ops.convt_weight_grads) -- same code, separate rows in rocprofv3's kernel table
+template <int NSTAGE, int TAG = 0>   // 2: two workgroups per CU; 3: one workgroup per CU with the DMA two K-steps ahead (experiment, VPTR_WGRAD_STAGES=3)
 __global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
                                                                 const int count, const int xmode, const int tile_base) {
   constexpr int BN = 176;
@@ -594,6 +596,7 @@ int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* des
     const char* e = getenv("VPTR_WGRAD_STAGES");
     stages = (e && atoi(e) == 3) ? 3 : 2;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess) {
       vptr_set_error("vptr_gemm_grouped(p16): cannot reserve LDS");
       stages = -1;
@@ -606,6 +609,7 @@ int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* des
   for (int base = 0; base < total_tiles; base += per) {
     const int nt = total_tiles - base < per ? total_tiles - base : per;
     if (stages == 3) vptr_wgrad_p16_kernel<3><<<nt, GNT, 3 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode, base);
+    else if (!proto->atomic) vptr_wgrad_p16_kernel<2, 1><<<nt, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode, base);
     else vptr_wgrad_p16_kernel<2><<<nt, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode, base);
   }
   return 0;

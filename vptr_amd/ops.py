@@ -649,7 +649,7 @@ def _launch_wgrad_group(its, atomic=1):
         check(lib.vptr_gemm_grouped(ctypes.byref(descs[0]), ptr(raw), ptr(st), n, total, stream()), "vptr_gemm_grouped")
         if prof is not None:
             e1.record()
-            prof.append(((cols // 16, prec, 6 if p16 else 1, 4 if p16 else 1, "grouped"), flops, e0, e1))
+            prof.append(((cols // 16, prec, 6 if p16 else 1, 4 if p16 else 1, "grouped" if atomic else "grouped_split"), flops, e0, e1))
 
 
 def convt_weight_grads(layers, tokens_per_split=2560):
