@@ -368,6 +368,10 @@ int vptr_window_copy(const float* src, float* dst, int frames, int Hs, int Ws, i
  * as its own statistics + normalise passes, stage-1 training train_AutoEncoder.py:44-86). */
 int vptr_conv7_in_fwd(const float* x, const float* w, const float* scale, const float* shift, float* y, int B, int Cimg,
                       int H, int W, int Cout, vptr_stream_t stream);
+/* the same with the result as bf16 hi / lo planes [(B*H*W + 1)][2][64] (vptr_split_planes format; the caller keeps the last row
+ * zero): the A operand of the strided plane-operand convolution that follows in the frozen encoder.  Cimg == 1, Cout == 64. */
+int vptr_conv7_in_fwd_planes(const float* x, const float* w, const float* scale, const float* shift, void* planes, int B, int Cimg,
+                             int H, int W, int Cout, vptr_stream_t stream);
 /* last layer: ReflectionPad2d(3) + Conv7x7(Cin -> Cimg) + bias + Tanh(1)/Sigmoid(2); x NHWC -> y NCHW; w [Cimg,Cin,7,7] */
 int vptr_conv7_out_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cimg,
                        int out_act, vptr_stream_t stream);

@@ -98,6 +98,7 @@ SIGNATURES = {
     "vptr_dropout": [P, P, L, F, P, U, P],
     "vptr_rowscale": [P, P, P, I, I, I, I, P],
     "vptr_conv7_in_fwd": [P, P, P, P, P, I, I, I, I, I, P],
+    "vptr_conv7_in_fwd_planes": [P, P, P, P, P, I, I, I, I, I, P],
     "vptr_conv7_out_fwd": [P, P, P, P, I, I, I, I, I, I, P],
     "vptr_conv7_out_bwd_data": [P, P, P, P, I, I, I, I, I, I, P],
     "vptr_conv7_out_bwd_weight": [P, P, P, P, P, I, I, I, I, I, I, P],

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void conv7_in_fwd_kernel(const float* __restri
 // LDS-bound), every output pixel vector leaves as one 256-byte store.
 __global__ __launch_bounds__(256, 4) void conv7_in_fwd2_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            float* __restrict__ y, int B, int H, int W, int rows_per_wg) {
+                                                            float* __restrict__ y, int B, int H, int W, int rows_per_wg, int planes) {
   extern __shared__ __attribute__((aligned(16))) float c7_sx[];   // [rows + 6][GW]: tile column c = padded column (ix = c - 3)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bands = (H + rows_per_wg - 1) / rows_per_wg;
@@ -103,8 +103,19 @@ __global__ __launch_bounds__(256, 4) void conv7_in_fwd2_kernel(const float* __re
           for (int j = 0; j < 4; ++j) acc[j] += wr[ky][kx] * xw[j + kx];
         __builtin_amdgcn_sched_barrier(0);   // keep the 21 window reads from all being hoisted to the top (84 live registers)
       }
+      if (planes) {   // bf16 hi / lo planes X[pixel][c / 32][hi 32 | lo 32] for the plane-operand convolution that follows (same 256 bytes per pixel)
+        unsigned char* prow = reinterpret_cast<unsigned char*>(y) + (((int64_t)b * H + oy) * W + ox0) * 256 + (lane >> 5) * 128 + (lane & 31) * 2;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) yrow[(int64_t)(ox0 + j) * 64] = scale ? fmaxf(acc[j] * sc + sh, 0.f) : acc[j];
+        for (int j = 0; j < 4; ++j) {
+          uint32_t h, l;
+          vptr_split2(scale ? fmaxf(acc[j] * sc + sh, 0.f) : acc[j], 0.f, h, l);
+          *reinterpret_cast<uint16_t*>(prow + j * 256) = (uint16_t)h;
+          *reinterpret_cast<uint16_t*>(prow + j * 256 + 64) = (uint16_t)l;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yrow[(int64_t)(ox0 + j) * 64] = scale ? fmaxf(acc[j] * sc + sh, 0.f) : acc[j];
+      }
     }
   }
 }
@@ -115,7 +126,7 @@ extern "C" int vptr_conv7_in_fwd(const float* x, const float* w, const float* sc
   VPTR_CHECK(Cout == 64, "conv7_in_fwd: Cout must be 64 (ngf of the reference encoder), got %d", Cout);
   if (Cimg == 1 && W % 4 == 0 && W <= 1024) {
     const int rpw = 8, bands = (H + rpw - 1) / rpw;
-    conv7_in_fwd2_kernel<<<B * bands, 256, sizeof(float) * (rpw + 6) * (W + 8), (hipStream_t)stream>>>(x, w, scale, shift, y, B, H, W, rpw);
+    conv7_in_fwd2_kernel<<<B * bands, 256, sizeof(float) * (rpw + 6) * (W + 8), (hipStream_t)stream>>>(x, w, scale, shift, y, B, H, W, rpw, 0);
     VPTR_LAUNCH_CHECK();
     return 0;
   }
@@ -123,6 +134,20 @@ extern "C" int vptr_conv7_in_fwd(const float* x, const float* w, const float* sc
   VPTR_CHECK(lds <= 64 * 1024, "conv7_in_fwd: too many image channels");
   const int64_t npix = (int64_t)B * H * W;
   conv7_in_fwd_kernel<<<cdiv(npix, 64), 256, lds, (hipStream_t)stream>>>(x, w, scale, shift, y, B, Cimg, H, W);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
+// the same into the plane operand format of vptr_gemm(VPTR_A_CONV_PLANES): planes [(B*H*W + 1)][2][64] bf16 whose last (all-zero)
+// row the caller zeroed once; single-channel images only (the second-generation kernel)
+extern "C" int vptr_conv7_in_fwd_planes(const float* x, const float* w, const float* scale, const float* shift, void* planes, int B,
+                                        int Cimg, int H, int W, int Cout, vptr_stream_t stream) {
+  VPTR_CHECK(B > 0 && Cimg == 1 && H > 3 && W > 3 && W % 4 == 0 && W <= 1024 && Cout == 64 && planes,
+             "conv7_in_fwd_planes: single-channel images, Cout = 64, W %% 4 == 0");
+  VPTR_CHECK((reinterpret_cast<uintptr_t>(planes) & 127) == 0, "conv7_in_fwd_planes: the plane buffer must be 128-byte aligned");
+  const int rpw = 8, bands = (H + rpw - 1) / rpw;
+  conv7_in_fwd2_kernel<<<B * bands, 256, sizeof(float) * (rpw + 6) * (W + 8), (hipStream_t)stream>>>(x, w, scale, shift, reinterpret_cast<float*>(planes), B, H, W,
+                                                                                                   rpw, 1);
   VPTR_LAUNCH_CHECK();
   return 0;
 }

@@ -150,26 +150,67 @@ class ResnetEncoder(nn.Module):
             y = _bn_act(t, bns[1], h * w, ops.ACT_NONE, residual=y)                  # out = x + conv_block(x)
         return ops.tokens_to_nchw(y, B, cin, h, w, relu=True)                        # the trailing nn.ReLU()
 
+    def _block_plane_bufs(self, B, h, w, cin, device):
+        """the two persistent, zero-initialised plane buffers the ResnetBlock convolutions alternate between"""
+        key = (B * h * w, cin, device)
+        if getattr(self, "_plane_bufs", (None,))[0] != key:
+            shape = (B * h * w + 1, (cin + 31) // 32, 64)
+            self._plane_bufs = (key, torch.zeros(shape, device=device, dtype=torch.bfloat16),
+                                torch.zeros(shape, device=device, dtype=torch.bfloat16))
+        return self._plane_bufs[1], self._plane_bufs[2]
+
     def _forward_impl(self, x):
         B, Cimg, H, W = x.shape
         m = self.model
         x = x.contiguous().float()
         scale, shift = _bn_eval(m[2])
         ngf = m[1].weight.shape[0]
-        y = torch.empty((B * H * W, ngf), device=x.device, dtype=torch.float32)
-        check(lib.vptr_conv7_in_fwd(ptr(x), ptr(m[1].weight.contiguous()), ptr(scale.contiguous()), ptr(shift.contiguous()),
-                                    ptr(y), B, Cimg, H, W, ngf, stream()), "vptr_conv7_in_fwd")
-        h, w, cin = H, W, ngf
-        idx = 4
-        for _ in range(self.n_downsampling):
-            conv, bn = m[idx], m[idx + 1]
-            cout = conv.weight.shape[0]
-            oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
-            scale, shift = _bn_eval(bn)
-            y = ops.conv_nhwc(y, ops.conv_weight_as_gemm_b(conv.weight, False), B, h, w, cin, oh, ow, 3, 3, 2, 1, "zero", False,
-                              cout, colscale=scale, bias=shift, act=ops.ACT_RELU)
-            h, w, cin = oh, ow, cout
-            idx += 3
+        # frozen encoder (stage 2) on single-channel images: the whole down-sampling chain in plane form as well -- the 7x7 kernel writes
+        # its output as bf16 hi / lo planes, every strided 3x3 convolution reads planes and writes planes (persistent, zero-initialised
+        # buffers: pad channels and the all-zero row are never touched), the last one straight into the ResnetBlocks' first buffer
+        chain = (ops.config.weights_frozen and Cimg == 1 and W % 4 == 0 and ngf == 64 and os.environ.get("VPTR_ENC_PLANES", "1") != "0"
+                 and os.environ.get("VPTR_ENC_PLANES_HEAD", "1") != "0"
+                 and all(m[4 + 3 * i].weight.shape[1] % 32 == 0 and m[4 + 3 * i].weight.shape[0] % 4 == 0 for i in range(self.n_downsampling)))
+        y = None
+        chain_out = None
+        if chain:
+            geo = [(H, W, ngf)]
+            for i in range(self.n_downsampling):
+                hh, ww, _ = geo[-1]
+                geo.append(((hh + 2 - 3) // 2 + 1, (ww + 2 - 3) // 2 + 1, m[4 + 3 * i].weight.shape[0]))
+            key = ("head", B, H, W, x.device, tuple(geo))
+            if getattr(self, "_head_bufs", (None,))[0] != key:
+                self._head_bufs = (key, [torch.zeros((B * hh * ww + 1, (cc + 31) // 32, 64), device=x.device, dtype=torch.bfloat16)
+                                         for (hh, ww, cc) in geo[:-1]])
+            bufs = list(self._head_bufs[1]) + [self._block_plane_bufs(B, geo[-1][0], geo[-1][1], geo[-1][2], x.device)[0]]
+            check(lib.vptr_conv7_in_fwd_planes(ptr(x), ptr(m[1].weight.contiguous()), ptr(scale.contiguous()), ptr(shift.contiguous()),
+                                               ptr(bufs[0]), B, Cimg, H, W, ngf, stream()), "vptr_conv7_in_fwd_planes")
+            idx = 4
+            for i in range(self.n_downsampling):
+                conv, bn = m[idx], m[idx + 1]
+                (h, w, cin), (oh, ow, cout) = geo[i], geo[i + 1]
+                scale, shift = _bn_eval(bn)
+                last = i == self.n_downsampling - 1   # the ResnetBlocks' residual path needs the last layer as fp32 too
+                y = ops.conv_nhwc_planes(bufs[i], ops.conv_weight_as_planes(conv.weight), B, h, w, cin, oh, ow, 3, 3, 2, 1, "zero", cout,
+                                         colscale=scale, bias=shift, act=ops.ACT_RELU, planes_out=bufs[i + 1], fp32_out=last)
+                idx += 3
+            h, w, cin = geo[-1]
+            chain_out = bufs[-1]
+        else:
+            y = torch.empty((B * H * W, ngf), device=x.device, dtype=torch.float32)
+            check(lib.vptr_conv7_in_fwd(ptr(x), ptr(m[1].weight.contiguous()), ptr(scale.contiguous()), ptr(shift.contiguous()),
+                                        ptr(y), B, Cimg, H, W, ngf, stream()), "vptr_conv7_in_fwd")
+            h, w, cin = H, W, ngf
+            idx = 4
+            for _ in range(self.n_downsampling):
+                conv, bn = m[idx], m[idx + 1]
+                cout = conv.weight.shape[0]
+                oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+                scale, shift = _bn_eval(bn)
+                y = ops.conv_nhwc(y, ops.conv_weight_as_gemm_b(conv.weight, False), B, h, w, cin, oh, ow, 3, 3, 2, 1, "zero", False,
+                                  cout, colscale=scale, bias=shift, act=ops.ACT_RELU)
+                h, w, cin = oh, ow, cout
+                idx += 3
         pad_mode = self.padding_type
         # frozen encoder (stage 2): activations and weights of the 18 ResnetBlock convolutions as bf16 hi / lo planes, staged
         # by global_load_lds ("convert once"); anywhere else the register-staged fp32 path
@@ -183,13 +224,9 @@ class ResnetEncoder(nn.Module):
                 # two persistent, zero-initialised plane buffers: the convs write their result in plane form themselves
                 # (pad channels and the all-zero row are never touched), only the very first input needs a split pass
                 if bi == 0:
-                    key = (B * h * w, cin, y.device)
-                    if getattr(self, "_plane_bufs", (None,))[0] != key:
-                        shape = (B * h * w + 1, (cin + 31) // 32, 64)
-                        self._plane_bufs = (key, torch.zeros(shape, device=y.device, dtype=torch.bfloat16),
-                                            torch.zeros(shape, device=y.device, dtype=torch.bfloat16))
-                    pa, pb = self._plane_bufs[1], self._plane_bufs[2]
-                    ops.split_planes(y, out=pa)
+                    pa, pb = self._block_plane_bufs(B, h, w, cin, y.device)
+                    if chain_out is not pa:
+                        ops.split_planes(y, out=pa)
                 ops.conv_nhwc_planes(pa, ops.conv_weight_as_planes(convs[0].weight), B, h, w, cin, h, w, 3, 3, 1, 1, pad_mode, cin,
                                      colscale=s1, bias=b1, act=ops.ACT_RELU, planes_out=pb, fp32_out=False)
                 y = ops.conv_nhwc_planes(pb, ops.conv_weight_as_planes(convs[1].weight), B, h, w, cin, h, w, 3, 3, 1, 1, pad_mode, cin,
