@@ -81,6 +81,25 @@ def rand_input(shape, seed, lo=0.0, hi=1.0):
     return torch.from_numpy(rs.uniform(lo, hi, size=shape).astype(np.float32))
 
 
+_BAIR_MEAN, _BAIR_STD = (0.61749697, 0.6050092, 0.52180636), (2.1824553, 2.1553133, 1.9115673)
+
+
+def clip_input(shape, seed, norm):
+    """synthetic clip (N, T, C, H, W) in the value range the reference's data pipeline hands the model (utils/dataset.py:19-58):
+    "kth" = VidNormalize(0.6013795, 2.7570653) on [0, 1) frames, "raw" = MovingMNIST (VidToTensor only: un-normalised [0, 1)),
+    "bair" = the per-channel VidNormalize of the BAIR set (:47)"""
+    x = rand_input(shape, seed)
+    if norm == "kth":
+        return (x - 0.6013795) / 2.7570653
+    if norm == "bair":
+        m = torch.tensor(_BAIR_MEAN).view(1, 1, 3, 1, 1)
+        sd = torch.tensor(_BAIR_STD).view(1, 1, 3, 1, 1)
+        return (x - m) / sd
+    if norm != "raw":
+        raise ValueError(norm)
+    return x
+
+
 def rand_normal(shape, seed, scale=1.0):
     rs = np.random.RandomState(seed)
     return torch.from_numpy((scale * rs.standard_normal(size=shape)).astype(np.float32))

@@ -322,21 +322,25 @@ def losses_case(ref, name, seed):
                         nce=np.array(nce(F.normalize(gf, p=2.0, dim=2), F.normalize(pf, p=2.0, dim=2)).item()))
 
 
-def step_case(ref, name, cfg, feat, HW, N, seed, steps=2, sample=0):
-    """single_iter recipe of train_NAR.py:49-107 with the real reference modules, dropout 0, no GAN."""
+clip_input = fill.clip_input
+
+
+def step_case(ref, name, cfg, feat, HW, N, seed, steps=2, sample=0, out_layer="Tanh", norm="kth"):
+    """single_iter recipe of train_NAR.py:49-107 with the real reference modules, dropout 0, no GAN.  out_layer="Sigmoid" +
+    norm="raw" is the MovingMNIST configuration (Test_VPTR.ipynb cell 3; ResNetAutoEncoder.py:91-96; train_FAR.py:182)."""
     enc = ref.VPTREnc(1, feat_dim=feat, n_downsampling=3, padding_type="reflect").eval()
-    dec = ref.VPTRDec(1, feat_dim=feat, n_downsampling=3, out_layer="Tanh", padding_type="reflect").eval()
+    dec = ref.VPTRDec(1, feat_dim=feat, n_downsampling=3, out_layer=out_layer, padding_type="reflect").eval()
     T = build_nar(ref, cfg, seed + 20)
     fill.apply_fill(enc, seed)
     fill.apply_fill(dec, seed + 10)
     opt = torch.optim.AdamW(T.parameters(), lr=1e-4)
     mse, gdl = ref.MSELoss(), ref.GDL(alpha=1)
     nce = ref.BiPatchNCE(N, cfg["Tf"], cfg["H"], cfg["W"], 1.0)
-    st = O.NARStep(dict(enc.state_dict()), dict(dec.state_dict()), dict(T.state_dict()), cfg)
+    st = O.NARStep(dict(enc.state_dict()), dict(dec.state_dict()), dict(T.state_dict()), cfg, out_layer=out_layer)
     recs = []
     for s in range(steps):
-        past = (fill.rand_input((N, cfg["Tp"], 1, HW, HW), seed + 100 + s) - 0.6013795) / 2.7570653
-        fut = (fill.rand_input((N, cfg["Tf"], 1, HW, HW), seed + 200 + s) - 0.6013795) / 2.7570653
+        past = clip_input((N, cfg["Tp"], 1, HW, HW), seed + 100 + s, norm)
+        fut = clip_input((N, cfg["Tf"], 1, HW, HW), seed + 200 + s, norm)
         with torch.no_grad():
             pf, ff = enc(past), enc(fut)
         T.train()
@@ -361,7 +365,10 @@ def step_case(ref, name, cfg, feat, HW, N, seed, steps=2, sample=0):
     e = max(rel(st.P_T[k], v) for k, v in T.state_dict().items() if v.is_floating_point())
     print(f"[{name}] {steps} train steps: losses {recs}; post-step params oracle-vs-ref {e:.2e}")
     assert e < 1e-4
-    save = {"cfg": json.dumps(cfg), "meta": json.dumps(dict(feat=feat, HW=HW, N=N, seed=seed, steps=steps)),
+    meta = dict(feat=feat, HW=HW, N=N, seed=seed, steps=steps)
+    if out_layer != "Tanh" or norm != "kth":      # the round 1-3 fixtures keep their exact meta
+        meta.update(out_layer=out_layer, norm=norm)
+    save = {"cfg": json.dumps(cfg), "meta": json.dumps(meta),
             "records": json.dumps(recs), "T_template": json.dumps(template_of(T.state_dict())),
             "enc_template": json.dumps(template_of(enc.state_dict())),
             "dec_template": json.dumps(template_of(dec.state_dict()))}
@@ -446,20 +453,22 @@ def nar_gan_step_case(ref, name, cfg, feat, HW, N, seed, steps=2, lam_gan=0.001)
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
 
 
-def far_step_case(ref, name, cfg, feat, HW, N, seed, steps=2):
-    """single_iter recipe of train_FAR.py:48-101 with the real reference modules (VPTR_Disc = None), dropout 0."""
-    enc = ref.VPTREnc(1, feat_dim=feat, n_downsampling=3, padding_type="reflect").eval()
-    dec = ref.VPTRDec(1, feat_dim=feat, n_downsampling=3, out_layer="Sigmoid", padding_type="reflect").eval()
+def far_step_case(ref, name, cfg, feat, HW, N, seed, steps=2, cimg=1, padding_type="reflect", out_layer="Sigmoid", norm="raw", sample=0):
+    """single_iter recipe of train_FAR.py:48-101 with the real reference modules (VPTR_Disc = None), dropout 0.  cimg=3,
+    padding_type="zero", out_layer="Tanh", norm="bair" is the BAIR configuration (train_FAR_mp.py:289-300, utils/dataset.py:47-50)."""
+    enc = ref.VPTREnc(cimg, feat_dim=feat, n_downsampling=3, padding_type=padding_type).eval()
+    dec = ref.VPTRDec(cimg, feat_dim=feat, n_downsampling=3, out_layer=out_layer, padding_type=padding_type).eval()
     T = build_nar(ref, cfg, seed + 20, far=True)
     fill.apply_fill(enc, seed)
     fill.apply_fill(dec, seed + 10)
     opt = torch.optim.AdamW(T.parameters(), lr=1e-4)
     mse, gdl = ref.MSELoss(), ref.GDL(alpha=1)
-    st = O.FARStep(dict(enc.state_dict()), dict(dec.state_dict()), dict(T.state_dict()), cfg, out_layer="Sigmoid")
+    st = O.FARStep(dict(enc.state_dict()), dict(dec.state_dict()), dict(T.state_dict()), cfg, padding_type=padding_type,
+                   out_layer=out_layer)
     recs = []
     for s in range(steps):
-        past = fill.rand_input((N, cfg["Tp"], 1, HW, HW), seed + 100 + s)
-        fut = fill.rand_input((N, cfg["Tf"], 1, HW, HW), seed + 200 + s)
+        past = clip_input((N, cfg["Tp"], cimg, HW, HW), seed + 100 + s, norm)
+        fut = clip_input((N, cfg["Tf"], cimg, HW, HW), seed + 200 + s, norm)
         with torch.no_grad():
             gt_feats = enc(torch.cat([past, fut[:, 0:-1, ...]], dim=1))
         T.train()
@@ -480,30 +489,41 @@ def far_step_case(ref, name, cfg, feat, HW, N, seed, steps=2):
     e = max(rel(st.P_T[k], v) for k, v in T.state_dict().items() if v.is_floating_point())
     print(f"[{name}] {steps} FAR train steps: losses {recs}; post-step params oracle-vs-ref {e:.2e}")
     assert e < 1e-4
-    save = {"cfg": json.dumps(cfg), "meta": json.dumps(dict(feat=feat, HW=HW, N=N, seed=seed, steps=steps, out_layer="Sigmoid")),
-            "records": json.dumps(recs), "T_template": json.dumps(template_of(T.state_dict()))}
+    meta = dict(feat=feat, HW=HW, N=N, seed=seed, steps=steps, out_layer=out_layer)
+    if cimg != 1 or padding_type != "reflect" or norm != "raw":
+        meta.update(cimg=cimg, padding_type=padding_type, norm=norm)
+    save = {"cfg": json.dumps(cfg), "meta": json.dumps(meta), "records": json.dumps(recs)}
+    if not sample:
+        save["T_template"] = json.dumps(template_of(T.state_dict()))
     for k, v in T.state_dict().items():
         if v.is_floating_point() and k not in ("temporal_pos", "lw_pos", "Tlw_pos"):
-            save["post:" + k] = v.numpy()
+            if sample:
+                flat = v.flatten()
+                save["post:T:" + k] = flat[::max(1, flat.numel() // sample)].numpy()
+            else:
+                save["post:" + k] = v.numpy()
+    if sample:
+        save["sample"] = np.array(sample)
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **save)
 
 
-def ae_step_case(ref, name, cimg, feat, HW, N, T, seed, steps=2, lam_gan=0.01):
-    """single_iter recipe of train_AutoEncoder.py:44-78 with the real reference modules (train-mode BN, PatchGAN, Adam)."""
+def ae_step_case(ref, name, cimg, feat, HW, N, T, seed, steps=2, lam_gan=0.01, out_layer="Tanh", norm="kth"):
+    """single_iter recipe of train_AutoEncoder.py:44-78 with the real reference modules (train-mode BN, PatchGAN, Adam).
+    out_layer="Sigmoid" + norm="raw" = MovingMNIST (train_AutoEncoder.py:132 comment, utils/dataset.py:36-39)."""
     enc = ref.VPTREnc(cimg, feat_dim=feat, n_downsampling=3, padding_type="reflect")
-    dec = ref.VPTRDec(cimg, feat_dim=feat, n_downsampling=3, out_layer="Tanh", padding_type="reflect")
+    dec = ref.VPTRDec(cimg, feat_dim=feat, n_downsampling=3, out_layer=out_layer, padding_type="reflect")
     disc = ref.VPTRDisc(cimg, ndf=64, n_layers=3, norm_layer=torch.nn.BatchNorm2d)
     fill.apply_fill(enc, seed)
     fill.apply_fill(dec, seed + 10)
     fill.apply_fill(disc, seed + 20)
-    st = O.AEStep(dict(enc.state_dict()), dict(dec.state_dict()), dict(disc.state_dict()), lam_gan=lam_gan)
+    st = O.AEStep(dict(enc.state_dict()), dict(dec.state_dict()), dict(disc.state_dict()), lam_gan=lam_gan, out_layer=out_layer)
     opt_G = torch.optim.Adam(list(enc.parameters()) + list(dec.parameters()), lr=2e-4, betas=(0.5, 0.999))
     opt_D = torch.optim.Adam(disc.parameters(), lr=2e-4, betas=(0.5, 0.999))
     gan, mse, gdl = ref.GANLoss("vanilla", target_real_label=1.0, target_fake_label=0.0), ref.MSELoss(), ref.GDL(alpha=1)
     recs = []
     for s in range(steps):
-        past = (fill.rand_input((N, T, cimg, HW, HW), seed + 100 + s) - 0.6013795) / 2.7570653
-        fut = (fill.rand_input((N, T, cimg, HW, HW), seed + 200 + s) - 0.6013795) / 2.7570653
+        past = clip_input((N, T, cimg, HW, HW), seed + 100 + s, norm)
+        fut = clip_input((N, T, cimg, HW, HW), seed + 200 + s, norm)
         x = torch.cat([past, fut], dim=1)
         enc.train(); enc.zero_grad(); dec.train(); dec.zero_grad()
         rec = dec(enc(x))
@@ -533,8 +553,10 @@ def ae_step_case(ref, name, cimg, feat, HW, N, T, seed, steps=2, lam_gan=0.01):
             for P, mod in ((st.P_enc, enc), (st.P_dec, dec), (st.P_disc, disc))]
     print(f"[{name}] {steps} AE train steps: losses {recs}; post-step params oracle-vs-ref enc/dec/disc {errs}")
     assert max(errs) < 1e-4
-    save = {"meta": json.dumps(dict(cimg=cimg, feat=feat, HW=HW, N=N, T=T, seed=seed, steps=steps, lam_gan=lam_gan)),
-            "records": json.dumps(recs)}
+    meta = dict(cimg=cimg, feat=feat, HW=HW, N=N, T=T, seed=seed, steps=steps, lam_gan=lam_gan)
+    if out_layer != "Tanh" or norm != "kth":
+        meta.update(out_layer=out_layer, norm=norm)
+    save = {"meta": json.dumps(meta), "records": json.dumps(recs)}
     for tag, mod in (("enc", enc), ("dec", dec), ("disc", disc)):
         for k, v in mod.state_dict().items():
             if v.is_floating_point():  # strided sample of <= ~4096 elements per tensor keeps the fixture small (the disc has 2.8 M)
@@ -623,6 +645,17 @@ def main():
         ("ae_bair528_digest", lambda n: ae_digest_case(ref, n, 3, 528, 64, 1, 2, "zero", "Tanh", 23)),
         ("ae_kth128_digest", lambda n: ae_digest_case(ref, n, 1, 528, 128, 1, 2, "reflect", "Tanh", 24)),
         ("rollouts_tiny", lambda n: rollout_case(ref, n, 111)),
+        # ---- round 4: reference-recorded 2-step TRAIN-STEP records at the literal size of every BASELINE.json config -------------
+        # config 1: stage-1 auto-encoder + PatchGAN on MovingMNIST, feat 528, batch 4 x (10 + 10) frames, Sigmoid output, raw inputs
+        ("step_ae528_mnist_digest", lambda n: ae_step_case(ref, n, 1, 528, 64, 4, 10, 83, out_layer="Sigmoid", norm="raw")),
+        # config 2: MovingMNIST NAR 10 -> 10 (4 + 8 layers), Sigmoid decoder on un-normalised [0, 1) frames
+        ("step_mnist_digest", lambda n: step_case(ref, n, k64, 528, 64, 2, 103, steps=2, sample=1024, out_layer="Sigmoid", norm="raw")),
+        # config 4: BAIR FAR 2 -> 28 (T_in = 29, 12 layers, RPE), 3-channel frames, zero padding, Tanh, BAIR normalisation
+        ("step_bair29_digest", lambda n: far_step_case(ref, n, dict(far, Tf=28, Tin=29), 528, 64, 1, 104, steps=2, cimg=3,
+                                                        padding_type="zero", out_layer="Tanh", norm="bair", sample=1024)),
+        # config 5: KTH 128 x 128 10 -> 40, 16 x 16 feature maps, 8 x 8 windows (152.6 M parameters)
+        ("step_kth128_digest", lambda n: step_case(ref, n, dict(k64, Tf=40, H=16, W=16, window_size=8), 528, 128, 1, 105, steps=2,
+                                                    sample=1024)),
     ]
     only = sys.argv[1:]
     for name, fn in cases:

@@ -10,7 +10,7 @@ Parity pin: the reference has no tests or golden vectors of its own
 (SURVEY.md section 4).  This restatement is pinned against the *imported
 reference itself* (run in the build container, see `oracle/make_golden.py`)
 and against the fixtures under `tests/golden/` that the same script generated.
-`tests/test_oracle_golden.py` re-checks the pin on every CPU test run.
+`tests/test_cpu.py::test_oracle_*_golden` re-check the pin on every CPU test run.
 
 Every function cites the reference file:line it follows (paths relative to
 the reference repo root).  Dropout / DropPath are identity by default: the
@@ -20,7 +20,7 @@ trained configuration (dropout 0.1) the masks can be INJECTED: inside a
 `with dropout_masks({site: scale tensor})` scope every nn.Dropout / attention
 dropout / DropPath site of the reference multiplies by the given tensor
 (values 0 or 1/keep), which lets a test run this oracle with exactly the masks
-another implementation drew (tests/test_dropout_parity_gpu.py).
+another implementation drew (tests/test_03_dropout_parity_gpu.py).
 """
 import math
 

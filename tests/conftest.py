@@ -16,6 +16,11 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
+    # File order is the run order (the driver runs `pytest -m gpu -x`): test_0* = oracle / golden parity (ops, P16 GEMMs, models,
+    # dropout-exact, drop-in records), test_1* = optimizer-state interchange, test_2* = SELF-comparisons (graph vs eager, DP vs
+    # single, RCCL forced exchange), whose bounds are noise-derived (tools/selfcmp_spread.py).  A flaky self-comparison can then
+    # never hide a parity test again (round 3: 231 of 240 unreached).  The sort is stable, so the order inside a file is kept.
+    items.sort(key=lambda it: os.path.basename(str(it.fspath)))
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

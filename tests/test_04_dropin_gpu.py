@@ -1,0 +1,100 @@
+"""north_star: "train_NAR.py drops in unchanged".  The scripts do not use NARTrainer: they call the `model` package's modules,
+`zero_grad(set_to_none=True)`, the criterion classes, `loss.backward()`, `clip_grad_norm_` and `torch.optim.AdamW` themselves
+(train_NAR.py:49-107, 205).  `vptr_amd.train.script_style_nar_iter` is that recipe on this package's objects; here it runs against
+the reference's own 2-step records: the tiny model (full post-step parameters) and the full-size K64 model of bench.py."""
+import pytest
+import torch
+
+from helpers import build_transformer, jload, load, post_step_params_close, sampled_post_params_close
+from oracle import fill
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.mark.parametrize("fixture", ["step_tiny", "step_k64_digest"])
+def test_script_style_iteration_matches_reference_records(dev, fixture):
+    import vptr_amd.model as pkg
+    from vptr_amd import ops
+    from vptr_amd.train import script_style_nar_iter
+    ops.unregister_flat_slabs()      # no flat slab anywhere: plain nn.Parameters with stock .grad tensors
+    z = load(fixture)
+    cfg, meta = jload(z, "cfg"), jload(z, "meta")
+    enc = pkg.VPTREnc(1, meta["feat"], 3, "reflect")
+    dec = pkg.VPTRDec(1, meta["feat"], 3, "Tanh", "reflect")
+    T = build_transformer(pkg, cfg, False)
+    fill.apply_fill(enc, meta["seed"])
+    fill.apply_fill(dec, meta["seed"] + 10)
+    fill.apply_fill(T, meta["seed"] + 20)
+    enc, dec, T = enc.to(dev).eval(), dec.to(dev).eval(), T.to(dev)      # train_NAR.py:190-191: Enc / Dec in eval mode
+    opt = torch.optim.AdamW(T.parameters(), lr=1e-4)                     # :205
+    mse, gdl = pkg.MSELoss(), pkg.GDL(alpha=1)
+    bpnce = pkg.BiPatchNCE(meta["N"], cfg["Tf"], cfg["H"], cfg["W"], 1.0).to(dev)
+    for s, ref in enumerate(jload(z, "records")):
+        past = ((fill.rand_input((meta["N"], cfg["Tp"], 1, meta["HW"], meta["HW"]), meta["seed"] + 100 + s) - 0.6013795) / 2.7570653).to(dev)
+        fut = ((fill.rand_input((meta["N"], cfg["Tf"], 1, meta["HW"], meta["HW"]), meta["seed"] + 200 + s) - 0.6013795) / 2.7570653).to(dev)
+        out = script_style_nar_iter(enc, dec, T, opt, past, fut, mse, gdl, bpnce, lam_pc=0.1, max_grad_norm=1.0)
+        for k in ("T_total", "T_GDL", "T_MSE", "T_bpc"):
+            assert abs(float(out[k]) - ref[k]) < TOL * abs(ref[k]) + 1e-6, (s, k, float(out[k]), ref[k])
+        assert abs(float(out["grad_norm"]) - ref["grad_norm"]) < 2e-3 * ref["grad_norm"]
+    assert all(p.grad is not None and not ops.flat_grad_for(p) is not None for p in T.parameters())
+    if fixture == "step_tiny":
+        post_step_params_close(T.state_dict(), z)
+    else:
+        sampled_post_params_close({"T": T.state_dict()}, z, lr=1e-4, rel_tol=2e-4)
+
+
+def _tiny_nar(dev):
+    import vptr_amd.model as pkg
+    from vptr_amd import ops
+    ops.unregister_flat_slabs()
+    z = load("step_tiny")
+    cfg, meta = jload(z, "cfg"), jload(z, "meta")
+    T = build_transformer(pkg, dict(cfg, num_decoder_layers=2), False)      # two decoder layers: the shared encoder-memory accumulator is live
+    fill.apply_fill(T, meta["seed"] + 20)
+    T = T.to(dev).train()
+    x = fill.rand_normal((2, cfg["Tp"], cfg["C"], cfg["H"], cfg["W"]), 5).to(dev)
+    return T, x
+
+
+def test_autograd_grad_and_backward_inputs_do_not_touch_dot_grad(dev):
+    """drop-in autograd semantics: the grouped weight-gradient path writes into `.grad` only when the engine is
+    accumulating there.  `torch.autograd.grad(loss, params)` must RETURN every gradient and leave `.grad` alone; `backward(inputs=[p])`
+    must fill p.grad only -- both equal to what a plain `loss.backward()` accumulates."""
+    T, x = _tiny_nar(dev)
+    params = [p for p in T.parameters() if p.requires_grad]
+    T(x).square().mean().backward()
+    ref = [p.grad.detach().clone() for p in params]
+    for p in params:
+        p.grad = None
+    got = torch.autograd.grad(T(x).square().mean(), params, allow_unused=False)
+    assert all(p.grad is None for p in params), "autograd.grad wrote into .grad"
+    for g, r in zip(got, ref):
+        assert g is not None and float((g - r).norm()) <= 1e-4 * float(r.norm()) + 1e-7
+    # backward(inputs=...) on one Linear weight and one LayerNorm weight
+    names = dict(T.named_parameters())
+    pick = [n for n in names if n.endswith("linear1.weight")][:1] + [n for n in names if n.endswith("norm1.weight")][:1]
+    T(x).square().mean().backward(inputs=[names[n] for n in pick])
+    idx = {id(p): i for i, p in enumerate(params)}
+    for n, p in names.items():
+        if n in pick:
+            r = ref[idx[id(p)]]
+            assert p.grad is not None and float((p.grad - r).norm()) <= 1e-4 * float(r.norm()) + 1e-7, n
+        elif p.requires_grad:
+            assert p.grad is None, "backward(inputs=...) touched the .grad of %s" % n
+
+
+def test_retain_graph_second_backward_keeps_encoder_memory_gradient(dev):
+    """two backward passes over one retained graph: the shared key / value gradient accumulator of the decoder layers
+    (ops.KVGradAccum) counts its users per BACKWARD pass, so the second pass hands the encoder-memory gradient over again
+    (round 3: the count went negative and the gradient was silently dropped)"""
+    T, x = _tiny_nar(dev)
+    x.requires_grad_(True)
+    loss = T(x).square().mean()
+    loss.backward(retain_graph=True)
+    g1 = x.grad.detach().clone()
+    enc_w = next(p for n, p in T.named_parameters() if "encoder" in n and n.endswith("linear1.weight"))
+    w1 = enc_w.grad.detach().clone()
+    loss.backward()
+    assert float((x.grad - 2 * g1).norm()) <= 1e-4 * float(g1.norm()), "second backward lost part of the input gradient"
+    assert float((enc_w.grad - 2 * w1).norm()) <= 1e-4 * float(w1.norm()), "second backward lost the encoder's parameter gradients"

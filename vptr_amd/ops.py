@@ -769,17 +769,34 @@ def flat_grad_for(t):
     return None
 
 
+def _engine_accumulates_into(leaf):
+    """True when the running backward pass is one that ACCUMULATES into `leaf.grad` (`loss.backward()`, or `backward(inputs=[...
+    leaf ...])`), False under `torch.autograd.grad(...)` / `backward(inputs=<others>)`: there the engine captures or drops the
+    gradient, and writing `.grad` behind its back would hand the caller None and pollute `.grad`.  The engine is
+    asked through `torch._C._will_engine_execute_node` on the leaf's AccumulateGrad node: with no explicit inputs every node of the
+    graph executes (True); with inputs it answers for this node, and raises for a leaf that `autograd.grad` captures."""
+    with torch.enable_grad():
+        acc = leaf.view_as(leaf).grad_fn.next_functions[0][0]
+    try:
+        return bool(torch._C._will_engine_execute_node(acc))
+    except RuntimeError:
+        return False
+
+
 def _loose_grad_for(t):
     """Gradient destination for a parameter OUTSIDE any flat slab (the reference's scripts: plain nn.Parameters, torch.optim.AdamW,
     zero_grad(set_to_none=True)): a view into the `.grad` of the leaf parameter that `t` is (or is a contiguous view of -- a row
     block of in_proj_weight, a 1x1 conv weight seen as [N, K]), created zero-filled if it is None.  The weight gradient can then
     join the grouped end-of-backward launch exactly like a slab-backed one, instead of running as a launch of its own (12-60 tiles
     with a 10 240-token K loop on 256 CUs: 196 of those made the script-style step 2.7x slower than NARTrainer's).  Returns None
-    -- the caller then hands a fresh tensor to autograd -- outside a backward pass, in a torch.distributed job (DDP's reducer must
-    see gradients arrive through AccumulateGrad hooks) and for parameters with hooks."""
+    -- the caller then hands a fresh tensor to autograd -- outside a backward pass, under `torch.autograd.grad` / `backward(inputs=
+    ...)` without this parameter / `create_graph=True` (the engine is not accumulating into `.grad` there), in a torch.distributed job
+    (DDP's reducer must see gradients arrive through AccumulateGrad hooks) and for parameters with hooks."""
     if not (config.group_wgrads and config.group_loose_wgrads) or t is None or not t.is_contiguous():
         return None
     if torch._C._current_graph_task_id() < 0:
+        return None
+    if torch.is_grad_enabled():      # backward(create_graph=True): the gradient must stay a graph output, not an in-place sum
         return None
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         return None
@@ -787,6 +804,8 @@ def _loose_grad_for(t):
     if base is None or not base.is_leaf or not base.requires_grad or not base.is_contiguous() or base.dtype != torch.float32:
         return None
     if base._backward_hooks or getattr(base, "_post_accumulate_grad_hooks", None):
+        return None
+    if not _engine_accumulates_into(base):
         return None
     off = (t.data_ptr() - base.data_ptr()) // 4
     if off < 0 or off + t.numel() > base.numel():
@@ -1271,6 +1290,31 @@ class KVGradAccum:
 
     def __init__(self):
         self.uses, self.k, self.v = 0, None, None
+        self.left, self.task = 0, -1      # users still to come in the running backward pass; its graph-task id
+
+    def enter_backward(self):
+        """called by every user's backward; True for the first user of a backward pass.  Participation is counted per BACKWARD
+        pass (a second pass over a retained graph starts a fresh count), and a pass that ends with users missing -- a pruned
+        branch, a user that took another code path -- raises instead of silently dropping the memory's gradient."""
+        task = torch._C._current_graph_task_id()
+        if self.left == 0 or task != self.task:
+            if self.left != 0:
+                self.k = self.v = None
+                self.left = 0
+                raise RuntimeError("KVGradAccum: the previous backward pass ended with %d of %d users missing" % (self.left, self.uses))
+            self.left, self.task = self.uses, task
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self._check_done)
+            except RuntimeError:
+                pass
+            return True
+        return False
+
+    def _check_done(self):
+        if self.left != 0:
+            left, self.left, self.k, self.v = self.left, 0, None, None
+            raise RuntimeError("KVGradAccum: backward finished with %d of %d key / value users not visited: the gradient of the shared "
+                               "key / value source would be incomplete" % (left, self.uses))
 
 
 class _ProjAttnFn(torch.autograd.Function):
@@ -1386,6 +1430,7 @@ class _ProjAttnFn(torch.autograd.Function):
         def dgrad(g, WT, out, M, **kw):
             return gemm_raw(g, WT, out, M, K, N, am, bm, lda=lda, ldb=ldb, **kw)
         dxq = dxk = dxv = None
+        took_acc = False
         if same_qk and (same_v or merge_v):
             if need[0] or need[1] or need[2]:
                 dxq = dgrad(dq, Tq_, new(Mq), Mq, kseg_extra=[(dk, Tk_), (dv, Tv_)])
@@ -1396,13 +1441,15 @@ class _ProjAttnFn(torch.autograd.Function):
                 dxv = dgrad(dv, Tv_, new(Mk), Mk)
         elif need[0] and need[1] and need[2] and Mq == Mk and use and ctx.kv_acc is not None:
             acc = ctx.kv_acc     # shared key / value source: sum the gradients inside the GEMMs (see KVGradAccum)
+            took_acc = True
+            acc.enter_backward()
             first = acc.k is None
             if first:
                 acc.k, acc.v = new(Mk), new(Mk)
             dxq = new(Mq)
             dgrad(dq, Tq_, dxq, Mq, batch_extra=[(dk, Tk_, acc.k, None, 1.0), (dv, Tv_, acc.v, None, 1.0)], batch_accum=0 if first else 0b110)
-            acc.uses -= 1
-            if acc.uses == 0:
+            acc.left -= 1
+            if acc.left == 0:
                 dxk, dxv = acc.k, acc.v
                 acc.k = acc.v = None
         elif need[0] and need[1] and need[2] and Mq == Mk:
@@ -1418,6 +1465,16 @@ class _ProjAttnFn(torch.autograd.Function):
                 dxk = dgrad(dk, Tk_, new(Mk), Mk)
             elif need[2]:
                 dxv = dgrad(dv, Tv_, new(Mk), Mk)
+        if ctx.kv_acc is not None and not took_acc:
+            # a user of the shared source that could not take the accumulating branch still counts as visited; if it is the last one
+            # of this backward pass it hands the sums over next to its own gradients
+            acc = ctx.kv_acc
+            acc.enter_backward()
+            acc.left -= 1
+            if acc.left == 0 and acc.k is not None:
+                dxk = acc.k if dxk is None else dxk + acc.k
+                dxv = acc.v if dxv is None else dxv + acc.v
+                acc.k = acc.v = None
         return (dxq, dxk, dxv, dWq, dbq, dWk, dbk, dWv, dbv, dtable) + (None,) * 12
 
 
