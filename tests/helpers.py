@@ -20,6 +20,16 @@ def rel(a, b, floor=0.0):
     return float((a - b).norm() / (b.norm() + floor + 1e-300))
 
 
+def margin(name, value, bound):
+    """bookkeeping for the noise-derived bounds of the self-comparison tests: with VPTR_MARGIN_LOG=<file> every checked (value, bound)
+    pair is appended to the file, so a run over several boxes shows how far each assertion is from failing (profiles/r04_margins.log)"""
+    path = os.environ.get("VPTR_MARGIN_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps({"check": name, "value": value, "bound": bound, "ratio": (value / bound) if bound else None}) + "\n")
+    return value
+
+
 def jload(z, key):
     return json.loads(str(z[key]))
 
@@ -56,16 +66,19 @@ def post_step_params_close(state_dict, z, rel_tol=1e-4, lr=1e-4, max_flip_frac=0
         tot += d.numel()
     relerr = (num / den) ** 0.5
     assert relerr < rel_tol, relerr
-    assert bad <= max_flip_frac * tot, (bad, tot)
+    assert bad <= max_flip_frac * tot, (bad, tot, sorted(worst, reverse=True)[:12])
     return relerr
 
 
 def sampled_post_params_close(state_dicts, z, lr, rel_tol, max_flip_frac=0.03):
     """as post_step_params_close, for fixtures that keep a strided sample (<= ~4096 elements) of every tensor under
-    `post:<tag>:<name>`; state_dicts maps tag -> state_dict"""
+    `post:<tag>:<name>`; state_dicts maps tag -> state_dict.  BatchNorm running statistics are buffers, not optimizer-updated
+    parameters: they count in the rel-L2 figure but not among the "updates that differ by more than lr / 2" (a running variance of
+    O(1) that agrees to 1e-4 relative is inside the parity bar and outside lr / 2)."""
     num = den = 0.0
     bad = tot = 0
     per = int(z["sample"]) if "sample" in z.files else 4096
+    worst = []
     for k in z.files:
         if not k.startswith("post:"):
             continue
@@ -74,9 +87,13 @@ def sampled_post_params_close(state_dicts, z, lr, rel_tol, max_flip_frac=0.03):
         d = flat[::max(1, flat.numel() // per)] - torch.from_numpy(z[k]).double()
         num += float((d * d).sum())
         den += float((torch.from_numpy(z[k]).double() ** 2).sum())
-        bad += int((d.abs() > 0.5 * lr).sum())
+        if "running_" in name:
+            continue
+        nb = int((d.abs() > 0.5 * lr).sum())
+        bad += nb
         tot += d.numel()
+        worst.append((nb / d.numel(), nb, d.numel(), "%s:%s" % (tag, name)))
     relerr = (num / den) ** 0.5
     assert relerr < rel_tol, relerr
-    assert bad <= max_flip_frac * tot, (bad, tot)
+    assert bad <= max_flip_frac * tot, (bad, tot, sorted(worst, reverse=True)[:12])
     return relerr

@@ -12,7 +12,7 @@ nodes and the losses are plain kernels; both are tested here."""
 import pytest
 import torch
 
-from helpers import build_transformer, jload, load
+from helpers import build_transformer, jload, load, margin
 from oracle import fill
 
 pytestmark = pytest.mark.gpu
@@ -54,7 +54,10 @@ def test_graph_replays_match_eager_steps(dev, dropout):
     past, fut = _batch(meta, cfg, 0, dev)
     tr.capture(past, fut, warmup=2)
     assert "memset" not in tr.graph_nodes, tr.graph_nodes
-    ok, rep = tr.verify_graph(past, fut, steps=5, rtol=2e-3, traj_rtol=5e-2, param_rtol=1e-4)
+    ok, rep = tr.verify_graph(past, fut, steps=5, rtol=2e-3, traj_rtol=5e-2, param_rtol=3e-4)
+    margin("graph:tiny%g:lockstep" % dropout, rep["worst_term_rel_diff"], 2e-3)
+    margin("graph:tiny%g:param" % dropout, rep["param_rel_l2"], 3e-4)
+    margin("graph:tiny%g:trajectory" % dropout, rep["trajectory_worst_rel_diff"], 5e-2)
     assert ok, rep
     for k, v in rep["graph_last"].items():
         assert v == v and abs(v) < 1e6, ("graph replay produced a non-finite / absurd value", k, v)
@@ -76,7 +79,10 @@ def test_graph_k64_bench_config_droppath_on(dev):
     past, fut = bench.synth_batch(n, 0, dev)
     tr.capture(past, fut, warmup=2)
     assert "memset" not in tr.graph_nodes and tr.graph_nodes.get("kernel", 0) > 500, tr.graph_nodes
-    ok, rep = tr.verify_graph(past, fut, steps=10, rtol=2e-3)
+    ok, rep = tr.verify_graph(past, fut, steps=10, rtol=2e-3, traj_rtol=5e-2, param_rtol=3e-4)
+    margin("graph:k64:lockstep", rep["worst_term_rel_diff"], 2e-3)
+    margin("graph:k64:param", rep["param_rel_l2"], 3e-4)
+    margin("graph:k64:trajectory", rep["trajectory_worst_rel_diff"], 5e-2)
     assert ok, rep
     g = rep["graph_last"]
     assert 0.0 <= g["T_GDL"] <= 4.0 and 0.0 <= g["T_MSE"] <= 1.5 and 0.0 < g["T_bpc"] < 8.0 and g["grad_norm"] < 100.0, g

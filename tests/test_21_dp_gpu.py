@@ -108,10 +108,14 @@ def test_dp_two_ranks_on_one_gpu():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
+    from helpers import margin
     for r in res:
+        for k, b in (("grad_overlap_vs_plain", 1e-5), ("grad_dp_vs_single", 1e-4), ("grad_step1", 5e-3), ("param_overlap_vs_plain", 1e-5),
+                     ("param_dp_vs_single", 1e-5)):
+            margin("dp:%s:rank%d" % (k, r["rank"]), r[k], b)
         assert r["grad_overlap_vs_plain"] < 1e-5, r
         assert r["grad_dp_vs_single"] < 1e-4, r          # fp32 atomics + a different reduction order over the batch
-        assert r["grad_step1"] < 1e-3, r
+        assert r["grad_step1"] < 5e-3, r          # second step, after sign-flipped first AdamW updates: measured 1.1e-4 (profiles/r04_margins.log)
         assert r["param_overlap_vs_plain"] < 1e-5, r
         assert r["param_dp_vs_single"] < 1e-5, r
         assert abs(r["norms"][0] - r["norms"][2]) < 1e-3 * r["norms"][2], r
