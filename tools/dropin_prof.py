@@ -97,3 +97,16 @@ print("%-12s %10s %10s" % ("section", "device ms", "host ms"))
 for k in names:
     print("%-12s %10.2f %10.2f" % (k, dev_ms[k] / steps, host_ms[k] / steps))
 print("%-12s %10.2f %10.2f" % ("sum", sum(dev_ms.values()) / steps, sum(host_ms.values()) / steps))
+
+if os.environ.get("VPTR_HOST_PROFILE") == "1":       # where the HOST time goes (the iteration is launch-bound): cProfile over 5 iterations
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(5):
+        one(False)
+    torch.cuda.synchronize()
+    pr.disable()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(45)
+    st.sort_stats("cumulative").print_stats(60)

@@ -113,7 +113,7 @@ class ResnetEncoder(nn.Module):
 
     def forward(self, x):
         """x (B, Cimg, H, W) NCHW -> (B, out_dim, H/2^n, W/2^n)."""
-        with ops.frozen_weights(getattr(self, "_vptr_frozen", False)):
+        with ops.frozen_weights(ops.weights_cacheable(self)):
             return self._forward(x)
 
     def _forward(self, x):
@@ -168,7 +168,9 @@ class ResnetEncoder(nn.Module):
         # frozen encoder (stage 2) on single-channel images: the whole down-sampling chain in plane form as well -- the 7x7 kernel writes
         # its output as bf16 hi / lo planes, every strided 3x3 convolution reads planes and writes planes (persistent, zero-initialised
         # buffers: pad channels and the all-zero row are never touched), the last one straight into the ResnetBlocks' first buffer
-        chain = (ops.config.weights_frozen and Cimg == 1 and W % 4 == 0 and ngf == 64 and os.environ.get("VPTR_ENC_PLANES", "1") != "0"
+        # (n_downsampling >= 1: the loop below is what produces the fp32 residual `y` of the first ResnetBlock.  The persistent plane /
+        # head buffers are per-module scratch keyed on shape: one forward at a time per module, i.e. one stream -- as every caller here)
+        chain = (ops.config.weights_frozen and self.n_downsampling >= 1 and Cimg == 1 and W % 4 == 0 and ngf == 64 and os.environ.get("VPTR_ENC_PLANES", "1") != "0"
                  and os.environ.get("VPTR_ENC_PLANES_HEAD", "1") != "0"
                  and all(m[4 + 3 * i].weight.shape[1] % 32 == 0 and m[4 + 3 * i].weight.shape[0] % 4 == 0 for i in range(self.n_downsampling)))
         y = None
@@ -247,12 +249,12 @@ class _DecoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feat, dec, *params):
-        with ops.frozen_weights(getattr(dec, "_vptr_frozen", False)):
+        with ops.frozen_weights(ops.weights_cacheable(dec)):
             return _DecoderFn._forward(ctx, feat, dec, *params)
 
     @staticmethod
     def backward(ctx, dout):
-        with ops.frozen_weights(getattr(ctx.dec, "_vptr_frozen", False)):
+        with ops.frozen_weights(ops.weights_cacheable(ctx.dec)):
             return _DecoderFn._backward(ctx, dout)
 
     @staticmethod

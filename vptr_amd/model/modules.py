@@ -132,6 +132,7 @@ class VPTRFormerNAR(nn.Module):
     def forward(self, past_gt_feat):
         """past_gt_feat (N,Tp,C,H,W) -> predicted future features (N,Tf,C,H,W), post-ReLU."""
         ops.new_seed_scope(past_gt_feat.device)
+        ops.ensure_module_planes(self)
         pred, _ = self.transformer(past_gt_feat, self.lw_pos, self.temporal_pos, self.Tlw_pos, self.frame_queries,
                                    init_tgt=None)
         return pred
@@ -164,6 +165,7 @@ class VPTRFormerFAR(nn.Module):
 
     def forward(self, input_feats):
         ops.new_seed_scope(input_feats.device)
+        ops.ensure_module_planes(self)
         return self.transformer(input_feats, self.lw_pos, self.temporal_pos)
 
     def _reset_parameters(self):

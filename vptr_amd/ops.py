@@ -50,6 +50,7 @@ class _Config:
     fused_mlp = os.environ.get("VPTR_FUSED_MLP", "1") != "0"
     # LayerNorm((F,H,W)) statistics accumulated by the epilogue of the producing GEMM / depthwise convolution; 0 = separate pass (A/B)
     fused_frame_stats = os.environ.get("VPTR_FUSED_STATS", "1") != "0"
+    loose_grad_arena = os.environ.get("VPTR_GRAD_ARENA", "1") != "0"   # models without a trainer: `.grad` tensors are views of one buffer per model
 
 
 config = _Config()
@@ -303,6 +304,7 @@ class WeightPlanes:
         self.versions = [t[5]._version for t in self.index]
         self.dirty = False
 
+    grad_arena = None
     dirty = False   # set by invalidate_weight_planes(): a write torch's version counters cannot see (.data, slab writes, c10d collectives)
 
     def stale(self):
@@ -344,6 +346,47 @@ _WPLANE_CACHE_BYTES = 3 << 30
 def register_weight_planes(store):
     import weakref
     _wplane_stores.append(weakref.ref(store))
+
+
+def ensure_module_planes(module):
+    """One P16 weight store per MODEL for modules used without a trainer (the reference's scripts: plain nn.Parameters stepped by
+    torch.optim.AdamW): every Linear-shaped weight of `module` gets its planes from ONE vptr_weight_planes launch per optimizer step
+    (WeightPlanes.lookup rebuilds the whole store when a version counter moved) instead of one launch + two table uploads per weight
+    and forward (196 per K64 forward: ~15 ms of host time, tools/dropin_prof.py).  Called at the top of VPTRFormerNAR / FAR.forward;
+    a no-op when a trainer's store (FlatAdamW) already covers the module's weights or when the store is current."""
+    if not config.use_p16:
+        return
+    st = module.__dict__.get("_vptr_planes")
+    if st is not None and st.grad_arena is not None and torch.is_grad_enabled():
+        _arm_grad_arena(st.grad_arena)
+    first = next((p for p in module.parameters() if p.dim() == 2 and p.shape[0] % 16 == 0 and p.shape[1] % 16 == 0 and p.is_contiguous()), None)
+    if first is None or not first.is_cuda:
+        return
+    if st is not None:
+        if st.sentinel == (first.data_ptr(), first.shape):
+            return
+        module.__dict__["_vptr_planes"] = None      # the parameters moved (.to(), a flat slab took them over): rebuild or defer
+        if st.grad_arena is not None:
+            for k in [k for k, e in _grad_arenas.items() if e[1] is st.grad_arena]:
+                del _grad_arenas[k]
+        _wplane_stores[:] = [r for r in _wplane_stores if r() is not None and r() is not st]
+    for ref in _wplane_stores:
+        other = ref()
+        if other is not None and other.lookup(first.detach()) is not None:
+            return                                   # a trainer's store serves these weights
+    lin = linear_weights_of(module.parameters())
+    if not lin:
+        return
+    with torch.no_grad():
+        st = WeightPlanes(lin)
+    st.sentinel = (first.data_ptr(), first.shape)
+    module.__dict__["_vptr_planes"] = st             # not a registered buffer / submodule: never in state_dict
+    register_weight_planes(st)
+    st.grad_arena = None
+    if flat_grad_for(first.detach()) is None and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        st.grad_arena = _register_grad_arena(module)   # kept alive by the store; entries of dead parameters are replaced on re-registration
+        if st.grad_arena is not None and torch.is_grad_enabled():
+            _arm_grad_arena(st.grad_arena)
 
 
 def invalidate_weight_planes():
@@ -769,6 +812,54 @@ def flat_grad_for(t):
     return None
 
 
+# ---- gradient arena of a model used WITHOUT a trainer (the reference's scripts: zero_grad(set_to_none=True) every iteration) ----------
+# After set_to_none every parameter's first gradient of the next backward pass needs a zero-filled `.grad` to accumulate into: as
+# torch.zeros_like per parameter that is 664 allocations + 664 fill launches per K64 iteration (tools/dropin_prof.py).  A model that
+# ran ensure_module_planes() owns ONE flat fp32 buffer instead: a forward pass that finds every `.grad` None zero-fills it with one
+# launch, and in backward a parameter's `.grad` becomes a view of its (still zero) range -- contiguous, own shape: torch.optim and
+# clip_grad_norm_ see ordinary tensors.  A range is handed out once per fill; anything else (a `.grad` set to None by hand between two
+# backward passes, ...) falls back to a fresh zeros_like.  Difference to stock autograd: a `.grad` tensor somebody KEPT from the
+# previous iteration is overwritten by the next forward pass's fill (config.loose_grad_arena = False restores fresh tensors).
+_grad_arenas = {}     # id(param) -> (weakref(param), arena dict, offset)
+
+
+def _register_grad_arena(module):
+    import weakref
+    params = [p for p in module.parameters() if p.requires_grad and p.dtype == torch.float32 and p.is_contiguous()]
+    if not params or not config.loose_grad_arena:
+        return None
+    total = sum(p.numel() for p in params)
+    arena = {"buf": torch.empty(total, device=params[0].device, dtype=torch.float32), "clean": False, "handed": set(),
+             "params": [weakref.ref(p) for p in params]}
+    off = 0
+    for p in params:
+        _grad_arenas[id(p)] = (weakref.ref(p), arena, off)
+        off += p.numel()
+    return arena
+
+
+def _arm_grad_arena(arena):
+    """forward pass: with every gradient None (the iteration began with zero_grad(set_to_none=True)) the arena is zero-filled"""
+    for r in arena["params"]:
+        p = r()
+        if p is not None and p.grad is not None:
+            return
+    arena["buf"].zero_()
+    arena["handed"].clear()
+    arena["clean"] = True
+
+
+def _arena_grad_for(base):
+    ent = _grad_arenas.get(id(base))
+    if ent is None or ent[0]() is not base:
+        return torch.zeros_like(base)
+    arena = ent[1]
+    if not arena["clean"] or id(base) in arena["handed"] or arena["buf"].device != base.device:
+        return torch.zeros_like(base)
+    arena["handed"].add(id(base))
+    return arena["buf"][ent[2]:ent[2] + base.numel()].view(base.shape)
+
+
 def _engine_accumulates_into(leaf):
     """True when the running backward pass is one that ACCUMULATES into `leaf.grad` (`loss.backward()`, or `backward(inputs=[...
     leaf ...])`), False under `torch.autograd.grad(...)` / `backward(inputs=<others>)`: there the engine captures or drops the
@@ -811,7 +902,7 @@ def _loose_grad_for(t):
     if off < 0 or off + t.numel() > base.numel():
         return None
     if base.grad is None:
-        base.grad = torch.zeros_like(base)
+        base.grad = _arena_grad_for(base)
     elif not base.grad.is_contiguous() or base.grad.dtype != torch.float32:
         return None
     return base.grad.view(-1)[off:off + t.numel()].view(t.shape)
@@ -834,21 +925,24 @@ def _linear_param_grads(g, x, W, bias_ref, need_w, need_b, alpha=1.0, p16=False)
     bias_done = False
     if need_w:
         slab = grad_dest_for(W)          # accumulate straight into the flat gradient slab / the parameter's .grad
-        if slab is not None and config.group_wgrads:
-            bslab = grad_dest_for(bias_ref) if (bias_ref is not None and need_b) else None
+        want_b = bias_ref is not None and need_b
+        bslab = grad_dest_for(bias_ref) if want_b else None
+        # the bias gradient rides on the weight's launch: deferring needs an in-place destination for BOTH (a bias whose gradient must
+        # go back through autograd -- backward(inputs=[weight]) without it, a hooked bias -- has to be complete when this node returns)
+        if slab is not None and config.group_wgrads and (bslab is not None or not want_b or not (p16 or alpha != 1.0)):
             defer_wgrad(g, x, slab, N, K, M, db=bslab, alpha=alpha, p16=p16)   # grouped at the end of backward
             bias_done = bslab is not None
         elif p16:
-            # P16 operands outside a flat slab (tests, stand-alone modules): the token-major kernel as a group of one
+            # P16 operands without in-place destinations (torch.autograd.grad, stand-alone modules in a torch.distributed job, tests):
+            # the token-major kernel as a group of one, results handed to autograd
             dW = slab if slab is not None else torch.zeros((N, K), device=g.device, dtype=torch.float32)
-            if bias_ref is not None and need_b:
-                bs = flat_grad_for(bias_ref)
-                db = bs if bs is not None else torch.zeros((N,), device=g.device, dtype=torch.float32)
+            if want_b:
+                db = bslab if bslab is not None else torch.zeros((N,), device=g.device, dtype=torch.float32)
                 bias_done = True
             _launch_wgrad_group([(g, x, dW, N, K, M, 3, db, float(alpha), True)])
             if slab is not None:
                 dW = None
-            if db is not None and flat_grad_for(bias_ref) is not None:
+            if bslab is not None:
                 db = None
             return dW, db
         else:
@@ -1814,6 +1908,31 @@ def conv_weight_as_gemm_b(weight, transposed):
         B = pack()
     setattr(weight, attr, (key, B))
     return B
+
+
+def in_flat_slab(t):
+    """True when `t`'s storage lies inside a registered optimizer slab (FlatAdamW): such parameters are stepped by raw kernels that
+    bump no version counter"""
+    p = t.data_ptr()
+    for base, nbytes, pref, _ in _flat_slabs:
+        if base <= p < base + nbytes and pref() is not None:
+            return True
+    return False
+
+
+def weights_cacheable(module):
+    """May packed conv weights / eval-BN folds of `module` be cached under their tensors' version counters?  Yes when a trainer marked
+    the module `_vptr_frozen`; else -- the reference's scripts, which drive plain modules (train_NAR.py:190-191: Enc / Dec in eval mode,
+    never stepped) -- when the module is in eval mode and its parameters do not live in an optimizer slab: torch.optim, load_state_dict
+    and the c10d broadcasts all write through versioned in-place ops, so a stale entry cannot be hit.  (Writes through `.data` are
+    invisible to version counters: call ops.invalidate_weight_planes() / re-create the module after such a write.)"""
+    flag = getattr(module, "_vptr_frozen", None)
+    if flag is not None:
+        return bool(flag)
+    if module.training:
+        return False
+    p = next(module.parameters(), None)
+    return p is not None and p.is_cuda and not in_flat_slab(p)
 
 
 class frozen_weights:
