@@ -409,30 +409,42 @@ def main():
         args.batch = shard_batch(args.global_batch, rank, world)[1]
     ops.config.gemm_precision = args.precision
     enc, dec, T = build_models(dev, args.dropout)
-    if world > 1:  # identical replicas: broadcast rank 0's parameters and buffers (what the DDP constructor does)
-        for t in list(T.state_dict().values()) + list(enc.state_dict().values()) + list(dec.state_dict().values()):
-            torch.distributed.broadcast(t, 0)
+    if world > 1:  # identical replicas: broadcast rank 0's parameters and buffers (what the DDP constructor does), one message per dtype
+        from vptr_amd.parallel import broadcast_modules_flat
+        broadcast_modules_flat([T, enc, dec], 0, pg)
     trainer = NARTrainer(enc, dec, T, batch_size=args.batch, lr=1e-4, max_grad_norm=1.0, lam_pc=0.1, process_group=pg)
     past, fut = synth_batch(args.batch, rank, dev)
 
-    use_graph = bool(args.graph) and world == 1 and not args.force_exchange
-    graph_note = "eager (one-rank RCCL group, forced gradient exchange)" if args.force_exchange else "eager"
+    # one GPU: the whole step is one hipGraph.  Several ranks (or --force-exchange): forward + backward are one hipGraph, the part that
+    # talks to other ranks (grouped weight-gradient chunks, RCCL all-reduces, optimizer) stays eager -- no collective is captured
+    dp = world > 1 or args.force_exchange
+    use_graph = bool(args.graph)
+    graph_note = "eager"
     graph_check = None
     if use_graph:
         try:
-            trainer.capture(past, fut, warmup=2)
-            # the graph is only timed if it computes what the eager step computes: 3 eager steps vs 3 replays from the same state
-            # (loss terms, gradient norm, post-step parameters); the state is restored afterwards
+            if dp:
+                trainer.capture_front(past, fut, warmup=2)
+            else:
+                trainer.capture(past, fut, warmup=2)
+            # the graph is only timed if it computes what the eager step computes: replay i vs an eager step from the same state, and a
+            # run of replays vs the eager trajectory (loss terms, gradient norm, post-step parameters); the state is restored afterwards
             ok, graph_check = trainer.verify_graph(past, fut, steps=3, rtol=2e-3)
             graph_check["nodes"] = trainer.graph_nodes
+            if world > 1:   # every rank takes the same branch
+                flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                ok = bool(flag.item() > 0.5)
             if ok:
-                graph_note = "hipGraph"
+                graph_note = "hipGraph (forward + backward) + eager exchange / optimizer" if dp else "hipGraph"
             else:
-                trainer._graph = None
+                trainer._graph = trainer._front = None
                 graph_note = "eager (hipGraph replays disagree with eager steps: %s)" % (graph_check.get("worst_term"),)
         except Exception as e:  # noqa: keep the bench alive, report eager numbers
-            trainer._graph = None
+            trainer._graph = trainer._front = None
             graph_note = "eager (graph capture failed: %s)" % str(e).split("\n")[0][:160]
+    if args.force_exchange:
+        graph_note += " [one-rank RCCL group, forced gradient exchange]"
 
     def sync():
         torch.cuda.synchronize()
@@ -477,7 +489,7 @@ def main():
         }
         if not args.no_roofline:
             try:
-                trainer._graph = None  # instrumented eager pass
+                trainer._graph = trainer._front = None  # instrumented eager pass
                 trainer.world = 1      # rank 0 alone runs it: no collective may be issued (the other ranks are at the final barrier)
                 trainer.pg = None
                 trainer._bufsync = None   # ... including the per-forward BatchNorm-buffer broadcast

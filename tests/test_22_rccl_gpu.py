@@ -99,6 +99,21 @@ def _worker(port, q):
 
         o_ov, f_ov = run_k64("overlap")
         o_no, f_no = run_k64("none")
+        # the data-parallel launch mode of bench.py: forward + backward as ONE hipGraph (no collective captured), the exchange eager
+        # (NARTrainer.capture_front); verify_graph compares replays with eager steps from the same state, both through the exchange path
+        os.environ["VPTR_DP_FORCE_EXCHANGE"], os.environ["VPTR_DP_OVERLAP"] = "1", "1"
+        ops.unregister_flat_slabs()
+        ops.manual_seed(dev, 5)
+        enc, dec, T = bench.build_models(dev, 0.1)
+        tr = NARTrainer(enc, dec, T, batch_size=2, lr=1e-4, max_grad_norm=1.0, lam_pc=0.1, process_group=dist.group.WORLD)
+        past, fut = bench.synth_batch(2, 0, dev)
+        tr.capture_front(past, fut, warmup=2)
+        ok, rep = tr.verify_graph(past, fut, steps=3, rtol=2e-3)
+        res["front_ok"], res["front_lockstep"], res["front_param"], res["front_traj"] = ok, rep["worst_term_rel_diff"], rep["param_rel_l2"], rep["trajectory_worst_rel_diff"]
+        res["front_nodes"] = tr.graph_nodes
+        res["front_last"] = rep["graph_last"]
+        del tr
+        torch.cuda.empty_cache()
         res["k64_terms_rel"] = max(abs(a[k] - b[k]) / (abs(b[k]) + 1e-6) for a, b in zip(o_ov, o_no) for k in a)
         res["k64_param_rel"] = rel(f_ov, f_no)
         res["k64_last"] = o_ov[-1]
@@ -129,3 +144,7 @@ def test_rccl_world1_forced_exchange():
     # amplify atomic-order noise); measured 2.2e-4 / 5.5e-6 (profiles/r04_margins.log), bounds >= 18x that
     assert res["k64_terms_rel"] < 5e-3 and res["k64_param_rel"] < 1e-4, res
     assert 0.0 <= res["k64_last"]["T_GDL"] <= 4.0, res
+    for k, b in (("front_lockstep", 2e-3), ("front_param", 3e-4), ("front_traj", 5e-2)):
+        margin("rccl:" + k, res[k], b)
+    assert res["front_ok"] and "memset" not in res["front_nodes"] and res["front_nodes"].get("kernel", 0) > 500, res
+    assert 0.0 <= res["front_last"]["T_GDL"] <= 4.0 and res["front_last"]["grad_norm"] < 100.0, res

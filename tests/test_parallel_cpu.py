@@ -60,6 +60,18 @@ def _worker(rank, world, port, q):
     assert bool(bs)
     bs.sync()
     assert float(bn.running_mean[0]) == 1.0 and float(bn.running_var[-1]) == 10.0 and int(bn.num_batches_tracked) == 7
+    # the job-start broadcast of several modules as one message per dtype (bench.py's multi-rank start-up)
+    from vptr_amd.parallel import broadcast_modules_flat
+    torch.manual_seed(200 + rank)
+    m1 = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.BatchNorm1d(4))
+    m2 = torch.nn.Linear(4, 2)
+    with torch.no_grad():
+        m1[1].num_batches_tracked.fill_(3 + rank)
+    broadcast_modules_flat([m1, m2], 0, None)
+    flat_sd = torch.cat([v.double().reshape(-1) for m in (m1, m2) for v in m.state_dict().values()])
+    both = [torch.zeros_like(flat_sd) for _ in range(world)]
+    dist.all_gather(both, flat_sd)
+    assert torch.equal(both[0], both[1]) and int(m1[1].num_batches_tracked) == 3
     q.put((rank, sd, float((flat - expect).abs().max()), float((flat - full).abs().max())))
     dist.barrier()
     dist.destroy_process_group()

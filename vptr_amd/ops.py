@@ -469,6 +469,19 @@ def defer_wgrad(g, x, dW, N, K, M, db=None, alpha=1.0, p16=False):
         pass
 
 
+def take_wgrads():
+    """hand the recorded (not yet launched) weight gradients to the caller and clear the queue (NARTrainer.capture_front keeps the
+    records of the captured backward pass: their operands have static addresses in the graph's pool)"""
+    items = list(_wgrad_q)
+    del _wgrad_q[:]
+    return items
+
+
+def requeue_wgrads(items):
+    """put records obtained from take_wgrads() back (after a replay of the graph that produces their operands)"""
+    _wgrad_q.extend(items)
+
+
 def discard_wgrads():
     """drop recorded weight gradients that were never launched (a backward pass that raised); called by FlatAdamW.zero_grad"""
     del _wgrad_q[:]

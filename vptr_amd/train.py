@@ -241,6 +241,9 @@ class NARTrainer:
         self.bucket_elems = bucket_mb * (1 << 20) // 4
         self._graph = None
 
+    _front = None          # data-parallel front graph (capture_front)
+    _front_items = ()
+
     # -- optional adversarial branch (train_NAR.py:22-30,37-41,66-79; train_FAR.py:22-45,66-80): off in the reference scripts ----
     def _init_gan(self, disc, lam_gan, lr, gan_mode):
         self.disc, self.lam_gan = disc, lam_gan
@@ -298,6 +301,13 @@ class NARTrainer:
             ops.flush_wgrads()  # no-op: the grouped weight-gradient launch already ran at the end of backward
             self._allreduce_grads()
             return
+        with ops.hold_wgrads():
+            loss.backward()
+        self._exchange_held_wgrads()
+
+    def _exchange_held_wgrads(self):
+        """the recorded weight gradients as DP_CHUNKS grouped launches with the slab ranges they complete sent out in between (see
+        `_backward_and_exchange`); also the eager tail of a front-graph step (`capture_front`)"""
         grad = self.opt.grad
         base, n = grad.data_ptr(), grad.numel()
         works, sent = [], [0]
@@ -312,8 +322,6 @@ class NARTrainer:
                 off = end
             sent[0] = hi
 
-        with ops.hold_wgrads():
-            loss.backward()
         ops.flush_wgrads(chunks=DP_CHUNKS, on_chunk=send_upto)
         if sent[0] < n:
             send_upto(None)
@@ -330,7 +338,7 @@ class NARTrainer:
         l_pc = ops.nce_loss(b.reshape(-1, C), a.reshape(-1, C), N * T, h * w, self.nce_temperature)
         return l_gdl + l_mse + self.lam_pc * l_pc, l_gdl, l_mse, l_pc
 
-    def _step_impl(self, past, future):
+    def _step_impl(self, past, future, front=False):
         with torch.no_grad():
             # train_NAR.py:54-56 encodes past and future in two calls; the encoder is per-frame (eval-mode BN), so one call on
             # the concatenated clip gives the same features with twice the rows per conv GEMM (480 instead of 240 tiles)
@@ -344,7 +352,7 @@ class NARTrainer:
         self.opt.zero_grad()
         if self.dec_weight_grads:
             self.dec.zero_grad(set_to_none=True)  # train_NAR.py:61
-        if self._bufsync:
+        if self._bufsync and not front:      # a collective: the front-graph step issues it eagerly before the replay
             self._bufsync.sync()
         pred_feats = self.T(past_feats)
         pred_frames = self.dec(pred_feats)
@@ -356,12 +364,31 @@ class NARTrainer:
             extra["T_gan"] = self.gan(self.disc(pred_frames.flatten(0, 1)), True)
             loss = loss + self.lam_gan * extra["T_gan"]
             extra["T_gan"] = extra["T_gan"].detach()
-        self._backward_and_exchange(loss)
-        self.opt.step(grad_scale=self._grad_scale)
-        return dict({"T_total": loss.detach(), "T_GDL": l_gdl.detach(), "T_MSE": l_mse.detach(), "T_bpc": l_pc.detach(),
-                     "grad_norm": self.opt.grad_norm()}, **extra)
+        return self._finish(loss, dict({"T_total": loss.detach(), "T_GDL": l_gdl.detach(), "T_MSE": l_mse.detach(), "T_bpc": l_pc.detach()},
+                                       **extra), front)
 
     def step(self, past, future):
+        if self._front is not None:
+            # data-parallel step: forward + backward replayed as one hipGraph, then the part that talks to other ranks runs eagerly --
+            # DP_CHUNKS grouped weight-gradient launches on the recorded operands (static addresses in the graph's pool), the all-reduces
+            # between them, the optimizer (3 launches)
+            if self.opt.planes is not None and self.opt.planes.stale():
+                self.opt.planes.refresh()
+            self._static_past.copy_(past)
+            self._static_future.copy_(future)
+            if self._bufsync:
+                self._bufsync.sync()
+            self._front.replay()
+            ops.requeue_wgrads(self._front_items)
+            self._grad_scale = 1.0
+            if os.environ.get("VPTR_DP_OVERLAP", "1") == "0":
+                ops.flush_wgrads()
+                self._allreduce_grads()
+            else:
+                self._exchange_held_wgrads()
+            self.opt.step(grad_scale=self._grad_scale)
+            self._static_out["grad_norm"] = self.opt.grad_norm()
+            return self._static_out
         if self._graph is not None:
             # replays are stream-ordered like any other launch; tests/test_20_graph_gpu.py compares them with eager steps (the
             # round-1 corruption was a captured table upload reading a recycled pinned buffer: ops._to_device_async)
@@ -409,6 +436,57 @@ class NARTrainer:
         self._graph = g
         return g
 
+    def capture_front(self, past, future, warmup=3):
+        """Data-parallel twin of `capture`: everything of the step that involves no other rank -- encoder, forward, losses, backward
+        with the weight gradients only RECORDED (ops.hold_wgrads), the LayerNorm parameter-gradient reductions -- becomes one hipGraph;
+        `step` replays it and then runs the exchange eagerly (grouped weight-gradient chunks, RCCL all-reduces, optimizer): ~1000
+        launches per step leave the host's critical path, no collective is ever captured.  The recorded weight-gradient operands live
+        in the graph's private pool, so their addresses are the same at every replay."""
+        if self.disc is not None:
+            raise RuntimeError("capture_front: the adversarial branch all-reduces inside the step; run it eagerly")
+        if self.pg is None:
+            raise RuntimeError("capture_front is the data-parallel capture; use capture() without a process group")
+        self._static_past, self._static_future = past.clone(), future.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for i in range(max(warmup, 1)):
+                if i == max(warmup, 1) - 1:
+                    ops._upload_stats.update(count=0, max_bytes=0)
+                self._step_impl(self._static_past, self._static_future)
+        torch.cuda.current_stream().wait_stream(s)
+        ops.reserve_graph_staging(count=ops._upload_stats["count"] + 2, nbytes=max(1 << 16, 2 * ops._upload_stats["max_bytes"]))
+        g = torch.cuda.CUDAGraph(keep_graph=True)
+        with torch.cuda.graph(g):
+            self._static_out = self._front_impl(self._static_past, self._static_future)
+            self._front_items = ops.take_wgrads()
+        self.graph_nodes = graph_node_census(g)
+        bad = {k: v for k, v in self.graph_nodes.items() if k not in ("kernel", "memcpy", "empty")}
+        if bad:
+            g.reset()
+            raise RuntimeError("captured step holds node types that are not replay-safe on this HIP runtime: %s (all nodes: %s)"
+                               % (bad, self.graph_nodes))
+        g.instantiate()
+        self._front = g
+        return g
+
+    def _front_impl(self, past, future):
+        """`_step_impl` up to the end of the backward pass: weight gradients recorded but not launched, no collective, no optimizer"""
+        return self._step_impl(past, future, front=True)
+
+    def _finish(self, loss, terms, front):
+        """backward + exchange + optimizer (the whole step), or -- front=True, under capture_front -- backward only, with the weight
+        gradients held for the eager tail"""
+        if front:
+            with ops.hold_wgrads():
+                loss.backward()
+            ops.flush_partial_reduces()
+            return terms
+        self._backward_and_exchange(loss)
+        self.opt.step(grad_scale=self._grad_scale)
+        terms["grad_norm"] = self.opt.grad_norm()
+        return terms
+
     # -- replay == eager, checked on the live model (bench.py runs this before it times a graph) -------------------------------------
     def _snapshot(self):
         dev = self.opt.flat.device
@@ -455,20 +533,21 @@ class NARTrainer:
             round-2 corruption began at the second replay).
           * trajectory (`traj_rtol`, loose, plus finiteness): `steps` back-to-back replays with no host read in between vs `steps`
             eager steps from the same initial state."""
-        if self._graph is None:
-            raise RuntimeError("verify_graph: capture() first")
+        if self._graph is None and self._front is None:
+            raise RuntimeError("verify_graph: capture() / capture_front() first")
         snap0 = self._snapshot()
-        g = self._graph
+        kind = "_graph" if self._graph is not None else "_front"
+        g = getattr(self, kind)
         worst, where, prel = 0.0, None, 0.0
         lock = []
         try:
             for i in range(steps):
                 pre = self._snapshot()
-                self._graph = g
+                setattr(self, kind, g)
                 rg = {k: float(v) for k, v in self.step(past, future).items()}
                 post_g = self._snapshot()
                 self._restore(pre)
-                self._graph = None
+                setattr(self, kind, None)
                 re_ = {k: float(v) for k, v in self.step(past, future).items()}
                 pe, pg = self.opt.flat.double(), post_g["flat"].double()
                 prel = max(prel, float((pe - pg).norm() / pe.norm()))
@@ -481,7 +560,7 @@ class NARTrainer:
             runs = {}
             for mode in ("eager", "graph"):
                 self._restore(snap0)
-                self._graph = g if mode == "graph" else None
+                setattr(self, kind, g if mode == "graph" else None)
                 outs = [self.step(past, future) for _ in range(steps)]           # no host read between the steps
                 torch.cuda.synchronize()
                 runs[mode] = [{k: float(v) for k, v in o.items()} for o in (outs if mode == "eager" else outs[-1:])]
@@ -491,7 +570,7 @@ class NARTrainer:
                 if d > tworst:
                     tworst, twhere = d, (steps - 1, k, a, runs["graph"][-1][k])
         finally:
-            self._graph = g
+            setattr(self, kind, g)
             self._restore(snap0)
         ok = worst <= rtol and prel <= param_rtol and tworst <= traj_rtol
         return ok, {"steps": steps, "worst_term_rel_diff": worst, "worst_term": where, "param_rel_l2": prel,
@@ -529,7 +608,7 @@ class FARTrainer(NARTrainer):
         self._bufsync = None   # the FAR transformer has no BatchNorm (LayerNorm conv-FFNs): nothing to broadcast per forward
         self._graph = None
 
-    def _step_impl(self, past, future):
+    def _step_impl(self, past, future, front=False):
         with torch.no_grad():
             gt_feats = self.enc(torch.cat([past, future[:, :-1]], dim=1))    # train_FAR.py:53-55
         if not self.T.training:   # nn.Module.train() walks ~500 sub-modules: ~5 ms of host time per step
@@ -548,10 +627,7 @@ class FARTrainer(NARTrainer):
             t_gan = self.gan(self.disc(pred_frames.flatten(0, 1)), True)
             loss = loss + self.lam_gan * t_gan
             extra["T_gan"] = t_gan.detach()
-        self._backward_and_exchange(loss)
-        self.opt.step(grad_scale=self._grad_scale)
-        return dict({"T_total": loss.detach(), "T_GDL": l_gdl.detach(), "T_MSE": l_mse.detach(), "grad_norm": self.opt.grad_norm()},
-                    **extra)
+        return self._finish(loss, dict({"T_total": loss.detach(), "T_GDL": l_gdl.detach(), "T_MSE": l_mse.detach()}, **extra), front)
 
     @torch.no_grad()
     def predict(self, past, num_pred):
