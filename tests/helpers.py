@@ -30,6 +30,26 @@ def margin(name, value, bound):
     return value
 
 
+def collect(q, procs, n, timeout=600):
+    """n results from the workers' queue; a worker that died (a c10d watchdog abort, a segfault) fails the test at once instead of
+    holding the GPU box until the queue timeout"""
+    import queue
+    import time
+    out, t0 = [], time.time()
+    while len(out) < n:
+        try:
+            out.append(q.get(timeout=5))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if not p.is_alive() and p.exitcode not in (0, None)]
+            if dead:
+                raise RuntimeError("worker process died with exit code(s) %s before reporting" % dead)
+            if all(not p.is_alive() for p in procs) and q.empty():
+                raise RuntimeError("workers exited without reporting")
+            if time.time() - t0 > timeout:
+                raise
+    return out
+
+
 def jload(z, key):
     return json.loads(str(z[key]))
 

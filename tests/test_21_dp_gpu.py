@@ -62,7 +62,7 @@ def _worker(rank, world, port, q):
             fut = fill.rand_input((G, cfg["Tf"], 1, meta["HW"], meta["HW"]), meta["seed"] + 200 + s).to(dev)
             return past, fut
 
-        def run(parallel, overlap):
+        def run(parallel, overlap, front=False):
             os.environ["VPTR_DP_OVERLAP"] = "1" if overlap else "0"
             ops.unregister_flat_slabs()
             enc, dec, T = make(rank if parallel else 0)
@@ -70,6 +70,11 @@ def _worker(rank, world, port, q):
                 broadcast_module(T, 0)
             tr = FARTrainer(enc, dec, T, lr=1e-4, max_grad_norm=1.0, process_group=dist.group.WORLD if parallel else None)
             off, per = shard_batch(G, rank, world) if parallel else (0, G)
+            if front:   # forward + backward as one hipGraph, exchange + optimizer eager (the multi-rank launch mode of bench.py)
+                snap = tr._snapshot()
+                p0, f0 = batch(0)
+                tr.capture_front(p0[off:off + per], f0[off:off + per], warmup=1)
+                tr._restore(snap)
             grads = []
             for s in range(2):
                 past, fut = batch(s)
@@ -80,6 +85,7 @@ def _worker(rank, world, port, q):
         g_ov, p_ov, n_ov = run(True, True)
         g_pl, p_pl, n_pl = run(True, False)
         g_1, p_1, n_1 = run(False, False)
+        g_fr, p_fr, n_fr = run(True, True, front=True)
 
         def rel(a, b):
             return float((a.double() - b.double()).norm() / b.double().norm())
@@ -90,6 +96,7 @@ def _worker(rank, world, port, q):
                "grad_dp_vs_single": rel(g_pl[0], g_1[0]),
                "grad_step1": max(rel(g_ov[1], g_pl[1]), rel(g_pl[1], g_1[1])),
                "param_overlap_vs_plain": rel(p_ov, p_pl), "param_dp_vs_single": rel(p_pl, p_1),
+               "grad_front_vs_plain": rel(g_fr[0], g_pl[0]), "param_front_vs_plain": rel(p_fr, p_pl),
                "norms": (n_ov, n_pl, n_1), "param_digest": float(p_ov.double().sum())}
         q.put(res)
         dist.barrier()
@@ -104,19 +111,21 @@ def test_dp_two_ranks_on_one_gpu():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r["rank"])
+    from helpers import collect
+    res = sorted(collect(q, procs, world, 600), key=lambda r: r["rank"])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
     from helpers import margin
     for r in res:
         for k, b in (("grad_overlap_vs_plain", 1e-5), ("grad_dp_vs_single", 1e-4), ("grad_step1", 5e-3), ("param_overlap_vs_plain", 1e-5),
-                     ("param_dp_vs_single", 1e-5)):
+                     ("param_dp_vs_single", 1e-5), ("grad_front_vs_plain", 1e-5), ("param_front_vs_plain", 1e-5)):
             margin("dp:%s:rank%d" % (k, r["rank"]), r[k], b)
         assert r["grad_overlap_vs_plain"] < 1e-5, r
         assert r["grad_dp_vs_single"] < 1e-4, r          # fp32 atomics + a different reduction order over the batch
         assert r["grad_step1"] < 5e-3, r          # second step, after sign-flipped first AdamW updates: measured 1.1e-4 (profiles/r04_margins.log)
         assert r["param_overlap_vs_plain"] < 1e-5, r
         assert r["param_dp_vs_single"] < 1e-5, r
+        assert r["grad_front_vs_plain"] < 1e-5 and r["param_front_vs_plain"] < 1e-5, r     # front-graph step == eager step
         assert abs(r["norms"][0] - r["norms"][2]) < 1e-3 * r["norms"][2], r
     assert res[0]["param_digest"] == res[1]["param_digest"], "replicas diverged"

@@ -130,7 +130,8 @@ def test_rccl_world1_forced_exchange():
     q = ctx.Queue()
     p = ctx.Process(target=_worker, args=(_free_port(), q))
     p.start()
-    res = q.get(timeout=900)
+    from helpers import collect
+    res = collect(q, [p], 1, 900)[0]
     p.join(120)
     assert "error" not in res, res["error"]
     from helpers import margin

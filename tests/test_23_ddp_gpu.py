@@ -135,7 +135,8 @@ def test_stock_ddp_wrapped_modules_two_ranks():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r["rank"])
+    from helpers import collect
+    res = sorted(collect(q, procs, world, 600), key=lambda r: r["rank"])
     for p in procs:
         p.join(120)
     for r in res:

@@ -456,8 +456,12 @@ class NARTrainer:
                 self._step_impl(self._static_past, self._static_future)
         torch.cuda.current_stream().wait_stream(s)
         ops.reserve_graph_staging(count=ops._upload_stats["count"] + 2, nbytes=max(1 << 16, 2 * ops._upload_stats["max_bytes"]))
+        # c10d's RCCL watchdog thread polls the events of earlier collectives (hipEventQuery): under the default GLOBAL capture mode
+        # that call, made while THIS thread captures, aborts the process ("operation not permitted when stream is capturing").  Drain
+        # the device first (no work left to poll) and capture in thread-local mode (other threads' calls stay legal).
+        torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph(keep_graph=True)
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._static_out = self._front_impl(self._static_past, self._static_future)
             self._front_items = ops.take_wgrads()
         self.graph_nodes = graph_node_census(g)
