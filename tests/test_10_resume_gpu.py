@@ -109,3 +109,34 @@ def test_two_optimizers_and_collection_keep_gradient_destinations(dev):
     assert ops.flat_grad_for(c[0]) is not None and ops.flat_grad_for(c[0]).data_ptr() == oc.grad.data_ptr()
     oc.close()
     ops.unregister_flat_slabs()
+
+
+def test_flat_adamw_grad_scale_equals_prescaled_gradients(dev):
+    """the data-parallel trainers all-reduce a SUM and fold the mean's 1 / world into the optimizer kernel (`FlatAdamW.step(grad_scale)`,
+    train.py `_exchange_held_wgrads`): step(grad_scale = s) on the summed gradients == step() on gradients multiplied by s beforehand --
+    parameters, Adam moments and the reported (clipped-against) gradient norm, with clipping active and inactive"""
+    from vptr_amd import ops
+    from vptr_amd.train import FlatAdamW
+    for max_norm, gmag in ((1.0, 3.0), (1.0, 1e-3), (None, 1.0)):      # clip engaged / not engaged / no clipping
+        ops.unregister_flat_slabs()
+        torch.manual_seed(11)
+        shapes = [(48, 32), (48,), (7, 5, 3), (1000,)]
+        pa = [torch.nn.Parameter(torch.randn(*s, device=dev)) for s in shapes]
+        pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+        oa = FlatAdamW(pa, lr=1e-3, max_grad_norm=max_norm)
+        ob = FlatAdamW(pb, lr=1e-3, max_grad_norm=max_norm)
+        world = 4
+        for it in range(3):
+            g = torch.randn_like(oa.grad) * gmag * world                 # "summed over 4 ranks"
+            oa.grad.copy_(g)
+            ob.grad.copy_(g * (1.0 / world))
+            oa.step(grad_scale=1.0 / world)
+            ob.step()
+            na, nb = float(oa.grad_norm()), float(ob.grad_norm())
+            assert abs(na - nb) <= 1e-5 * nb, (max_norm, gmag, it, na, nb)
+            assert abs(nb - float((g / world).double().norm())) <= 1e-4 * nb
+        for name in ("flat", "m", "v"):
+            a, b = getattr(oa, name).double(), getattr(ob, name).double()
+            assert float((a - b).norm()) <= 1e-6 * float(b.norm()) + 1e-12, (max_norm, gmag, name)
+        oa.close(); ob.close()
+    ops.unregister_flat_slabs()
