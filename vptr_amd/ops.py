@@ -776,7 +776,9 @@ def flush_wgrads(chunks=1, on_chunk=None):
             bounds.append(i + 1)
     bounds.append(len(items))
     for hi in bounds:
-        _launch_wgrad_group(items[lo:hi])
+        # the chunk boundaries follow slab addresses (what makes a gradient range final); INSIDE a chunk the single-launch order applies:
+        # largest problems first, problems that read the same X next to each other
+        _launch_wgrad_group(sorted(items[lo:hi], key=lambda it: (-it[3] * it[4], it[1].data_ptr(), it[2].data_ptr())))
         if on_chunk is not None:
             on_chunk(items[hi][2].data_ptr() if hi < len(items) else None)
         lo = hi
