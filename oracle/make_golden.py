@@ -645,6 +645,8 @@ def main():
         ("ae_bair528_digest", lambda n: ae_digest_case(ref, n, 3, 528, 64, 1, 2, "zero", "Tanh", 23)),
         ("ae_kth128_digest", lambda n: ae_digest_case(ref, n, 1, 528, 128, 1, 2, "reflect", "Tanh", 24)),
         ("rollouts_tiny", lambda n: rollout_case(ref, n, 111)),
+        # the bench workload at the bench's per-GPU batch: 16 clips = 10 240 tokens (the 240-tile and 960-tile GEMM grids, 160-frame statistics)
+        ("step_k64_n16_digest", lambda n: step_case(ref, n, k64, 528, 64, 16, 106, steps=2, sample=1024)),
         # ---- round 4: reference-recorded 2-step TRAIN-STEP records at the literal size of every BASELINE.json config -------------
         # config 1: stage-1 auto-encoder + PatchGAN on MovingMNIST, feat 528, batch 4 x (10 + 10) frames, Sigmoid output, raw inputs
         ("step_ae528_mnist_digest", lambda n: ae_step_case(ref, n, 1, 528, 64, 4, 10, 83, out_layer="Sigmoid", norm="raw")),
