@@ -4,7 +4,7 @@
 # MI355X_MICROARCH.md), (3) MFMA utilisation / wait / LDS counters of the top kernels (own passes, --kernel-trace only).
 # Writes gpurun_out/r02/*; copy the summaries into profiles/.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=${R:-r03}; export R
+R=${R:-r04}; export R
 OUT=gpurun_out/$R; rm -rf $OUT; mkdir -p $OUT
 BENCH="python bench.py --graph 0 --no-cpu-baseline --no-other-configs"   # eager launches: one traced kernel per launch
 SHORT="python bench.py --graph 0 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs"
@@ -48,7 +48,7 @@ try:
     rr = list(csv.DictReader(open(OUT + "/rccl/r_kernel_stats.csv")))
     with open(OUT + "/%s_rccl_world1_kernel_stats.md" % R, "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --force-exchange --steps 5 --warmup 2 ...  (ONE-rank RCCL group, the step through the\n")
-        f.write("# multi-rank code path: 4 chunked weight-gradient launches, async all-reduces of the 473.5 MB slab in <= 64 MB pieces; 7 steps traced)\n")
+        f.write("# multi-rank code path: forward + backward as one hipGraph (capture_front), then 4 chunked weight-gradient launches, async all-reduces of the\n# 473.5 MB slab in <= 64 MB pieces, optimizer; the trace covers capture warm-up, verify_graph and the 7 bench steps)\n")
         f.write("# RCCL / c10d kernels in the trace: %s\n\n" % ([short(r["Name"])[:60] for r in rr if ("nccl" in r["Name"].lower() or "rccl" in r["Name"].lower()) and "rocclr" not in r["Name"].lower()] or "none (in-place all-reduce on one rank launches no kernel)"))
         f.write("| kernel | calls | total ms | avg us |\n|---|---|---|---|\n")
         for r in rr[:25]:
