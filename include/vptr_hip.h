@@ -27,8 +27,17 @@ extern "C" {
 
 typedef void* vptr_stream_t; /* hipStream_t */
 
-int vptr_abi_version(void);
+int vptr_abi_version(void); /* 8 */
 const char* vptr_last_error(void);
+
+/* Run-to-run reproducibility (ABI 8).  The reference (cuDNN / cuBLAS defaults, train_NAR.py) is not bit-deterministic and neither is the
+ * default path here: several backward kernels let workgroups meet in fp32 atomics.  vptr_set_deterministic(1) makes every LAUNCHER that
+ * does so pick a geometry with ONE adder per destination (BatchNorm-type norm-act column sums, depthwise-conv weight gradients, row-table
+ * sums, column sums); callers use vptr_sumsq_ws instead of vptr_sumsq and leave vptr_gemm_desc.frame_stats / vptr_dwconv3x3_fwd(frame_stats)
+ * NULL.  With that, the stage-2 train step (NAR / FAR transformers; <= 16-token attention problems) is bit-reproducible on one device --
+ * tests/test_11_deterministic_gpu.py.  Host-side switch, read when a launch is enqueued; returns the previous value. */
+int vptr_set_deterministic(int on);
+int vptr_get_deterministic(void);
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM + fused epilogue on MFMA (bf16 inputs split from fp32 in the staging path, fp32 accumulate).
@@ -445,6 +454,8 @@ int vptr_droppath_scales(const float* keep, float* out, int nreq, int maxcount, 
  * ---------------------------------------------------------------------------------------------- */
 /* sumsq_dev[0] += sum(g^2) */
 int vptr_sumsq(const float* g, int64_t n, float* sumsq_dev, vptr_stream_t stream);
+/* sumsq_dev[0] = sum(g^2) in a fixed order: nws workgroups leave partials in ws[nws] (caller-owned), one workgroup adds them by index */
+int vptr_sumsq_ws(const float* g, int64_t n, float* sumsq_dev, float* ws, int nws, vptr_stream_t stream);
 /* p,m,v updated in place. clip coefficient = min(1, max_norm / (sqrt(sumsq_dev[0]) + 1e-6)) if sumsq_dev != null.
  * step_dev: DEVICE pointer to the (float) step count already incremented for this step. grad_scale multiplies g first. */
 int vptr_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

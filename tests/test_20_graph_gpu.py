@@ -93,6 +93,33 @@ def test_graph_k64_bench_config_droppath_on(dev):
     torch.cuda.empty_cache()
 
 
+def test_graph_far_step(dev):
+    """`FARTrainer.capture`: the FAR step (causal temporal attention, LayerNorm conv-FFNs, no NCE branch) as one hipGraph -- tiny
+    model, lock-step + trajectory check as above"""
+    import vptr_amd.model as pkg
+    from vptr_amd import ops
+    from vptr_amd.train import FARTrainer
+    z = load("step_far_tiny")
+    cfg, meta = jload(z, "cfg"), jload(z, "meta")
+    ops.unregister_flat_slabs()
+    ops.manual_seed(dev, 4321)
+    enc = pkg.VPTREnc(1, meta["feat"], 3, "reflect")
+    dec = pkg.VPTRDec(1, meta["feat"], 3, meta["out_layer"], "reflect")
+    T = build_transformer(pkg, cfg, True, dropout=0.1)
+    fill.apply_fill(enc, meta["seed"]); fill.apply_fill(dec, meta["seed"] + 10); fill.apply_fill(T, meta["seed"] + 20)
+    tr = FARTrainer(enc.to(dev), dec.to(dev), T.to(dev), lr=1e-4, max_grad_norm=1.0)
+    past = fill.rand_input((meta["N"], cfg["Tp"], 1, meta["HW"], meta["HW"]), meta["seed"] + 100).to(dev)
+    fut = fill.rand_input((meta["N"], cfg["Tf"], 1, meta["HW"], meta["HW"]), meta["seed"] + 200).to(dev)
+    tr.capture(past, fut, warmup=2)
+    assert "memset" not in tr.graph_nodes, tr.graph_nodes
+    ok, rep = tr.verify_graph(past, fut, steps=4, rtol=5e-3, traj_rtol=5e-2, param_rtol=3e-4)
+    margin("graph:far_tiny:lockstep", rep["worst_term_rel_diff"], 5e-3)
+    margin("graph:far_tiny:trajectory", rep["trajectory_worst_rel_diff"], 5e-2)
+    assert ok, rep
+    del tr
+    ops.unregister_flat_slabs()
+
+
 def test_graph_census_sees_memset_nodes(dev):
     """the guard itself: a captured hipMemsetAsync shows up as a memset node in graph_node_census (capture() raises on those)"""
     import ctypes

@@ -117,6 +117,9 @@ SIGNATURES = {
     "vptr_nce_bwd": [P, P, P, P, P, P, I, I, I, F, P],
     "vptr_droppath_scales": [P, P, I, I, P, U, P],
     "vptr_sumsq": [P, L, P, P],
+    "vptr_sumsq_ws": [P, L, P, P, I, P],
+    "vptr_set_deterministic": [I],
+    "vptr_get_deterministic": [],
     "vptr_adamw": [P, P, P, P, L, F, F, F, F, F, P, P, F, F, P],
 }
 EXPORTS = sorted(list(SIGNATURES) + ["vptr_abi_version", "vptr_last_error"])
@@ -134,7 +137,7 @@ def _load():
         fn.restype = c_int
     lib.vptr_abi_version.restype = c_int
     lib.vptr_last_error.restype = ctypes.c_char_p
-    if lib.vptr_abi_version() != 7:
+    if lib.vptr_abi_version() != 8:
         raise ImportError("vptr_amd: ABI version mismatch in %s" % LIB_PATH)
     return lib
 

@@ -29,6 +29,10 @@ void vptr_set_error(const char* fmt, ...);
     }                                                                            \
   } while (0)
 
+// vptr_set_deterministic(1): launchers whose workgroups meet in fp32 atomics switch to geometries with ONE adder per destination (or to
+// fixed-order two-pass reductions), so results no longer depend on the order in which workgroups retire (api.hip)
+extern int g_vptr_deterministic;
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t hmin64(int64_t a, int64_t b) { return a < b ? a : b; }
 

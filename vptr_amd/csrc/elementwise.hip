@@ -254,6 +254,30 @@ extern "C" int vptr_sumsq(const float* g, int64_t n, float* sumsq_dev, vptr_stre
   return 0;
 }
 
+// Fixed-order variant: every block leaves its partial in a caller-owned workspace, one block adds the partials in index order
+// (run-to-run reproducible: no atomics; vptr_set_deterministic mode of FlatAdamW)
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ ws) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += g[i] * g[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ ws, int nws, float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nws; i += 256) s += ws[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) *out = s;
+}
+extern "C" int vptr_sumsq_ws(const float* g, int64_t n, float* sumsq_dev, float* ws, int nws, vptr_stream_t stream) {
+  VPTR_CHECK(n > 0 && sumsq_dev && ws && nws >= 1 && nws <= 65536, "sumsq_ws: bad arguments");
+  sumsq_partial_kernel<<<nws, 256, 0, (hipStream_t)stream>>>(g, n, ws);
+  sumsq_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(ws, nws, sumsq_dev);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
 // torch.optim.AdamW semantics (decoupled weight decay, bias correction), clip_grad_norm_ coefficient folded in.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,

@@ -265,6 +265,7 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_fused_kernel(const float* __re
 
 // rows of partial sums a deferred backward call writes (0: this geometry has no deferred variant)
 extern "C" int vptr_layernorm_bwd_partials(int rows, int C) {
+  if (g_vptr_deterministic) return (C % 4 == 0 && C <= 1024 && rows > 0) ? cdiv(rows, 32) : 0;   // every vectorised geometry: no atomics at all
   if (rows < 4096 || C % 4 != 0 || C <= 256 || C > 768) return 0;
   return cdiv(rows, 32);
 }
@@ -275,7 +276,9 @@ static int layernorm_bwd_impl(const float* dy, const float* dy2, const float* x,
   if (partials) {
     // deferred parameter gradients: no atomics, so more and shorter workgroups (32 rows each instead of 64) cost nothing
     VPTR_CHECK(dx && vptr_layernorm_bwd_partials(rows, C) > 0, "layernorm_bwd: no deferred variant for rows %d, C %d", rows, C);
-    ln_bwd_fused_kernel<3, 8><<<cdiv(rows, 32), 512, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, nullptr, nullptr, rows, C, 32, dx_add, partials);
+    if (C <= 256) ln_bwd_fused_kernel<1, 4><<<cdiv(rows, 32), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, nullptr, nullptr, rows, C, 32, dx_add, partials);
+    else if (C <= 768) ln_bwd_fused_kernel<3, 8><<<cdiv(rows, 32), 512, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, nullptr, nullptr, rows, C, 32, dx_add, partials);
+    else ln_bwd_fused_kernel<4, 4><<<cdiv(rows, 32), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, nullptr, nullptr, rows, C, 32, dx_add, partials);
     VPTR_LAUNCH_CHECK();
     return 0;
   }
@@ -283,18 +286,20 @@ static int layernorm_bwd_impl(const float* dy, const float* dy2, const float* x,
     // fewer, longer workgroups: the per-column atomics at the end contend across workgroups.  Big inputs: 8 waves x 8 rows each = 64 rows
     // per workgroup (half the atomics of 4 waves x 8 rows at the same number of waves in flight: -0.25 ms per step; 16 waves or fewer rows lose)
     const bool big = rows >= 4096;
-    const int rpb = big ? 64 : 4;
+    const bool det = g_vptr_deterministic != 0;   // callers without an in-place destination (no partial buffer): ONE workgroup, one adder per column
+    const int rpb = det ? rows : (big ? 64 : 4);
     const int nb = cdiv(rows, rpb);
-    if (C <= 256) ln_bwd_fused_kernel<1, 4><<<cdiv(rows, big ? 32 : 4), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, big ? 32 : 4, dx_add, nullptr);
+    const int rpb2 = det ? rows : (big ? 32 : 4);
+    if (C <= 256) ln_bwd_fused_kernel<1, 4><<<cdiv(rows, rpb2), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb2, dx_add, nullptr);
     else if (C <= 768 && big) ln_bwd_fused_kernel<3, 8><<<nb, 512, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb, dx_add, nullptr);
     else if (C <= 768) ln_bwd_fused_kernel<3, 4><<<nb, 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb, dx_add, nullptr);
-    else ln_bwd_fused_kernel<4, 4><<<cdiv(rows, big ? 32 : 4), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, big ? 32 : 4, dx_add, nullptr);
+    else ln_bwd_fused_kernel<4, 4><<<cdiv(rows, rpb2), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb2, dx_add, nullptr);
     VPTR_LAUNCH_CHECK();
     return 0;
   }
   if (dx) ln_bwd_dx_kernel<<<cdiv(rows, 4), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, rows, C, dx_add);
   if (dgamma && dbeta) {
-    const int rpb = 64;
+    const int rpb = g_vptr_deterministic ? rows : 64;
     dim3 grid(cdiv(C, 256), cdiv(rows, rpb));
     ln_bwd_param_kernel<<<grid, 256, 0, st>>>(dy, dy2, x, mean, rstd, dgamma, dbeta, rows, C, rpb);
   }
@@ -419,7 +424,7 @@ extern "C" int vptr_rowmod_sum(const float* src, float* out, int rows, int C, in
   VPTR_CHECK(rows > 0 && C > 0 && div >= 1 && mod >= 1, "rowmod_sum: bad arguments");
   const int period = div * mod;
   const int nper = (rows + period - 1) / period;
-  const int gpb = 8;
+  const int gpb = g_vptr_deterministic ? nper : 8;   // deterministic: one workgroup (one adder) per output element
   dim3 grid(cdiv(C, 256), mod, cdiv(nper, gpb));
   rowmod_sum_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, out, rows, C, div, mod, gpb);
   VPTR_LAUNCH_CHECK();
@@ -455,7 +460,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ s
 
 extern "C" int vptr_colsum(const float* src, float* out, int rows, int C, vptr_stream_t stream) {
   VPTR_CHECK(rows > 0 && C > 0, "colsum: empty input");
-  if (C % 4 == 0) {
+  if (g_vptr_deterministic) {   // one thread walks a whole column: one adder per destination
+    rowmod_sum_kernel<<<dim3(cdiv(C, 256), 1, 1), 256, 0, (hipStream_t)stream>>>(src, out, rows, C, rows, 1, 1);
+  } else if (C % 4 == 0) {
     colsum_kernel<<<dim3(cdiv(C / 4, 32), cdiv(rows, 256)), 256, 0, (hipStream_t)stream>>>(src, out, rows, C / 4);
   } else {  // odd widths: one output row of rowmod_sum, runs of 64 rows per block
     dim3 grid(cdiv(C, 256), 1, cdiv(rows, 64));
@@ -1059,7 +1066,7 @@ static int norm_act_bwd_impl(const float* dy, const float* x, const float* mean,
   const int blocks = (int)hmin64((total + 255) / 256, 8192);
   if (per_col) {
     zero_fill_kernel<<<cdiv(2 * F, 256), 256, 0, st>>>(scratch, 2 * F);  // a kernel node, not a memset node (see below)
-    const int rpb = 64;   // (32 rows per chunk for the narrow tensors: 33.7 -> 42.2 us -- twice the atomics)
+    const int rpb = g_vptr_deterministic ? rows : 64;   // (32 rows per chunk for the narrow tensors: 33.7 -> 42.2 us -- twice the atomics; deterministic: one adder per column)
     if (vec4)
       norm_act_bwd_col_reduce4<<<dim3(cdiv(F / 4, 64), cdiv(rows, rpb)), 256, 0, st>>>(dy, x, mean, rstd, w, b, scratch, rows, F / 4, act,
                                                                                       dropout_p, seed_dev, site, rpb, rowscale, rs_div, rs_mod);
@@ -1082,7 +1089,7 @@ static int norm_act_bwd_impl(const float* dy, const float* x, const float* mean,
     const int ysplit = partials ? vptr_norm_act_bwd_partials(rows, F, HW, 0) : 0;
     if (partials) VPTR_CHECK(ysplit > 0 && (reinterpret_cast<uintptr_t>(partials) & 15) == 0, "norm_act_bwd: no deferred variant for this geometry");
     // deferred: no atomics, so the frames are cut into more chunks (more waves in flight, 2 - 5 frames per wave instead of 10)
-    const int fpb = partials ? (frames + ysplit - 1) / ysplit : (frames >= 64 ? (frames + 3) / 4 : frames);
+    const int fpb = partials ? (frames + ysplit - 1) / ysplit : ((frames >= 64 && !g_vptr_deterministic) ? (frames + 3) / 4 : frames);   // no partial buffer + deterministic: one adder per element
     if (partials) VPTR_CHECK(cdiv(frames, fpb) == ysplit, "norm_act_bwd: frames %d do not split into %d chunks", frames, ysplit);   // (holds by construction)
     const int nparts = cdiv(E4, 64);  // scratch: [2*frames] sums followed by [nparts, frames, 2] per-wave partials
     float* part = scratch + 2 * frames;
@@ -1322,7 +1329,7 @@ extern "C" int vptr_dwconv3x3_bwd(const float* dy, const float* x, const float* 
       dwconv_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(dy, w9, nullptr, dx, frames, H, W, F / 4, 1);
   }
   if (dw9 && db) {
-    const int fpb = frames >= 64 ? 8 : 1;
+    const int fpb = g_vptr_deterministic ? frames : (frames >= 64 ? 8 : 1);   // deterministic: one adder per tap and channel
     if (W % 2 == 0)
       dwconv_bwd_w_kernel<true><<<dim3(cdiv(F / 4, DWB_C4), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
     else

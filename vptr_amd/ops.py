@@ -51,9 +51,32 @@ class _Config:
     # LayerNorm((F,H,W)) statistics accumulated by the epilogue of the producing GEMM / depthwise convolution; 0 = separate pass (A/B)
     fused_frame_stats = os.environ.get("VPTR_FUSED_STATS", "1") != "0"
     loose_grad_arena = os.environ.get("VPTR_GRAD_ARENA", "1") != "0"   # models without a trainer: `.grad` tensors are views of one buffer per model
+    deterministic = False   # ops.set_deterministic / VPTR_DETERMINISTIC=1
 
 
 config = _Config()
+
+
+def set_deterministic(on=True):
+    """Run-to-run reproducibility of the stage-2 train step (NAR / FAR transformers with <= 16-token attention problems -- every K64
+    / BAIR-64 attention -- on one device): the launchers of the library stop letting workgroups meet in fp32 atomics
+    (vptr_set_deterministic: one adder per destination for the BatchNorm-type norm-act column sums, the depthwise-convolution weight
+    gradients, row-table and column sums), the conv-FFN frame statistics go back to their own fixed-order pass, and `FlatAdamW` takes
+    the gradient norm through a fixed-order two-pass sum.  The default path keeps the atomics (they are faster; the reference's
+    cuDNN / cuBLAS path is not bit-deterministic either).  Slower: the single-adder geometries serialise ~40 small reductions per step.
+    Also: VPTR_DETERMINISTIC=1 in the environment.  tests/test_11_deterministic_gpu.py runs steps twice and compares bit for bit."""
+    on = bool(on)
+    if on and not config.deterministic:
+        config._fused_before = config.fused_frame_stats
+        config.fused_frame_stats = False
+    elif not on and config.deterministic:
+        config.fused_frame_stats = getattr(config, "_fused_before", True)
+    config.deterministic = on
+    lib.vptr_set_deterministic(int(on))
+
+
+if os.environ.get("VPTR_DETERMINISTIC") == "1":
+    set_deterministic(True)
 
 
 def _direct_apply(fn_cls):

@@ -177,13 +177,19 @@ class FlatAdamW:
         return self.sumsq.sqrt() * self._last_scale
 
     _last_scale = 1.0
+    _sumsq_ws = None
 
     def step(self, grad_scale=1.0):
         """grad_scale multiplies every gradient before clipping (e.g. 1 / accumulation steps)"""
         n = self.flat.numel()
         self._last_scale = float(grad_scale)
-        self.sumsq.zero_()
-        check(lib.vptr_sumsq(ptr(self.grad), n, ptr(self.sumsq), stream()), "vptr_sumsq")
+        if ops.config.deterministic:   # fixed-order two-pass sum (no atomics): the clip coefficient is reproducible bit for bit
+            if self._sumsq_ws is None:
+                self._sumsq_ws = torch.empty(1024, device=self.flat.device, dtype=torch.float32)
+            check(lib.vptr_sumsq_ws(ptr(self.grad), n, ptr(self.sumsq), ptr(self._sumsq_ws), self._sumsq_ws.numel(), stream()), "vptr_sumsq_ws")
+        else:
+            self.sumsq.zero_()
+            check(lib.vptr_sumsq(ptr(self.grad), n, ptr(self.sumsq), stream()), "vptr_sumsq")
         self.step_dev.add_(1.0)
         check(lib.vptr_adamw(ptr(self.flat), ptr(self.grad), ptr(self.m), ptr(self.v), n, self.lr, self.betas[0], self.betas[1],
                              self.eps, self.weight_decay, ptr(self.step_dev),
