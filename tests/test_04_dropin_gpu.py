@@ -115,7 +115,7 @@ def test_script_mode_state_is_released_with_the_model(dev):
         opt.step()
     st = T.__dict__.get("_vptr_planes")
     assert st is not None and st.grad_arena is not None, "the script-mode store / arena was not created"
-    p0 = next(p for p in T.parameters() if p.grad is not None and p.dim() == 2)
+    p0 = next(p for n, p in T.named_parameters() if n.endswith("linear1.weight"))       # a Linear weight: gradient accumulated in place
     base, nbytes = st.grad_arena.buf.data_ptr(), st.grad_arena.buf.numel() * 4
     assert base <= p0.grad.data_ptr() < base + nbytes, ".grad is not a view of the model's arena"
     refs = (weakref.ref(st), weakref.ref(st.grad_arena))
