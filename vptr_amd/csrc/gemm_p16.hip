@@ -300,22 +300,25 @@ __device__ __forceinline__ bf16x8 p16_tr_frag(const unsigned char* st, const int
 
 // TAG only names the launch for the profiler: 0 = the end-of-backward launch into the gradient slab (atomic adds), 1 = plain-store launches
 // of token-range sub-problems (ops.convt_weight_grads) -- same code, separate rows in rocprofv3's kernel table
-template <int NSTAGE, int TAG = 0>   // 2: two workgroups per CU; 3: one workgroup per CU with the DMA two K-steps ahead (experiment, VPTR_WGRAD_STAGES=3)
-__global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
-                                                                const int count, const int xmode, const int tile_base) {
+// Panel-synchronous scheduling (VPTR_WGRAD_SYNC=S, default 16): the co-resident tiles of one XCD keep within 1.5 blocks of S K-steps of
+// each other, so that tiles which share an operand panel find it in the XCD's 4 MB L2 instead of re-fetching it over the fabric (default
+// launch: L2 hit rate 35 %, 38 - 48 GB per launch against 8.9 GB of distinct bytes).  A counting barrier in split phases on one 32-bit word
+// per XCD: a workgroup ARRIVES (fire-and-forget L2 atomic) when it has finished block b and WAITS half a block later until all n
+// participants have arrived for block b -- it cannot arrive for block b + 1 before that, so the cumulative count is exact.  Every wait is a
+// BOUNDED spin (a workgroup that times out once stops waiting for the rest of the launch but keeps arriving), so a participant that is
+// not resident costs time, never a hang.
+struct WgSync {
+  int* cnt;        // this XCD's arrival counter (cumulative over the launch; reset by the last workgroup of the XCD to leave)
+  int base;        // arrivals of all earlier rounds: round * slots * arrivals_per_tile
+  int n;           // participants of this round
+  int S;           // K-steps per block
+  bool live;       // false after a timeout
+};
+
+template <int NSTAGE, bool SYNC>
+__device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const int tile, unsigned char* p16_smem, WgSync& sy) {
   constexpr int BN = 176;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
-  const int lg = tile_base + ((xmode & 0xff) == 1 ? (int)blockIdx.x : xcd_logical_block());
-  if ((xmode & 0x100) && (threadIdx.x >> 6) >= 4) __builtin_amdgcn_s_setprio(1);   // experiment: see vptr_gemm_p16_kernel
-  int lo = 0, hi = count - 1;  // last g with tile_start[g] <= lg (workgroup-uniform scalar search)
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (tile_start[mid] <= lg) lo = mid;
-    else hi = mid - 1;
-  }
-  const vptr_gemm_desc& p = descs[lo];
   const int NG = p.M, KX = p.N, T = p.K;   // D[NG][KX] += alpha * G[T][NG]^T . X[T][KX]
-  const int tile = lg - tile_start[lo];
   const int tiles_n = (KX + BN - 1) / BN;
   const int m0 = (tile / tiles_n) * GBM, n0 = (tile % tiles_n) * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -387,6 +390,18 @@ __global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kerne
   issue(0, 0);
   if (NSTAGE == 3 && nk > 1) issue(1, 1);
   for (int kt = 0; kt < nk; ++kt) {
+    if (SYNC && kt > 0 && threadIdx.x == 0) {   // wave 0 reaches this step's barrier late if it has to wait: the other waves wait there
+      const int ph = kt % sy.S;
+      if (ph == 0) __hip_atomic_fetch_add(sy.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // finished block kt / S - 1
+      else if (ph == (sy.S >> 1) && kt > sy.S && sy.live) {
+        const int target = sy.base + (kt / sy.S) * sy.n;
+        int spins = 0;
+        while (__hip_atomic_load(sy.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          if (++spins > 3000) { sy.live = false; break; }   // ~1.5 ms: somebody is not resident -- go on unsynchronised
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
+    }
     if (NSTAGE == 3 && kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | 5);   // vmcnt(5): step kt landed, step kt + 1 may still fly
     else __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
@@ -480,6 +495,60 @@ __global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kerne
         const int row = m0 + wm * 32 + mi * 16 + lq * 4 + r;
         if (row < NG) unsafeAtomicAdd(p.a_rowsum + row, acc[mi][5][r] * alpha);
       }
+  }
+}
+
+
+template <int NSTAGE, int TAG = 0>   // 2: two workgroups per CU; 3: one workgroup per CU with the DMA two K-steps ahead (experiment, VPTR_WGRAD_STAGES=3)
+__global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
+                                                                const int count, const int xmode, const int tile_base) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
+  const int lg = tile_base + ((xmode & 0xff) == 1 ? (int)blockIdx.x : xcd_logical_block());
+  if ((xmode & 0x100) && (threadIdx.x >> 6) >= 4) __builtin_amdgcn_s_setprio(1);   // experiment: see vptr_gemm_p16_kernel
+  int lo = 0, hi = count - 1;  // last g with tile_start[g] <= lg (workgroup-uniform scalar search)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_start[mid] <= lg) lo = mid;
+    else hi = mid - 1;
+  }
+  WgSync none = {nullptr, 0, 0, 1, false};
+  wgrad_p16_tile<NSTAGE, false>(descs[lo], lg - tile_start[lo], p16_smem, none);
+}
+
+// Persistent form for the panel-synchronous schedule: gridDim.x = 8 * slots workgroups (two per CU), workgroup b serves XCD b & 7 as its
+// slot b >> 3; XCD x owns the same contiguous range of the logical tile order as in the plain launch and walks it in ROUNDS of `slots`
+// tiles.  Requires every problem of the launch to have the same token count (the caller vouches: vptr_gemm_desc.split_k = -S on the
+// prototype).  g_wgrad_sync_ws: 64 ints per XCD (counter at [x * 64], leave counter at [x * 64 + 32]); the kernel leaves them zero.
+__device__ int g_wgrad_sync_ws[8 * 64];   // module-scope, zero at load; one launch of the kernel at a time (launches on ONE stream serialise)
+__global__ __launch_bounds__(GNT, 4) void vptr_wgrad_p16_sync_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
+                                                                    const int count, const int total_tiles, const int S) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
+  int* const ws = g_wgrad_sync_ws;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int xq = total_tiles >> 3, xr = total_tiles & 7;
+  const int first = xcd * xq + min(xcd, xr), mine = xq + (xcd < xr ? 1 : 0);   // this XCD's tiles: [first, first + mine)
+  const int nk = (descs[0].K + 31) >> 5;
+  const int per_tile = (nk - 1) / S;   // arrivals per tile (steps S, 2 S, ... < nk)
+  WgSync sy = {ws + xcd * 64, 0, 0, S, true};
+  for (int r = 0; r * slots + slot < mine; ++r) {
+    const int lg = first + r * slots + slot;
+    int lo = 0, hi = count - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (tile_start[mid] <= lg) lo = mid;
+      else hi = mid - 1;
+    }
+    sy.base = r * slots * per_tile;
+    sy.n = min(slots, mine - r * slots);
+    if (r > 0) __syncthreads();   // the previous tile's last stage is still being read by slower waves
+    wgrad_p16_tile<2, true>(descs[lo], lg - tile_start[lo], p16_smem, sy);
+  }
+  if (threadIdx.x == 0) {   // the last workgroup of this XCD to leave puts the two words back to zero for the next launch
+    int* done = ws + xcd * 64 + 32;
+    if (__hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == slots - 1) {
+      __hip_atomic_store(ws + xcd * 64, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -618,6 +687,23 @@ int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* des
       stages = -1;
       return -1;
     }
+  }
+  // panel-synchronous persistent launch (default since round 4; VPTR_WGRAD_SYNC=0 restores the plain one) for prototypes whose split_k is -1
+  // (the host vouches that all problems share one token count)
+  static int sync_s = -1;
+  if (sync_s < 0) {
+    const char* e = getenv("VPTR_WGRAD_SYNC");   // block length S in K-steps (even, 2 .. 64); 0 = plain launch.  Default 16: same time as
+    sync_s = e ? atoi(e) : 16;                    // the plain launch, a third of its fabric traffic (profiles/r04_wgrad_standalone_pmc.txt)
+    if (sync_s < 2 || sync_s > 64 || (sync_s & 1)) sync_s = 0;
+    int per_cu = 0;   // the schedule assumes that 2 workgroups per CU are resident at once: ask the runtime (a wrong answer costs time, not a hang)
+    if (sync_s && (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_sync_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
+                   hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vptr_wgrad_p16_sync_kernel, GNT, 2 * P16_STAGE) != hipSuccess || per_cu < 2))
+      sync_s = 0;
+  }
+  if (sync_s && proto->split_k == -1 && proto->atomic && total_tiles >= 1024 && vptr_cu_count() > 0 && vptr_cu_count() % 4 == 0) {
+    const int grid = 2 * vptr_cu_count();   // two workgroups per CU (80 KB of LDS each), a multiple of 8
+    vptr_wgrad_p16_sync_kernel<<<grid, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, total_tiles, sync_s);
+    return 0;
   }
   // gen > 0: the tile list as consecutive launches of `gen` tiles (one "generation" of resident workgroups each): every launch starts its
   // tiles together, so tiles that share operand panels begin in step instead of inheriting the finishing skew of their predecessors

@@ -717,6 +717,8 @@ def _launch_wgrad_group(its, atomic=1):
             d.a_mode, d.b_mode = (A_P16T, B_P16T) if p16 else (1, 1)
             starts.append(total)
             total += ((rows_ + 127) // 128) * ((cols_ + cols - 1) // cols)
+        if p16 and atomic and len({sub[9] for sub in subs}) == 1:
+            descs[0].split_k = -1     # every problem walks the same number of tokens: the panel-synchronous launch may serve the group (VPTR_WGRAD_SYNC)
         dev = grp[0][0].device
         import struct
         raw = _to_device_async(bytes(descs), dev)
