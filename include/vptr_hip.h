@@ -39,6 +39,11 @@ const char* vptr_last_error(void);
 int vptr_set_deterministic(int on);
 int vptr_get_deterministic(void);
 
+/* Telemetry of the panel-synchronous grouped weight-gradient launch (vptr_gemm_grouped with token-major P16 operands):
+ * out_dev[8] (device ints) = per XCD, how many workgroups gave up a bounded wait since the library was loaded.  All zero = every
+ * participant was resident whenever somebody waited for it. */
+int vptr_wgrad_sync_stats(int* out_dev, vptr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * GEMM + fused epilogue on MFMA (bf16 inputs split from fp32 in the staging path, fp32 accumulate).
  *   D[M,N] = epilogue( op(A)[M,K] * op(B)[K,N] )

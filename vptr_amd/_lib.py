@@ -120,6 +120,7 @@ SIGNATURES = {
     "vptr_sumsq_ws": [P, L, P, P, I, P],
     "vptr_set_deterministic": [I],
     "vptr_get_deterministic": [],
+    "vptr_wgrad_sync_stats": [P, P],
     "vptr_adamw": [P, P, P, P, L, F, F, F, F, F, P, P, F, F, P],
 }
 EXPORTS = sorted(list(SIGNATURES) + ["vptr_abi_version", "vptr_last_error"])

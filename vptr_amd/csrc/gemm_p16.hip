@@ -397,7 +397,11 @@ __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const in
         const int target = sy.base + (kt / sy.S) * sy.n;
         int spins = 0;
         while (__hip_atomic_load(sy.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          if (++spins > 3000) { sy.live = false; break; }   // ~1.5 ms: somebody is not resident -- go on unsynchronised
+          if (++spins > 3000) {   // ~1.5 ms: somebody is not resident -- go on unsynchronised (counted: tools/wgrad_sync_probe.py reads the word)
+            sy.live = false;
+            __hip_atomic_fetch_add(sy.cnt + 48, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
           __builtin_amdgcn_s_sleep(8);
         }
       }
@@ -550,6 +554,18 @@ __global__ __launch_bounds__(GNT, 4) void vptr_wgrad_p16_sync_kernel(const vptr_
       __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+__global__ void wgrad_sync_stats_kernel(int* __restrict__ out) {
+  if (threadIdx.x < 8) out[threadIdx.x] = g_wgrad_sync_ws[threadIdx.x * 64 + 48];
+}
+// telemetry: out_dev[8] (device ints) = how often a workgroup of XCD x gave up waiting in the panel-synchronous weight-gradient launches
+// since the library was loaded (0 everywhere = every participant was always resident)
+extern "C" int vptr_wgrad_sync_stats(int* out_dev, vptr_stream_t stream) {
+  VPTR_CHECK(out_dev != nullptr, "wgrad_sync_stats: null output");
+  wgrad_sync_stats_kernel<<<1, 64, 0, (hipStream_t)stream>>>(out_dev);
+  VPTR_LAUNCH_CHECK();
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

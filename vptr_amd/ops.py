@@ -730,7 +730,11 @@ def _launch_wgrad_group(its, atomic=1):
         check(lib.vptr_gemm_grouped(ctypes.byref(descs[0]), ptr(raw), ptr(st), n, total, stream()), "vptr_gemm_grouped")
         if prof is not None:
             e1.record()
-            prof.append(((cols // 16, prec, 6 if p16 else 1, 4 if p16 else 1, "grouped" if atomic else "grouped_split"), flops, e0, e1))
+            # (which kernel the launcher picks for this group: the panel-synchronous persistent one needs VPTR_WGRAD_SYNC != 0 (default 16), the
+            # uniform-token vouch and >= 1024 tiles -- mirrored here so that bench.py names the kernel rocprofv3 will list)
+            sync = p16 and atomic and descs[0].split_k == -1 and total >= 1024 and os.environ.get("VPTR_WGRAD_SYNC", "16") not in ("0", "")
+            prof.append(((cols // 16, prec, 6 if p16 else 1, 4 if p16 else 1, ("grouped_sync" if sync else "grouped") if atomic else "grouped_split"),
+                         flops, e0, e1))
 
 
 def convt_weight_grads(layers, tokens_per_split=2560):
