@@ -311,11 +311,10 @@ struct WgSync {
   int* cnt;        // this XCD's arrival counter (cumulative over the launch; reset by the last workgroup of the XCD to leave)
   int base;        // arrivals of all earlier rounds: round * slots * arrivals_per_tile
   int n;           // participants of this round
-  int S;           // K-steps per block
   bool live;       // false after a timeout
 };
 
-template <int NSTAGE, bool SYNC>
+template <int NSTAGE, int SYNC>   // SYNC: 0 = none, else the block length S (a power of two) of the panel-synchronous schedule
 __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const int tile, unsigned char* p16_smem, WgSync& sy) {
   constexpr int BN = 176;
   const int NG = p.M, KX = p.N, T = p.K;   // D[NG][KX] += alpha * G[T][NG]^T . X[T][KX]
@@ -390,11 +389,11 @@ __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const in
   issue(0, 0);
   if (NSTAGE == 3 && nk > 1) issue(1, 1);
   for (int kt = 0; kt < nk; ++kt) {
-    if (SYNC && kt > 0 && threadIdx.x == 0) {   // wave 0 reaches this step's barrier late if it has to wait: the other waves wait there
-      const int ph = kt % sy.S;
+    if (SYNC > 0 && kt > 0 && (kt & (SYNC / 2 - 1)) == 0 && threadIdx.x == 0) {   // wave 0 reaches this step's barrier late if it has to wait: the other waves wait there
+      const int ph = kt & (SYNC - 1);
       if (ph == 0) __hip_atomic_fetch_add(sy.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // finished block kt / S - 1
-      else if (ph == (sy.S >> 1) && kt > sy.S && sy.live) {
-        const int target = sy.base + (kt / sy.S) * sy.n;
+      else if (kt > SYNC && sy.live) {
+        const int target = sy.base + (kt / SYNC) * sy.n;
         int spins = 0;
         while (__hip_atomic_load(sy.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
           if (++spins > 3000) {   // ~1.5 ms: somebody is not resident -- go on unsynchronised (counted: tools/wgrad_sync_probe.py reads the word)
@@ -515,8 +514,8 @@ __global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kerne
     if (tile_start[mid] <= lg) lo = mid;
     else hi = mid - 1;
   }
-  WgSync none = {nullptr, 0, 0, 1, false};
-  wgrad_p16_tile<NSTAGE, false>(descs[lo], lg - tile_start[lo], p16_smem, none);
+  WgSync none = {nullptr, 0, 0, false};
+  wgrad_p16_tile<NSTAGE, 0>(descs[lo], lg - tile_start[lo], p16_smem, none);
 }
 
 // Persistent form for the panel-synchronous schedule: gridDim.x = 8 * slots workgroups (two per CU), workgroup b serves XCD b & 7 as its
@@ -524,8 +523,9 @@ __global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kerne
 // tiles.  Requires every problem of the launch to have the same token count (the caller vouches: vptr_gemm_desc.split_k = -S on the
 // prototype).  g_wgrad_sync_ws: 64 ints per XCD (counter at [x * 64], leave counter at [x * 64 + 32]); the kernel leaves them zero.
 __device__ int g_wgrad_sync_ws[8 * 64];   // module-scope, zero at load; one launch of the kernel at a time (launches on ONE stream serialise)
+template <int S>
 __global__ __launch_bounds__(GNT, 4) void vptr_wgrad_p16_sync_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
-                                                                    const int count, const int total_tiles, const int S) {
+                                                                    const int count, const int total_tiles) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
   int* const ws = g_wgrad_sync_ws;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(GNT, 4) void vptr_wgrad_p16_sync_kernel(const vptr_
   const int first = xcd * xq + min(xcd, xr), mine = xq + (xcd < xr ? 1 : 0);   // this XCD's tiles: [first, first + mine)
   const int nk = (descs[0].K + 31) >> 5;
   const int per_tile = (nk - 1) / S;   // arrivals per tile (steps S, 2 S, ... < nk)
-  WgSync sy = {ws + xcd * 64, 0, 0, S, true};
+  WgSync sy = {ws + xcd * 64, 0, 0, true};
   for (int r = 0; r * slots + slot < mine; ++r) {
     const int lg = first + r * slots + slot;
     int lo = 0, hi = count - 1;
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(GNT, 4) void vptr_wgrad_p16_sync_kernel(const vptr_
     sy.base = r * slots * per_tile;
     sy.n = min(slots, mine - r * slots);
     if (r > 0) __syncthreads();   // the previous tile's last stage is still being read by slower waves
-    wgrad_p16_tile<2, true>(descs[lo], lg - tile_start[lo], p16_smem, sy);
+    wgrad_p16_tile<2, S>(descs[lo], lg - tile_start[lo], p16_smem, sy);
   }
   if (threadIdx.x == 0) {   // the last workgroup of this XCD to leave puts the two words back to zero for the next launch
     int* done = ws + xcd * 64 + 32;
@@ -708,17 +708,21 @@ int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* des
   // (the host vouches that all problems share one token count)
   static int sync_s = -1;
   if (sync_s < 0) {
-    const char* e = getenv("VPTR_WGRAD_SYNC");   // block length S in K-steps (even, 2 .. 64); 0 = plain launch.  Default 16: same time as
+    const char* e = getenv("VPTR_WGRAD_SYNC");   // block length S in K-steps (8, 16 or 32); 0 = plain launch.  Default 16: same time as
     sync_s = e ? atoi(e) : 16;                    // the plain launch, a third of its fabric traffic (profiles/r04_wgrad_standalone_pmc.txt)
-    if (sync_s < 2 || sync_s > 64 || (sync_s & 1)) sync_s = 0;
+    if (sync_s != 8 && sync_s != 16 && sync_s != 32) sync_s = 0;   // instantiated block lengths
     int per_cu = 0;   // the schedule assumes that 2 workgroups per CU are resident at once: ask the runtime (a wrong answer costs time, not a hang)
-    if (sync_s && (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_sync_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
-                   hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vptr_wgrad_p16_sync_kernel, GNT, 2 * P16_STAGE) != hipSuccess || per_cu < 2))
+    if (sync_s && (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_sync_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_sync_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_sync_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
+                   hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vptr_wgrad_p16_sync_kernel<16>, GNT, 2 * P16_STAGE) != hipSuccess || per_cu < 2))
       sync_s = 0;
   }
   if (sync_s && proto->split_k == -1 && proto->atomic && total_tiles >= 1024 && vptr_cu_count() > 0 && vptr_cu_count() % 4 == 0) {
     const int grid = 2 * vptr_cu_count();   // two workgroups per CU (80 KB of LDS each), a multiple of 8
-    vptr_wgrad_p16_sync_kernel<<<grid, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, total_tiles, sync_s);
+    if (sync_s == 8) vptr_wgrad_p16_sync_kernel<8><<<grid, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, total_tiles);
+    else if (sync_s == 32) vptr_wgrad_p16_sync_kernel<32><<<grid, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, total_tiles);
+    else vptr_wgrad_p16_sync_kernel<16><<<grid, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, total_tiles);
     return 0;
   }
   // gen > 0: the tile list as consecutive launches of `gen` tiles (one "generation" of resident workgroups each): every launch starts its
