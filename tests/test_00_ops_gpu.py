@@ -2,7 +2,6 @@
 
 Tolerances (rel-L2): split-bf16 GEMM (precision 3) 3e-5; single-pass bf16 (precision 1) 1.5e-2; fp32 vector kernels 2e-5.
 """
-import math
 
 import pytest
 import torch

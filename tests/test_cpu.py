@@ -1,7 +1,6 @@
 """CPU-only tests: the oracle against the golden vectors captured from the reference, host-side logic (module tree,
 state_dict keys, position tables, init), and that the C-ABI library loads and exports every declared symbol."""
 import ctypes
-import json
 import os
 import re
 

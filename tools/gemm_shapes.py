@@ -1,5 +1,5 @@
 """Per-shape GEMM table of one NAR train step (GPU box): launches, total ms, TFLOP/s by (M, N, K, a_mode, b_mode)."""
-import os, sys, ctypes
+import os, sys
 import torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)

@@ -7,7 +7,6 @@ rows = (n, t, h, w) flattened -- the reference's window partition and (T, N*HW, 
 import bisect
 import ctypes
 import os
-import math
 
 import torch
 
