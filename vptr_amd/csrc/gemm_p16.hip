@@ -92,11 +92,12 @@ extern "C" int vptr_weight_planes(const vptr_wplane_entry* table_dev, const int*
 // K % 32 == 16: the last step's second granule does not exist; its DMA lanes re-fetch the first one (always valid memory)
 // and the A fragments of lanes lq >= 2 are zeroed.
 // ---------------------------------------------------------------------------------------------------------------------
-// LEAN: plain epilogue only (gemm_shared.h).  NST = 3: the instantiation for grids of at most one workgroup per CU (nothing else on
-// the CU hides a stall): three stages with the DMA two K-steps ahead, its pieces issued between the MFMA groups instead of in a
-// burst after the barrier (cache-cold 10 240 x 528 x 2112: 79.7 -> 73.1 us in tools/gemm_p16_probe).  Both chosen by the launcher.
+// LEAN: plain epilogue only (gemm_shared.h).  NST >= 3: the instantiations for grids of at most one workgroup per CU (nothing else on
+// the CU hides a stall): NST stages with the DMA NST - 1 K-steps ahead, its pieces issued between the MFMA groups instead of in a
+// burst after the barrier (cache-cold 10 240 x 528 x 2112: 79.7 -> 73.1 us in tools/gemm_p16_probe with three stages; four stages = the
+// CU's whole 160 KB: 77.9 -> 74.0 us inside the step, VPTR_GEMM_LONE_STAGES=3 restores three).  Chosen by the launcher.
 template <int EPI, int NST>   // EPI: 0 every epilogue option, 1 lean, 2 activation gradient, 3 lean + row scale + dropout (gemm_shared.h)
-__global__ __launch_bounds__(GNT, NST == 3 ? 2 : 4) void vptr_gemm_p16_kernel(const vptr_gemm_desc p, const int epi_rows_) {
+__global__ __launch_bounds__(GNT, NST >= 3 ? 2 : 4) void vptr_gemm_p16_kernel(const vptr_gemm_desc p, const int epi_rows_) {
   constexpr int NFN = 11, BN = 176;
   extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -180,8 +181,9 @@ __global__ __launch_bounds__(GNT, NST == 3 ? 2 : 4) void vptr_gemm_p16_kernel(co
   // lo chunk = hi chunk + 2 under the XOR swizzle: (ch + 2) ^ f = (ch ^ f) ^ 2 because bit 1 of ch is clear
   const int nkt = nk * nseg;
   issue(0, 0);
-  if (NST == 3 && nkt > 1) issue(1, 1);
-  int sc = 0, sn = 2;   // NST == 3: stage of step kt, stage that step kt + 2 goes to
+  if (NST >= 3 && nkt > 1) issue(1, 1);
+  if (NST >= 4 && nkt > 2) issue(2, 2);
+  int sc = 0, sn = NST - 1;   // NST >= 3: stage of step kt, stage that step kt + NST - 1 goes to
 #ifdef VPTR_P16_TIMING
   long long cyc_wait = 0, cyc_issue = 0, cyc_t = 0;   // shader-clock cycles this wave spent waiting for the step / issuing its DMA
 #endif
@@ -190,7 +192,8 @@ __global__ __launch_bounds__(GNT, NST == 3 ? 2 : 4) void vptr_gemm_p16_kernel(co
     cyc_t = clock64();
 #endif
     // step kt has landed: with three stages step kt + 1 (5 pieces per wave) may still be in flight
-    if (NST == 3 && kt + 1 < nkt) __builtin_amdgcn_s_waitcnt(0x0f70 | 5);
+    if (NST >= 4 && kt + 2 < nkt) __builtin_amdgcn_s_waitcnt(0x0f70 | 10);   // four stages: steps kt + 1 and kt + 2 may be in flight
+    else if (NST >= 3 && kt + 1 < nkt) __builtin_amdgcn_s_waitcnt(0x0f70 | 5);
     else __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();                      // ... for every wave, and everyone is done reading the stage the next DMA overwrites
 #ifdef VPTR_P16_TIMING
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(GNT, NST == 3 ? 2 : 4) void vptr_gemm_p16_kernel(co
 #ifdef VPTR_P16_TIMING
     cyc_issue += clock64() - cyc_t;
 #endif
-    const unsigned char* st = p16_smem + (NST == 3 ? sc : (kt & 1)) * P16_STAGE;
+    const unsigned char* st = p16_smem + (NST >= 3 ? sc : (kt & 1)) * P16_STAGE;
     bf16x8 ah[2], al[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(GNT, NST == 3 ? 2 : 4) void vptr_gemm_p16_kernel(co
         bh[(ni + 1) & 1] = *reinterpret_cast<const bf16x8*>(st + offBh[ni + 1]);
         bl[(ni + 1) & 1] = *reinterpret_cast<const bf16x8*>(st + (offBh[ni + 1] ^ 32));
       }
-      if (NST == 3 && ni < 5 && kt + 2 < nkt) issue1(kt + 2, sn, ni);
+      if (NST >= 3 && ni < 5 && kt + NST - 1 < nkt) issue1(kt + NST - 1, sn, ni);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
@@ -240,9 +243,9 @@ __global__ __launch_bounds__(GNT, NST == 3 ? 2 : 4) void vptr_gemm_p16_kernel(co
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (NST == 3) {
-      sc = sc == 2 ? 0 : sc + 1;
-      sn = sn == 2 ? 0 : sn + 1;
+    if (NST >= 3) {
+      sc = sc == NST - 1 ? 0 : sc + 1;
+      sn = sn == NST - 1 ? 0 : sn + 1;
     }
   }
 #ifdef VPTR_P16_TIMING
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(GNT, NST == 3 ? 2 : 4) void vptr_gemm_p16_kernel(co
 #else
     gemm_epilogue_rows_halves_batched<NFN, EPI>(p, mb, acc, reinterpret_cast<float*>(p16_smem), m0, n0, wm, wn, lr, lq, tid, true, false);
 #endif
-  } else if (NST == 3 && (epi_rows || p.d_p16) && !p.atomic && epi_vec_ok(p)) {
+  } else if (NST >= 3 && (epi_rows || p.d_p16) && !p.atomic && epi_vec_ok(p)) {
     // the full epilogue with its operand loads batched: affordable under this instantiation's 256-register budget
     __syncthreads();
     gemm_epilogue_rows_halves_batched<NFN, 0>(p, mb, acc, reinterpret_cast<float*>(p16_smem), m0, n0, wm, wn, lr, lq, tid, true, false);
@@ -387,7 +390,8 @@ __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const in
   const bool rows_live = m0 + wm * 32 < NG;
 
   issue(0, 0);
-  if (NSTAGE == 3 && nk > 1) issue(1, 1);
+  if (NSTAGE >= 3 && nk > 1) issue(1, 1);
+  if (NSTAGE >= 4 && nk > 2) issue(2, 2);
   for (int kt = 0; kt < nk; ++kt) {
     if (SYNC > 0 && kt > 0 && (kt & (SYNC / 2 - 1)) == 0 && threadIdx.x == 0) {   // wave 0 reaches this step's barrier late if it has to wait: the other waves wait there
       const int ph = kt & (SYNC - 1);
@@ -405,16 +409,17 @@ __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const in
         }
       }
     }
-    if (NSTAGE == 3 && kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | 5);   // vmcnt(5): step kt landed, step kt + 1 may still fly
+    if (NSTAGE >= 4 && kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | 10);
+    else if (NSTAGE >= 3 && kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | 5);   // vmcnt(5): step kt landed, step kt + 1 may still fly
     else __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
-    if (NSTAGE == 3) {
-      if (kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
+    if (NSTAGE >= 3) {
+      if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
     } else if (kt + 1 < nk) {
       issue(kt + 1, (kt + 1) & 1);
     }
     if (!rows_live && !colsum_wave) continue;   // wave-uniform: this wave's 32 rows lie beyond NG (the last row tile of a 528-row problem keeps 16 of 128)
-    const unsigned char* st = p16_smem + (NSTAGE == 3 ? kt % 3 : (kt & 1)) * P16_STAGE;
+    const unsigned char* st = p16_smem + (NSTAGE >= 3 ? kt % NSTAGE : (kt & 1)) * P16_STAGE;
     bf16x8 ah[2], al[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -640,7 +645,11 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P16_STAGE) != hipSuccess) {
       vptr_set_error("vptr_gemm(p16): cannot reserve %d bytes of LDS", 2 * P16_STAGE);
       return -1;
     }
@@ -661,7 +670,15 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
   const bool lean3 = !lean && (p16_epi_rows_flag() & 4) == 0 && !d.colscale && dpre_ok && (d.rowscale || d.dropout_p > 0.f) && d.act == VPTR_ACT_NONE &&
                      !d.act_after && !d.atomic && !d.frame_stats && (ebits & 15) == 0 && (d.N & 3) == 0 && (d.ldd & 3) == 0 && (d.ldr & 3) == 0 &&
                      getenv("VPTR_GEMM_NO_EPI3") == nullptr;
-  const bool lone = tiles <= vptr_cu_count() && (p16_epi_rows_flag() & 16) == 0;   // at most one workgroup per CU
+  static int lone_stages = 0, force_lone = 0;
+  if (!lone_stages) {
+    const char* e = getenv("VPTR_GEMM_LONE_STAGES");
+    lone_stages = (e && atoi(e) == 3) ? 3 : 4;   // default since round 4: four stages (all 160 KB), the DMA three K-steps ahead
+    const char* f = getenv("VPTR_GEMM_FORCE_LONE");   // experiment: the one-workgroup-per-CU instantiation for every grid
+    force_lone = f ? atoi(f) : 0;
+  }
+  const bool lone = (tiles <= vptr_cu_count() || force_lone) && (p16_epi_rows_flag() & 16) == 0;   // at most one workgroup per CU
+  const bool lone4 = lone && lone_stages == 4;
   const int rows = lean ? 1 : (p16_epi_rows_flag() & 2);
   if (d.frame_stats)   // served by the lean epilogue only: no fallback
     VPTR_CHECK(d.frame_rows >= 64 && d.frame_rows % 64 == 0 && d.M % 64 == 0 && !d.act_grad_src && lean && d.batch == 1,
@@ -670,13 +687,17 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
     VPTR_CHECK(!d.colscale && !d.Dpre && !d.rowscale && !d.residual && !d.bias && !d.act_after && !d.atomic && d.batch == 1 && d.ksegs == 1 &&
                    d.act != VPTR_ACT_NONE && ((ebits | reinterpret_cast<uintptr_t>(d.act_grad_src)) & 15) == 0 && (d.N & 3) == 0 && (d.ldd & 3) == 0,
                "vptr_gemm(p16): act_grad_src combines with alpha / dropout / P16 output only and needs 16-byte aligned operands, N, ldd multiples of 4");
-    if (lone) vptr_gemm_p16_kernel<2, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
+    if (lone4) vptr_gemm_p16_kernel<2, 4><<<tiles, GNT, 4 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
+    else if (lone) vptr_gemm_p16_kernel<2, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
     else vptr_gemm_p16_kernel<2, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
     return 0;
   }
   if (d.batch_accum)
     VPTR_CHECK(lean && d.batch > 1 && !d.d_p16 && (d.batch_accum >> d.batch) == 0, "vptr_gemm(p16): batch_accum is an option of plain fp32-output batch launches");
-  if (lean3 && lone) vptr_gemm_p16_kernel<3, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
+  if (lean3 && lone4) vptr_gemm_p16_kernel<3, 4><<<tiles, GNT, 4 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
+  else if (lean && lone4) vptr_gemm_p16_kernel<1, 4><<<tiles, GNT, 4 * P16_STAGE, st>>>(d, rows | p16_prio_flag());
+  else if (!lean3 && !lean && lone4) vptr_gemm_p16_kernel<0, 4><<<tiles, GNT, 4 * P16_STAGE, st>>>(d, rows | p16_prio_flag());
+  else if (lean3 && lone) vptr_gemm_p16_kernel<3, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
   else if (lean3) vptr_gemm_p16_kernel<3, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
   else if (lean && lone) vptr_gemm_p16_kernel<1, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, rows | p16_prio_flag());
   else if (lean) vptr_gemm_p16_kernel<1, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, rows | p16_prio_flag());
@@ -695,10 +716,11 @@ int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* des
     const char* ge = getenv("VPTR_WGRAD_GEN");
     gen = ge ? atoi(ge) : 0;
     const char* e = getenv("VPTR_WGRAD_STAGES");
-    stages = (e && atoi(e) == 3) ? 3 : 2;
+    stages = (e && (atoi(e) == 3 || atoi(e) == 4)) ? atoi(e) : 2;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P16_STAGE) != hipSuccess) {
       vptr_set_error("vptr_gemm_grouped(p16): cannot reserve LDS");
       stages = -1;
       return -1;
@@ -730,7 +752,8 @@ int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* des
   const int per = gen > 0 ? gen : total_tiles;
   for (int base = 0; base < total_tiles; base += per) {
     const int nt = total_tiles - base < per ? total_tiles - base : per;
-    if (stages == 3) vptr_wgrad_p16_kernel<3><<<nt, GNT, 3 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), base);
+    if (stages == 4) vptr_wgrad_p16_kernel<4><<<nt, GNT, 4 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), base);
+    else if (stages == 3) vptr_wgrad_p16_kernel<3><<<nt, GNT, 3 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), base);
     else if (!proto->atomic) vptr_wgrad_p16_kernel<2, 1><<<nt, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), base);
     else vptr_wgrad_p16_kernel<2><<<nt, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), base);
   }
