@@ -149,7 +149,13 @@ __global__ __launch_bounds__(GNT, NST >= 3 ? 2 : 4) void vptr_gemm_p16_kernel(co
     const int c = pch ^ (((lane >> 4) + 4 * wave) & 7);
     tadj = c >= 4 ? -64 : 0;
   }
+#ifdef VPTR_NT_ELIM   // elimination build (WRONG results): only the first VPTR_NT_ELIM of a wave's 5 pieces per K-step are staged
+  constexpr int NPIECE = VPTR_NT_ELIM;
+#else
+  constexpr int NPIECE = 5;
+#endif
   auto issue1 = [&](const int kt, const int stage, const int i) {   // piece i of this wave: 0, 1 = A, 2 .. 4 = B
+    if (i >= NPIECE) return;
     const int sg = (int)(kt >= nk) + (int)(kt >= 2 * nk);
     const int kk = kt - sg * nk;
     const int64_t off = (int64_t)kk * 128 + ((ktail && kk == nk - 1) ? tadj : 0);
@@ -192,8 +198,8 @@ __global__ __launch_bounds__(GNT, NST >= 3 ? 2 : 4) void vptr_gemm_p16_kernel(co
     cyc_t = clock64();
 #endif
     // step kt has landed: with three stages step kt + 1 (5 pieces per wave) may still be in flight
-    if (NST >= 4 && kt + 2 < nkt) __builtin_amdgcn_s_waitcnt(0x0f70 | 10);   // four stages: steps kt + 1 and kt + 2 may be in flight
-    else if (NST >= 3 && kt + 1 < nkt) __builtin_amdgcn_s_waitcnt(0x0f70 | 5);
+    if (NST >= 4 && kt + 2 < nkt) __builtin_amdgcn_s_waitcnt(0x0f70 | (2 * NPIECE));   // four stages: steps kt + 1 and kt + 2 may be in flight
+    else if (NST >= 3 && kt + 1 < nkt) __builtin_amdgcn_s_waitcnt(0x0f70 | NPIECE);
     else __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();                      // ... for every wave, and everyone is done reading the stage the next DMA overwrites
 #ifdef VPTR_P16_TIMING
