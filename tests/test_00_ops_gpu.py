@@ -530,7 +530,8 @@ def test_norm_act(ops, dev, mode):
     assert rel(resd.grad, go) < 1e-6
 
 
-@pytest.mark.parametrize("frames,H,W,Fc", [(5, 8, 6, 32), (32, 8, 8, 1024), (3, 5, 7, 16), (70, 4, 4, 64)])   # 2nd: two-column forward kernel; 3rd: odd W
+@pytest.mark.parametrize("frames,H,W,Fc", [(5, 8, 6, 32), (32, 8, 8, 1024), (3, 5, 7, 16), (70, 4, 4, 64), (40, 4, 4, 2048), (24, 16, 16, 1024),
+                                            (48, 8, 6, 1024)])   # 2nd, 5th, 6th: two-column forward kernel with DPP halo exchange (W / 2 = 4, 2, 8); 3rd: odd W; 7th: W / 2 = 3 (no DPP)
 def test_dwconv(ops, dev, frames, H, W, Fc):
     x, w, b, go = rn((frames * H * W, Fc), 80), rn((Fc, 1, 3, 3), 81, 0.3), rn((Fc,), 82), rn((frames * H * W, Fc), 83)
     xn = x.double().reshape(frames, H, W, Fc).permute(0, 3, 1, 2).clone().requires_grad_(True)

@@ -1230,6 +1230,71 @@ __global__ __launch_bounds__(256) void dwconv_fwd2_kernel(const float* __restric
     }
   }
 }
+// Third generation (W / 2 divides 16): the x pairs of one channel quad sit in ADJACENT lanes, every thread loads only its own two columns
+// and takes the outer two from its neighbours with DPP row shifts -- 2 loads per row instead of 4 and every input element crosses the
+// fabric once (dwconv_fwd2 re-fetches the shared columns from workgroups on other XCDs: 150 MB fetched for an 86.5 MB input at the
+// step's shape, profiles/r04_pmc_traffic.json).
+__device__ __forceinline__ float dpp_from_prev(float v) {   // lane i <- lane i - 1 (row of 16 lanes; 0 at the row start)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_from_next(float v) {   // lane i <- lane i + 1 (0 at the row end)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xf, 0xf, true));
+}
+__device__ __forceinline__ DwRow2 dw_load_row3(const float4* __restrict__ x, int64_t frame_row0, int row, int H, int xw0, int W, int F4,
+                                               int c4, float lok, float rok_) {
+  const float rok = (row >= 0 && row < H) ? 1.f : 0.f;
+  const int64_t base = (frame_row0 + min(max(row, 0), H - 1)) * W;
+  DwRow2 o;
+  o.c1 = scale4(x[(base + xw0) * F4 + c4], rok);
+  o.c2 = scale4(x[(base + xw0 + 1) * F4 + c4], rok);
+  o.c0 = make_float4(dpp_from_prev(o.c2.x) * lok, dpp_from_prev(o.c2.y) * lok, dpp_from_prev(o.c2.z) * lok, dpp_from_prev(o.c2.w) * lok);
+  o.c3 = make_float4(dpp_from_next(o.c1.x) * rok_, dpp_from_next(o.c1.y) * rok_, dpp_from_next(o.c1.z) * rok_, dpp_from_next(o.c1.w) * rok_);
+  return o;
+}
+__global__ __launch_bounds__(256) void dwconv_fwd3_kernel(const float* __restrict__ x_, const float* __restrict__ w9,
+                                                          const float* __restrict__ b, float* __restrict__ y_, int frames, int H,
+                                                          int W, int F4, int flip, float* __restrict__ stats) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int W2 = W >> 1;
+  if (idx >= (int64_t)frames * W2 * F4) return;   // whole groups of W2 lanes leave together (the total is a multiple of W2)
+  const int xp = (int)(idx % W2), xw0 = xp * 2;
+  const int c4 = (int)((idx / W2) % F4);
+  const int64_t f = idx / ((int64_t)F4 * W2);
+  const float lok = xp > 0 ? 1.f : 0.f, rok_ = xp + 1 < W2 ? 1.f : 0.f;
+  const float4* __restrict__ x = reinterpret_cast<const float4*>(x_);
+  float4* __restrict__ y = reinterpret_cast<float4*>(y_);
+  float4 w[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) w[t] = reinterpret_cast<const float4*>(w9)[(int64_t)(flip ? 8 - t : t) * F4 + c4];
+  const float4 bias = b ? reinterpret_cast<const float4*>(b)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  DwRow2 r0 = dw_load_row3(x, f * H, -1, H, xw0, W, F4, c4, lok, rok_), r1 = dw_load_row3(x, f * H, 0, H, xw0, W, F4, c4, lok, rok_);
+  float ssum = 0.f, ssq = 0.f;
+  for (int yh = 0; yh < H; ++yh) {
+    const DwRow2 r2 = dw_load_row3(x, f * H, yh + 1, H, xw0, W, F4, c4, lok, rok_);
+    float4 a = bias, a2 = bias;
+    fma4(a, w[0], r0.c0); fma4(a, w[1], r0.c1); fma4(a, w[2], r0.c2);
+    fma4(a, w[3], r1.c0); fma4(a, w[4], r1.c1); fma4(a, w[5], r1.c2);
+    fma4(a, w[6], r2.c0); fma4(a, w[7], r2.c1); fma4(a, w[8], r2.c2);
+    fma4(a2, w[0], r0.c1); fma4(a2, w[1], r0.c2); fma4(a2, w[2], r0.c3);
+    fma4(a2, w[3], r1.c1); fma4(a2, w[4], r1.c2); fma4(a2, w[5], r1.c3);
+    fma4(a2, w[6], r2.c1); fma4(a2, w[7], r2.c2); fma4(a2, w[8], r2.c3);
+    y[((f * H + yh) * W + xw0) * F4 + c4] = a;
+    y[((f * H + yh) * W + xw0 + 1) * F4 + c4] = a2;
+    if (stats) {
+      ssum += ((a.x + a.y) + (a.z + a.w)) + ((a2.x + a2.y) + (a2.z + a2.w));
+      ssq += ((a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w)) + ((a2.x * a2.x + a2.y * a2.y) + (a2.z * a2.z + a2.w * a2.w));
+    }
+    r0 = r1;
+    r1 = r2;
+  }
+  if (stats) {   // the wave lies inside one frame (W2 * F4 % 64 == 0)
+    const float S = wave_sum(ssum), Q = wave_sum(ssq);
+    if ((threadIdx.x & 63) == 0) {
+      unsafeAtomicAdd(stats + 2 * f, S);
+      unsafeAtomicAdd(stats + 2 * f + 1, Q);
+    }
+  }
+}
 // dw9[tap, c] += sum_{f,y,x} dy[f,y,x,c] * x[f,y+ky-1,x+kx-1,c];  db[c] += sum dy.
 // Block = 32 channel quads x 8 x-lanes over a chunk of frames; every thread walks its columns with the same rolling window
 // (1 + 3 float4 loads per pixel), the 8 x-lanes are summed through LDS and each block issues 40 atomics per channel quad.
@@ -1302,15 +1367,27 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restri
   }
 }
 
+static bool dw_v3(int W, int64_t total) {   // VPTR_DWCONV_GEN=2 restores dwconv_fwd2_kernel
+  static int gen = -1;
+  if (gen < 0) {
+    const char* e = getenv("VPTR_DWCONV_GEN");
+    gen = e ? atoi(e) : 3;
+  }
+  const int W2 = W / 2;
+  return gen >= 3 && W % 2 == 0 && W2 >= 1 && 16 % W2 == 0 && total % 2 == 0;
+}
 extern "C" int vptr_dwconv3x3_fwd(const float* x, const float* w9, const float* b, float* y, int frames, int H, int W, int F,
                                   float* frame_stats, vptr_stream_t stream) {
   VPTR_CHECK(frames > 0 && H > 0 && W > 0 && F > 0 && F % 4 == 0, "dwconv3x3_fwd: bad arguments");
   const int64_t total = (int64_t)frames * W * (F / 4);
   if (frame_stats) {   // no silent fallback: the caller asks for statistics only where this kernel can give them (vptr_amd/ops.py)
     VPTR_CHECK(W % 2 == 0 && ((W / 2) * (F / 4)) % 64 == 0, "dwconv3x3_fwd: frame_stats needs W even and (W/2)*(F/4) %% 64 == 0");
-    dwconv_fwd2_kernel<<<(unsigned)((total / 2 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, w9, b, y, frames, H, W, F / 4, 0, frame_stats);
-  } else if (W % 2 == 0 && total >= (1 << 16))
-    dwconv_fwd2_kernel<<<(unsigned)((total / 2 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, w9, b, y, frames, H, W, F / 4, 0, nullptr);
+    if (dw_v3(W, total)) dwconv_fwd3_kernel<<<(unsigned)((total / 2 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, w9, b, y, frames, H, W, F / 4, 0, frame_stats);
+    else dwconv_fwd2_kernel<<<(unsigned)((total / 2 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, w9, b, y, frames, H, W, F / 4, 0, frame_stats);
+  } else if (W % 2 == 0 && total >= (1 << 16)) {
+    if (dw_v3(W, total)) dwconv_fwd3_kernel<<<(unsigned)((total / 2 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, w9, b, y, frames, H, W, F / 4, 0, nullptr);
+    else dwconv_fwd2_kernel<<<(unsigned)((total / 2 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, w9, b, y, frames, H, W, F / 4, 0, nullptr);
+  }
   else
     dwconv_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, w9, b, y, frames, H, W, F / 4, 0);
   VPTR_LAUNCH_CHECK();
@@ -1323,7 +1400,9 @@ extern "C" int vptr_dwconv3x3_bwd(const float* dy, const float* x, const float* 
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)frames * W * (F / 4);
   if (dx) {
-    if (W % 2 == 0 && total >= (1 << 16))
+    if (W % 2 == 0 && total >= (1 << 16) && dw_v3(W, total))
+      dwconv_fwd3_kernel<<<(unsigned)((total / 2 + 255) / 256), 256, 0, st>>>(dy, w9, nullptr, dx, frames, H, W, F / 4, 1, nullptr);
+    else if (W % 2 == 0 && total >= (1 << 16))
       dwconv_fwd2_kernel<<<(unsigned)((total / 2 + 255) / 256), 256, 0, st>>>(dy, w9, nullptr, dx, frames, H, W, F / 4, 1, nullptr);
     else
       dwconv_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(dy, w9, nullptr, dx, frames, H, W, F / 4, 1);
