@@ -670,7 +670,7 @@ def _to_device_async(host_bytes, dev):
     return out
 
 
-def _launch_wgrad_group(its, atomic=1):
+def _launch_wgrad_group(its, atomic=1, allow_sync=True):
     groups = {}
     for it in its:
         p16 = it[9]
@@ -717,7 +717,7 @@ def _launch_wgrad_group(its, atomic=1):
             d.a_mode, d.b_mode = (A_P16T, B_P16T) if p16 else (1, 1)
             starts.append(total)
             total += ((rows_ + 127) // 128) * ((cols_ + cols - 1) // cols)
-        if p16 and atomic and len({sub[9] for sub in subs}) == 1:
+        if allow_sync and p16 and atomic and len({sub[9] for sub in subs}) == 1:
             descs[0].split_k = -1     # every problem walks the same number of tokens: the panel-synchronous launch may serve the group (VPTR_WGRAD_SYNC)
         dev = grp[0][0].device
         import struct
@@ -807,7 +807,11 @@ def flush_wgrads(chunks=1, on_chunk=None):
     for hi in bounds:
         # the chunk boundaries follow slab addresses (what makes a gradient range final); INSIDE a chunk the single-launch order applies:
         # largest problems first, problems that read the same X next to each other
-        _launch_wgrad_group(sorted(items[lo:hi], key=lambda it: (-it[3] * it[4], it[1].data_ptr(), it[2].data_ptr())))
+        # plain launch for the chunks: the persistent panel-synchronous kernel assumes that ALL its 512 workgroups are resident at once (every
+        # CU's whole LDS), and a chunk runs beside the all-reduce kernels of the previous one -- a displaced workgroup would cost the others
+        # a bounded-spin time-out (VPTR_WGRAD_SYNC_CHUNKS=1 allows it anyway)
+        _launch_wgrad_group(sorted(items[lo:hi], key=lambda it: (-it[3] * it[4], it[1].data_ptr(), it[2].data_ptr())),
+                            allow_sync=os.environ.get("VPTR_WGRAD_SYNC_CHUNKS") == "1")
         if on_chunk is not None:
             on_chunk(items[hi][2].data_ptr() if hi < len(items) else None)
         lo = hi
