@@ -135,7 +135,7 @@ def test_wgrad_p16_grouped_bench_size(ops, dev):
 
 @pytest.mark.parametrize("M,N,K", [(10240, 2112, 528), (10240, 528, 2112), (10240, 528, 528), (2560, 2112, 528)])
 def test_gemm_p16_nt_bench_size(ops, dev, M, N, K):
-    """the nt instantiations the timed step launches: > 256-tile grids (two-stage loop) and the 240-tile N = 528 grids (three-stage
+    """the nt instantiations the timed step launches: > 256-tile grids (two-stage loop) and the 240-tile N = 528 grids (four-stage
     loop), lean epilogue (bias + residual) and the GELU + saved pre-activation + P16-output epilogue of fc1 / linear1"""
     gen = torch.Generator(device=dev).manual_seed(7)
     x = torch.randn((M, K), device=dev, generator=gen)
