@@ -950,10 +950,8 @@ __global__ __launch_bounds__(256) void norm_act_bwd_frame_affine(const float* __
   const float ws[4] = {wv.x, wv.y, wv.z, wv.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
   float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
   const int hw = (e * 4) / F;
-  for (int f = f0 + wave; f < f1; f += 4) {
-    float t1 = 0.f, t2 = 0.f;
-    const float4 d = reinterpret_cast<const float4*>(dy)[(int64_t)f * E4 + e];
-    const float4 xv = reinterpret_cast<const float4*>(x)[(int64_t)f * E4 + e];
+  // two frames per iteration: both frames' loads are issued before the first frame's reductions (a wave has nothing else in flight)
+  auto one_frame = [&](const int f, const float4 d, const float4 xv, float& t1, float& t2) {
     const float mu = mean[f], rs = rstd[f];
     const int64_t i = ((int64_t)f * E4 + e) * 4;
     float rsc = 1.f;
@@ -969,13 +967,32 @@ __global__ __launch_bounds__(256) void norm_act_bwd_frame_affine(const float* __
       t1 += g * ws[q];
       t2 += g * ws[q] * xh;
     }
+  };
+  for (int f = f0 + wave; f < f1; f += 8) {
+    const int fb = f + 4;
+    const bool two = fb < f1;
+    const int fbc = two ? fb : f;
+    const float4 d0 = reinterpret_cast<const float4*>(dy)[(int64_t)f * E4 + e];
+    const float4 x0 = reinterpret_cast<const float4*>(x)[(int64_t)f * E4 + e];
+    const float4 d1 = reinterpret_cast<const float4*>(dy)[(int64_t)fbc * E4 + e];
+    const float4 x1 = reinterpret_cast<const float4*>(x)[(int64_t)fbc * E4 + e];
+    float t1 = 0.f, t2 = 0.f, u1 = 0.f, u2 = 0.f;
+    one_frame(f, d0, x0, t1, t2);
+    if (two) one_frame(fb, d1, x1, u1, u2);   // wave-uniform
     if (fsum) {  // per-wave partials, no atomics: 500+ waves adding into the same 2*frames words serialise badly
       t1 = wave_sum(t1);
       t2 = wave_sum(t2);
+      u1 = wave_sum(u1);
+      u2 = wave_sum(u2);
       if (lane == 0) {
         float* dst = fsum + ((int64_t)blockIdx.x * frames + f) * 2;
         dst[0] = t1;
         dst[1] = t2;
+        if (two) {
+          float* dst2 = fsum + ((int64_t)blockIdx.x * frames + fb) * 2;
+          dst2[0] = u1;
+          dst2[1] = u2;
+        }
       }
     }
   }
