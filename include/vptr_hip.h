@@ -43,6 +43,17 @@ int vptr_get_deterministic(void);
  * out_dev[8] (device ints) = per XCD, how many workgroups gave up a bounded wait since the library was loaded.  All zero = every
  * participant was resident whenever somebody waited for it. */
 int vptr_wgrad_sync_stats(int* out_dev, vptr_stream_t stream);
+/* Library-owned device state (the ONE exception to "no global mutable state"): the persistent panel-synchronous launch keeps its
+ * per-XCD arrival counters in a module-scope __device__ array (512 ints, zero at load, left zero by every launch) and assumes that all
+ * of its workgroups are resident.  Contract: AT MOST ONE such launch in flight per device, on one stream, with nothing else competing
+ * for the CUs -- which is what launches issued from one stream give.  vptr_gemm_grouped takes this path only for prototypes with
+ * split_k == -1 (the caller vouches: equal token counts, exclusive use of the device for the duration); callers that run beside other
+ * work (a second trainer on another stream, weight-gradient chunks beside RCCL kernels or beside a main-stream backward pass) pass
+ * split_k >= 0 and get the plain grouped launch, which has no shared state.  Breaking the contract cannot hang or corrupt results
+ * (destination adds are atomic, every wait is bounded) -- it costs bounded-spin time-outs, visible in vptr_wgrad_sync_stats.
+ * The A/B switches of INTEGRATION.md's table (VPTR_GEMM_*, VPTR_WGRAD_*, VPTR_NORM_*, VPTR_DWCONV_GEN) are read ONCE, at the first launch
+ * that consults them; VPTR_ATTN16 / VPTR_ATTN_MFMA / VPTR_ATTN16_FWD1 are read per launch (the tests switch attention families inside
+ * one process). */
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM + fused epilogue on MFMA (bf16 inputs split from fp32 in the staging path, fp32 accumulate).

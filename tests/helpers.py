@@ -83,6 +83,7 @@ def post_step_params_close(state_dict, z, rel_tol=1e-4, lr=1e-4, max_flip_frac=0
     run-dependent): compare the concatenated parameters globally and bound the share of updates that differ by > lr/2."""
     num = den = 0.0
     bad = tot = 0
+    worst = []
     for k in z.files:
         if not k.startswith("post:"):
             continue
@@ -90,8 +91,10 @@ def post_step_params_close(state_dict, z, rel_tol=1e-4, lr=1e-4, max_flip_frac=0
         d = state_dict[k[5:]].detach().cpu().double() - r
         num += float((d * d).sum())
         den += float((r * r).sum())
-        bad += int((d.abs() > 0.5 * lr).sum())
+        nb = int((d.abs() > 0.5 * lr).sum())
+        bad += nb
         tot += d.numel()
+        worst.append((nb / max(d.numel(), 1), nb, d.numel(), k[5:]))
     relerr = (num / den) ** 0.5
     assert relerr < rel_tol, relerr
     assert bad <= max_flip_frac * tot, (bad, tot, sorted(worst, reverse=True)[:12])

@@ -1,0 +1,72 @@
+"""bench.py's own rank start-up (the reference's data-parallel entry point spawns its workers itself: train_NAR_mp.py:319-326): `python
+bench.py --gpus 2` with no WORLD_SIZE in the environment must come back with a line that says n_gpus == 2 -- two real processes, a
+verified collective layer between them, per-rank timings and the exchange accounting -- for the headline job and for the BAIR FAR /
+KTH128 entry points.  A one-GPU box can run this with both ranks on cuda:0 and gloo as the exchange backend (RCCL refuses two ranks
+on one device); the 8-GPU node runs the same code with one GPU per rank over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, timeout=900):
+    env = dict(os.environ, VPTR_BENCH_SHARE_GPU="1", VPTR_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-other-configs"] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]            # rank 0 prints, nobody else does
+    return json.loads(lines[0])
+
+
+def _check(d, per_gpu_batch, frames):
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["global_batch"] == 2 * per_gpu_batch
+    assert d["loss_sane"], d["final_terms"]
+    c = d["comm"]
+    assert c["backend"] == "gloo" and c["rccl_ranks"] == 2 and d["rccl_ranks"] == 0      # gloo here: no RCCL claim
+    assert c["rank_sum_check"] == 3.0 and len(c["devices"]) == 2
+    assert c["launched_by"].startswith("bench.py self-launch")
+    assert c["allreduce_bytes_per_step"] > 0 and c["allreduce_calls_per_step"] >= 1
+    assert c["exposed_comm_ms_per_step"]["max"] >= 0.0
+    pr = d["per_rank_ms_per_step"]
+    assert 0 < pr["min"] <= pr["max"] <= d["ms_per_step"] * 1.05
+    assert abs(d["value"] - 2 * per_gpu_batch * frames / d["ms_per_step"] * 1e3) <= 1e-3 * d["value"] + 0.5
+    assert d["roofline"]["frac"] is not None and d["roofline"]["hbm_side"].get("kernel") == "adamw_kernel"
+
+
+def test_self_launch_two_ranks_k64():
+    d = _run(["--batch", "4"])
+    _check(d, 4, 10)
+    # K64 slab: 118,368,576 fp32 gradients all-reduced every step
+    assert d["comm"]["allreduce_bytes_per_step"] == 4 * 118368576
+    assert "hipGraph" in d["config"]["launch"], d["config"]["launch"]
+
+
+def test_self_launch_two_ranks_bair_far():
+    d = _run(["--config", "bair_far", "--batch", "2"])
+    _check(d, 2, 29)
+    assert d["config"]["baseline_config"] == 4 and "FAR" in d["metric"]
+
+
+def test_self_launch_two_ranks_kth128():
+    d = _run(["--config", "kth128", "--batch", "1"])
+    _check(d, 1, 40)
+    assert d["config"]["baseline_config"] == 5 and "128x128" in d["metric"]
+
+
+def test_rank_failure_is_loud():
+    """a rank that dies takes the job down with a non-zero exit code: no partial line"""
+    env = dict(os.environ, VPTR_BENCH_SHARE_GPU="1", VPTR_BENCH_BACKEND="nccl")     # RCCL + shared GPU is refused by every rank
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -3,6 +3,7 @@ state_dict keys, position tables, init), and that the C-ABI library loads and ex
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -488,3 +489,22 @@ def test_rollout_loops_match_reference_notebook_on_cpu():
     assert got.shape == tuple(z["bair_frames"].shape) and rel(got, z["bair_frames"]) < 2e-5
     with pytest.raises(ValueError):
         nar_rollout(enc, dec, narb, torch.from_numpy(z["bair_past"]), rounds=2, chain="feats")   # Tf != Tp cannot chain features
+
+
+def test_bench_refuses_fewer_devices_than_asked():
+    """`python bench.py --gpus 2` on a host with fewer than 2 visible GPUs (this container has none) must exit non-zero with a clear
+    message and print no result line -- never a silent one-GPU measurement labelled n_gpus 1"""
+    import subprocess
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("this host can run --gpus 2")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VPTR_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "GPU(s) visible" in (r.stderr + r.stdout) and "--gpus 2" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    # a launcher that brought up a different number of ranks than --gpus says is refused too, in either direction
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stderr + r.stdout)

@@ -601,6 +601,12 @@ static int p16_prio_flag() {   // VPTR_GEMM_PRIO=1: bit 8 of the kernels' mode a
   return v;
 }
 
+static bool p16_no_epi3() {   // VPTR_GEMM_NO_EPI3 (A/B switch), read once
+  static int v = -1;
+  if (v < 0) v = getenv("VPTR_GEMM_NO_EPI3") != nullptr;
+  return v != 0;
+}
+
 static int p16_epi_rows_flag() {
   static int v = -1;
   if (v < 0) {
@@ -675,7 +681,7 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
   // the same plus a DropPath row scale and / or dropout (out-projections and linear2 of every block: 46 launches of the K64 step)
   const bool lean3 = !lean && (p16_epi_rows_flag() & 4) == 0 && !d.colscale && dpre_ok && (d.rowscale || d.dropout_p > 0.f) && d.act == VPTR_ACT_NONE &&
                      !d.act_after && !d.atomic && !d.frame_stats && (ebits & 15) == 0 && (d.N & 3) == 0 && (d.ldd & 3) == 0 && (d.ldr & 3) == 0 &&
-                     getenv("VPTR_GEMM_NO_EPI3") == nullptr;
+                     !p16_no_epi3();
   static int lone_stages = 0, force_lone = 0;
   if (!lone_stages) {
     const char* e = getenv("VPTR_GEMM_LONE_STAGES");

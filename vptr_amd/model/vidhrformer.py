@@ -462,7 +462,7 @@ class VidHRformerDecoderNAR(nn.Module):
             mem, mem_k = ops.as_p16(mem), ops.as_p16(mem_k)
         x = tgt
         # every layer's encoder-decoder attention reads the same (mem_k, mem): their input gradients are summed inside the GEMMs
-        kv_acc = ops.KVGradAccum() if (torch.is_grad_enabled() and mem.requires_grad and len(self.layers) > 1) else None
+        kv_acc = ops.KVGradAccum((mem_k, mem)) if (torch.is_grad_enabled() and mem.requires_grad and len(self.layers) > 1) else None
         for layer in self.layers:
             x = layer.forward_tokens(x, g, qpos_tab, qpos_tpos_tab, mem, mem_k, T1, lw_pos, tpos_f, Tlw_pos, kv_acc=kv_acc)
         if self.norm is not None:

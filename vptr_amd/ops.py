@@ -225,6 +225,7 @@ def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None
 
 
 _gemm_prof = None
+_opt_prof = None    # list -> FlatAdamW.step appends (slab elements, plane elements, 3 HIP events) per call (bench.py hbm roofline)
 
 
 def gemm_nfn(N):
@@ -590,7 +591,9 @@ def _flush_wgrads_side():
     side = _wgrad_side["stream"]
     side.wait_stream(cur)          # every operand recorded so far has been produced on the main stream
     with torch.cuda.stream(side):
-        _launch_wgrad_group(items)
+        # never the panel-synchronous persistent kernel here: it assumes all its workgroups resident and owns the device-wide barrier
+        # words (include/vptr_hip.h), and a side-stream launch runs beside the main stream's backward kernels
+        _launch_wgrad_group(items, allow_sync=False)
     for it in items:
         it[0].record_stream(side)
         it[1].record_stream(side)
@@ -866,9 +869,19 @@ def flat_grad_for(t):
 # ran ensure_module_planes() owns ONE flat fp32 buffer instead: a forward pass that finds every `.grad` None zero-fills it with one
 # launch, and in backward a parameter's `.grad` becomes a view of its (still zero) range -- contiguous, own shape: torch.optim and
 # clip_grad_norm_ see ordinary tensors.  A range is handed out once per fill; anything else (a `.grad` set to None by hand between two
-# backward passes, ...) falls back to a fresh zeros_like.  Difference to stock autograd: a `.grad` tensor somebody KEPT from the
-# previous iteration is overwritten by the next forward pass's fill (config.loose_grad_arena = False restores fresh tensors).
+# backward passes, ...) falls back to a fresh zeros_like.  A `.grad` tensor (or a view of one) somebody KEPT from the previous iteration
+# is never overwritten: the fill sees the extra reference on the buffer's storage and takes a new buffer for this iteration, the kept
+# tensors keep the old one alive (stock-autograd semantics; config.loose_grad_arena = False restores per-parameter tensors).
 _grad_arenas = {}     # id(param) -> (weakref(param), weakref(arena), offset); the arena itself is owned by the model's weight-plane store
+
+
+def _storage_refs(t):
+    """number of live tensors (views included) that share t's storage, + the temporary wrapper of this query; a very large number
+    when the runtime cannot tell (the arena then always takes a fresh buffer: correct, merely slower)"""
+    f = getattr(torch._C, "_storage_Use_Count", None)
+    if f is None:
+        return 1 << 30
+    return int(f(t.untyped_storage()._cdata))
 
 
 class _GradArena:
@@ -877,6 +890,7 @@ class _GradArena:
     def __init__(self, params):
         import weakref
         self.buf = torch.empty(sum(p.numel() for p in params), device=params[0].device, dtype=torch.float32)
+        self.base_refs = _storage_refs(self.buf)     # the buffer alone: anything above it at arm time is a gradient somebody kept
         self.clean = False
         self.handed = set()
         self.params = [weakref.ref(p) for p in params]
@@ -904,6 +918,11 @@ def _arm_grad_arena(arena):
         p = r()
         if p is not None and p.grad is not None:
             return
+    if _storage_refs(arena.buf) > arena.base_refs:
+        # somebody KEPT a gradient of the previous iteration (a stashed `p.grad` or a view of it: per-task gradients, logging, manual
+        # accumulation): stock autograd would never touch that tensor again, so it keeps the old buffer and this iteration gets a new one
+        arena.buf = torch.empty_like(arena.buf)
+        arena.base_refs = _storage_refs(arena.buf)
     arena.buf.zero_()
     arena.handed.clear()
     arena.clean = True
@@ -924,12 +943,26 @@ def _engine_accumulates_into(leaf):
     gradient, and writing `.grad` behind its back would hand the caller None and pollute `.grad`.  The engine is
     asked through `torch._C._will_engine_execute_node` on the leaf's AccumulateGrad node: with no explicit inputs every node of the
     graph executes (True); with inputs it answers for this node, and raises for a leaf that `autograd.grad` captures."""
-    with torch.enable_grad():
-        acc = leaf.view_as(leaf).grad_fn.next_functions[0][0]
-    try:
-        return bool(torch._C._will_engine_execute_node(acc))
-    except RuntimeError:
+    will = getattr(torch._C, "_will_engine_execute_node", None)
+    if will is None:      # a torch build without the query: take the conservative autograd hand-off
         return False
+    ent = _acc_nodes.get(id(leaf))
+    acc = ent[1] if ent is not None and ent[0]() is leaf else None
+    if acc is None:       # the AccumulateGrad node of a leaf is unique and lives as long as the leaf: look it up once per parameter
+        import weakref
+        with torch.enable_grad():
+            acc = leaf.view_as(leaf).grad_fn.next_functions[0][0]
+        if len(_acc_nodes) > 8192:
+            for k in [k for k, e in _acc_nodes.items() if e[0]() is None]:
+                del _acc_nodes[k]
+        _acc_nodes[id(leaf)] = (weakref.ref(leaf), acc)
+    try:
+        return bool(will(acc))
+    except (RuntimeError, TypeError):
+        return False
+
+
+_acc_nodes = {}    # id(leaf) -> (weakref(leaf), its AccumulateGrad node)
 
 
 def _loose_grad_for(t):
@@ -1440,21 +1473,47 @@ class KVGradAccum:
     two [Mk, K] buffers, the following ones add into them inside their input-gradient GEMM (vptr_gemm_desc.batch_accum), and the LAST
     one hands the sums to autograd -- the others return None.  One object per forward pass."""
 
-    def __init__(self):
+    def __init__(self, sources=()):
+        """sources: the shared key / value tensors themselves -- their autograd nodes tell, per backward pass, whether anybody wants
+        the gradient this object sums (a pruned pass -- torch.autograd.grad(loss, [one decoder weight]), backward(inputs=...) -- visits
+        only some of the users and needs no memory gradient at all)"""
         self.uses, self.k, self.v = 0, None, None
         self.left, self.task = 0, -1      # users still to come in the running backward pass; its graph-task id
+        self.needed = True
+        self.nodes = []
+        for t in sources:
+            if t is None or not t.requires_grad:
+                continue
+            if t.grad_fn is not None:
+                self.nodes.append(t.grad_fn)
+            else:
+                with torch.enable_grad():
+                    self.nodes.append(t.view_as(t).grad_fn.next_functions[0][0])
+
+    def _source_grad_needed(self):
+        will = getattr(torch._C, "_will_engine_execute_node", None)
+        if will is None or not self.nodes:
+            return True
+        try:
+            return any(bool(will(n)) for n in self.nodes)
+        except (RuntimeError, TypeError):
+            return True
 
     def enter_backward(self):
         """called by every user's backward; True for the first user of a backward pass.  Participation is counted per BACKWARD
-        pass (a second pass over a retained graph starts a fresh count), and a pass that ends with users missing -- a pruned
-        branch, a user that took another code path -- raises instead of silently dropping the memory's gradient."""
+        pass (a second pass over a retained graph starts a fresh count).  A pass that ends with users missing although the running
+        graph task wants the sources' gradient (a user that took another code path, a loss taken from an intermediate layer) raises
+        instead of silently handing over an incomplete sum; a pruned pass that does not want that gradient just drops the sums."""
         task = torch._C._current_graph_task_id()
         if self.left == 0 or task != self.task:
             if self.left != 0:
+                left, needed = self.left, self.needed
                 self.k = self.v = None
                 self.left = 0
-                raise RuntimeError("KVGradAccum: the previous backward pass ended with %d of %d users missing" % (self.left, self.uses))
+                if needed:
+                    raise RuntimeError("KVGradAccum: the previous backward pass ended with %d of %d users missing" % (left, self.uses))
             self.left, self.task = self.uses, task
+            self.needed = self._source_grad_needed()
             try:
                 torch.autograd.Variable._execution_engine.queue_callback(self._check_done)
             except RuntimeError:
@@ -1465,8 +1524,9 @@ class KVGradAccum:
     def _check_done(self):
         if self.left != 0:
             left, self.left, self.k, self.v = self.left, 0, None, None
-            raise RuntimeError("KVGradAccum: backward finished with %d of %d key / value users not visited: the gradient of the shared "
-                               "key / value source would be incomplete" % (left, self.uses))
+            if self.needed:
+                raise RuntimeError("KVGradAccum: backward finished with %d of %d key / value users not visited: the gradient of the shared "
+                                   "key / value source would be incomplete" % (left, self.uses))
 
 
 class _ProjAttnFn(torch.autograd.Function):

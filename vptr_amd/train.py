@@ -17,6 +17,7 @@ MI355X-first differences in *how* (not *what*):
 train_AutoEncoder.py:44-78; both NAR and FAR trainers take the optional adversarial branch (`disc=`, `lam_gan=`).
 """
 import os
+import time
 
 import torch
 import torch.nn.functional as F
@@ -191,12 +192,21 @@ class FlatAdamW:
             self.sumsq.zero_()
             check(lib.vptr_sumsq(ptr(self.grad), n, ptr(self.sumsq), stream()), "vptr_sumsq")
         self.step_dev.add_(1.0)
+        prof = ops._opt_prof
+        if prof is not None:   # bench.py's HBM roofline pass: HIP events on the launch stream around the optimizer's streaming kernels
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
         check(lib.vptr_adamw(ptr(self.flat), ptr(self.grad), ptr(self.m), ptr(self.v), n, self.lr, self.betas[0], self.betas[1],
                              self.eps, self.weight_decay, ptr(self.step_dev),
                              ptr(self.sumsq) if self.max_grad_norm is not None else None,
                              float(self.max_grad_norm or 0.0), float(grad_scale), stream()), "vptr_adamw")
+        if prof is not None:
+            ev[1].record()
         if self.planes is not None:
             self.planes.refresh()
+        if prof is not None:
+            ev[2].record()
+            prof.append((n, self.planes.wp.numel() if self.planes is not None else 0, ev))
 
 
 def _channel_last_ids(transformer):
@@ -285,11 +295,37 @@ class NARTrainer:
     # -- data-parallel gradient exchange: a few large RCCL all-reduces on the flat gradient slab ---------------------
     _grad_scale = 1.0   # factor the next optimizer step applies to the gradient slab (1 / world after a summed exchange)
 
+    comm_stats = None   # set to a dict by bench.py: per-step exchange accounting (bytes, calls, device-side exposed time, host wait time)
+
+    def _comm_begin(self):
+        st = self.comm_stats
+        if st is None:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()      # on the launch stream, behind the last kernel that produces gradients
+        return (e0, time.perf_counter())
+
+    def _comm_end(self, tok, nbytes, calls):
+        """e0 -> e1 on the launch stream brackets nothing but the wait for the collectives: the time the stream idles there is the
+        communication the step could not hide behind compute (0 when every all-reduce finished under the weight-gradient chunks)"""
+        if tok is None:
+            return
+        st = self.comm_stats
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        st.setdefault("events", []).append((tok[0], e1))
+        st["wait_host_s"] = st.get("wait_host_s", 0.0) + time.perf_counter() - tok[1]
+        st["bytes"] = st.get("bytes", 0) + int(nbytes)
+        st["calls"] = st.get("calls", 0) + int(calls)
+        st["steps"] = st.get("steps", 0) + 1
+
     def _allreduce_grads(self):
         if self.pg is None or (self.world == 1 and os.environ.get("VPTR_DP_FORCE_EXCHANGE") != "1"):
             return
         from .parallel import allreduce_sum_
+        tok = self._comm_begin()
         allreduce_sum_(self.opt.grad, self.pg, self.bucket_elems)
+        self._comm_end(tok, self.opt.grad.numel() * 4, -(-self.opt.grad.numel() // self.bucket_elems))
         self._grad_scale = 1.0 / self.world
 
     def _backward_and_exchange(self, loss):
@@ -331,8 +367,10 @@ class NARTrainer:
         ops.flush_wgrads(chunks=DP_CHUNKS, on_chunk=send_upto)
         if sent[0] < n:
             send_upto(None)
+        tok = self._comm_begin()
         for w in works:
             w.wait()
+        self._comm_end(tok, n * 4, len(works))
         self._grad_scale = 1.0 / self.world   # the mean over ranks is folded into the optimizer kernel (FlatAdamW.step(grad_scale)): no extra pass over the slab
 
     def losses(self, pred_frames, future, pred_feats, future_feats):
