@@ -658,6 +658,15 @@ def main():
         # config 5: KTH 128 x 128 10 -> 40, 16 x 16 feature maps, 8 x 8 windows (152.6 M parameters)
         ("step_kth128_digest", lambda n: step_case(ref, n, dict(k64, Tf=40, H=16, W=16, window_size=8), 528, 128, 1, 105, steps=2,
                                                     sample=1024)),
+        # ---- round 5: configs 4 and 5 at batch sizes that run the MULTI-ROUND GEMM grids the bench times (> 256 tiles on a 528-wide
+        # output needs > 10 880 tokens): BAIR T = 29 at N = 6 (11 136 tokens), KTH128 at the bench's own per-GPU batch 2 (20 480 tokens)
+        ("far_bair29_digest_n6", lambda n: transformer_case(ref, n, dict(far, Tf=28, Tin=29), True, 6, 56, full=False, check64=False)),
+        ("nar_kth128_digest_n2", lambda n: transformer_case(ref, n, dict(k64, Tf=40, H=16, W=16, window_size=8), False, 2, 57, full=False,
+                                                             check64=False)),
+        ("step_bair29_n6_digest", lambda n: far_step_case(ref, n, dict(far, Tf=28, Tin=29), 528, 64, 6, 107, steps=2, cimg=3,
+                                                           padding_type="zero", out_layer="Tanh", norm="bair", sample=1024)),
+        ("step_kth128_n2_digest", lambda n: step_case(ref, n, dict(k64, Tf=40, H=16, W=16, window_size=8), 528, 128, 2, 108, steps=2,
+                                                       sample=1024)),
     ]
     only = sys.argv[1:]
     for name, fn in cases:

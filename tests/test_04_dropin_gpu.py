@@ -125,3 +125,55 @@ def test_script_mode_state_is_released_with_the_model(dev):
     assert all(r() is not None for r in ops._wplane_stores) or True
     live = [k for k, e in ops._grad_arenas.items() if e[1]() is not None]
     assert not live, "arena entries of a dead model are still live"
+
+
+def test_kept_gradients_survive_the_next_iteration(dev):
+    """stock-autograd semantics of the script-mode gradient arena: a gradient tensor -- or a view of one -- that the
+    caller KEPT across `zero_grad(set_to_none=True)` (per-task gradient stashing, logging, manual accumulation) must not be touched by
+    the next iteration's zero fill; the arena notices the extra reference on its buffer and moves to a fresh one"""
+    T, x = _tiny_nar(dev)
+    names = dict(T.named_parameters())
+    w = next(p for n, p in names.items() if n.endswith("linear1.weight"))
+    T.zero_grad(set_to_none=True)
+    T(x).square().mean().backward()
+    st = T.__dict__["_vptr_planes"]
+    buf0 = st.grad_arena.buf.data_ptr()
+    assert buf0 <= w.grad.data_ptr() < buf0 + st.grad_arena.buf.numel() * 4
+    kept, kept_view = w.grad, next(p for n, p in names.items() if n.endswith("linear2.weight")).grad.view(-1)[:64]
+    ref, ref_view = kept.detach().clone(), kept_view.detach().clone()
+    T.zero_grad(set_to_none=True)
+    T(2.0 * x).square().mean().backward()                # a different input: different gradients, freshly zero-filled destination
+    assert torch.equal(kept, ref) and torch.equal(kept_view, ref_view), "a kept gradient was overwritten by the next iteration"
+    assert w.grad is not kept and w.grad.data_ptr() != kept.data_ptr()
+    assert float((w.grad - ref).norm()) > 1e-3 * float(ref.norm())
+    # nothing kept: the arena goes back to re-using one buffer
+    del kept, kept_view
+    T.zero_grad(set_to_none=True)
+    T(x).square().mean().backward()
+    b1 = st.grad_arena.buf.data_ptr()
+    T.zero_grad(set_to_none=True)
+    T(x).square().mean().backward()
+    assert st.grad_arena.buf.data_ptr() == b1
+    assert float((w.grad - ref).norm()) <= 1e-4 * float(ref.norm()) + 1e-7
+
+
+def test_pruned_backward_passes_do_not_need_the_memory_gradient(dev):
+    """`torch.autograd.grad(loss, [a parameter of the LAST decoder layer])` / `backward(inputs=...)` visit only some of the decoder
+    layers' encoder-decoder attentions and do not want the shared memory's gradient at all: ops.KVGradAccum must let such a pass end
+    quietly (it used to raise "users not visited"), and the next full backward pass must still be complete"""
+    T, x = _tiny_nar(dev)
+    x.requires_grad_(True)
+    names = dict(T.named_parameters())
+    last = [n for n in names if "decoder.layers.1." in n and n.endswith("linear2.weight")][0]
+    T(x).square().mean().backward()
+    ref_w, ref_x = names[last].grad.detach().clone(), x.grad.detach().clone()
+    for p in T.parameters():
+        p.grad = None
+    x.grad = None
+    (g,) = torch.autograd.grad(T(x).square().mean(), [names[last]])
+    assert float((g - ref_w).norm()) <= 1e-4 * float(ref_w.norm()) + 1e-7
+    T(x).square().mean().backward(inputs=[names[last]])
+    assert float((names[last].grad - ref_w).norm()) <= 1e-4 * float(ref_w.norm()) + 1e-7
+    names[last].grad = None
+    T(x).square().mean().backward()                        # a full pass afterwards: memory gradient complete
+    assert float((x.grad - ref_x).norm()) <= 1e-4 * float(ref_x.norm()) + 1e-7

@@ -10,6 +10,8 @@ norm and a strided sample of every post-step parameter tensor):
   config 4  BAIR FAR 2 -> 28: VPTRFormerFAR(2, 28, 12 layers, RPE), T_in = 29, 3-channel frames, zero padding, BAIR normalisation
             (train_FAR.py:48-101; train_FAR_mp.py:289-300; utils/dataset.py:47-50)                     step_bair29_digest
   config 5  KTH 128 x 128 10 -> 40: 16 x 16 feature maps, 8 x 8 windows, 152.6 M parameters           step_kth128_digest
+  round 5   configs 4 and 5 again at batch sizes that run multi-round GEMM grids: BAIR N = 6 (11 136 tokens), KTH128 N = 2 (the bench's
+            per-GPU batch, 20 480 tokens; two panel-synchronous weight-gradient launches)   step_bair29_n6_digest, step_kth128_n2_digest
 
 Bars: loss terms 1e-3 (north_star), gradient norm 2e-3, post-step parameters 2e-4 rel-L2 over the sampled elements with at most 3 %
 of the sampled updates off by more than lr / 2 (the first AdamW updates are ~lr * sign(g): helpers.sampled_post_params_close)."""
@@ -35,7 +37,7 @@ def _release():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("fixture", ["step_mnist_digest", "step_kth128_digest"])
+@pytest.mark.parametrize("fixture", ["step_mnist_digest", "step_kth128_digest", "step_kth128_n2_digest"])
 def test_nar_config_step_digest(pkg, dev, fixture):
     from vptr_amd.train import NARTrainer
     z = load(fixture)
@@ -60,9 +62,10 @@ def test_nar_config_step_digest(pkg, dev, fixture):
     _release()
 
 
-def test_far_bair29_step_digest(pkg, dev):
+@pytest.mark.parametrize("fixture", ["step_bair29_digest", "step_bair29_n6_digest"])
+def test_far_bair29_step_digest(pkg, dev, fixture):
     from vptr_amd.train import FARTrainer
-    z = load("step_bair29_digest")
+    z = load(fixture)
     cfg, meta = jload(z, "cfg"), jload(z, "meta")
     assert meta["cimg"] == 3 and meta["padding_type"] == "zero" and cfg["Tp"] + cfg["Tf"] - 1 == 29
     enc = pkg.VPTREnc(meta["cimg"], meta["feat"], 3, meta["padding_type"])

@@ -120,6 +120,86 @@ __global__ __launch_bounds__(256, 4) void conv7_in_fwd2_kernel(const float* __re
   }
 }
 
+// Colour images (BAIR: Cimg = 3), same idea: lane = output channel.  The 49 taps of ONE input channel sit in registers at a time, so
+// the accumulators cover a whole row chunk of up to 64 outputs (16 quads) and the channel loop is outermost per chunk: 49 tap loads per
+// (row chunk, input channel) against 64 x 49 FMAs.  Input x [B][Cimg][H][W], weights [64][Cimg][7][7].
+__global__ __launch_bounds__(256, 2) void conv7_in_fwd2c_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              float* __restrict__ y, int B, int Cimg, int H, int W, int rows_per_wg, int planes) {
+  extern __shared__ __attribute__((aligned(16))) float c7_sx[];   // [Cimg][rows + 6][GW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bands = (H + rows_per_wg - 1) / rows_per_wg;
+  const int b = blockIdx.x / bands, band = blockIdx.x % bands;
+  const int oy_a = band * rows_per_wg, oy_b = min(H, oy_a + rows_per_wg);
+  const int GW = W + 8, trows = oy_b - oy_a + 6, tsz = trows * GW;
+  const float* xb = x + (int64_t)b * Cimg * H * W;
+  for (int i = tid; i < Cimg * tsz; i += 256) {
+    const int ci = i / tsz, r = i - ci * tsz;
+    const int t = r / GW, c = r - t * GW;
+    c7_sx[i] = c < W + 6 ? xb[((int64_t)ci * H + reflect_idx(oy_a - 3 + t, H)) * W + reflect_idx(c - 3, W)] : 0.f;
+  }
+  const float sc = scale ? scale[lane] : 1.f, sh = scale ? shift[lane] : 0.f;
+  __syncthreads();
+  for (int oy = oy_a + wave; oy < oy_b; oy += 4) {
+    for (int xc = 0; xc < W; xc += 64) {
+      const int nq = min(16, (W - xc) >> 2);
+      float acc[16][4];
+#pragma unroll
+      for (int qi = 0; qi < 16; ++qi)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[qi][j] = 0.f;
+      for (int ci = 0; ci < Cimg; ++ci) {
+        float wr[7][7];
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 7; ++kx) wr[ky][kx] = w[(lane * Cimg + ci) * 49 + ky * 7 + kx];
+        const float* tile = c7_sx + ci * tsz + (oy - oy_a) * GW + xc;
+#pragma unroll
+        for (int qi = 0; qi < 16; ++qi) {
+          if (qi < nq) {   // wave-uniform
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky) {
+              const float4* xp = reinterpret_cast<const float4*>(tile + ky * GW + 4 * qi);
+              const float4 a0 = xp[0], a1 = xp[1], a2 = xp[2];
+              const float xw[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+#pragma unroll
+              for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[qi][j] += wr[ky][kx] * xw[j + kx];
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+      }
+      if (planes) {
+        unsigned char* prow = reinterpret_cast<unsigned char*>(y) + (((int64_t)b * H + oy) * W + xc) * 256 + (lane >> 5) * 128 + (lane & 31) * 2;
+#pragma unroll
+        for (int qi = 0; qi < 16; ++qi) {
+          if (qi < nq) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              uint32_t h, l;
+              vptr_split2(scale ? fmaxf(acc[qi][j] * sc + sh, 0.f) : acc[qi][j], 0.f, h, l);
+              *reinterpret_cast<uint16_t*>(prow + (qi * 4 + j) * 256) = (uint16_t)h;
+              *reinterpret_cast<uint16_t*>(prow + (qi * 4 + j) * 256 + 64) = (uint16_t)l;
+            }
+          }
+        }
+      } else {
+        float* yrow = y + (((int64_t)b * H + oy) * W + xc) * 64 + lane;
+#pragma unroll
+        for (int qi = 0; qi < 16; ++qi) {
+          if (qi < nq) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) yrow[(int64_t)(qi * 4 + j) * 64] = scale ? fmaxf(acc[qi][j] * sc + sh, 0.f) : acc[qi][j];
+          }
+        }
+      }
+    }
+  }
+}
+
 extern "C" int vptr_conv7_in_fwd(const float* x, const float* w, const float* scale, const float* shift, float* y, int B,
                                  int Cimg, int H, int W, int Cout, vptr_stream_t stream) {
   VPTR_CHECK(B > 0 && Cimg > 0 && H > 3 && W > 3, "conv7_in_fwd: bad arguments");
@@ -127,6 +207,12 @@ extern "C" int vptr_conv7_in_fwd(const float* x, const float* w, const float* sc
   if (Cimg == 1 && W % 4 == 0 && W <= 1024) {
     const int rpw = 8, bands = (H + rpw - 1) / rpw;
     conv7_in_fwd2_kernel<<<B * bands, 256, sizeof(float) * (rpw + 6) * (W + 8), (hipStream_t)stream>>>(x, w, scale, shift, y, B, H, W, rpw, 0);
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
+  if (Cimg <= 4 && W % 4 == 0 && W <= 512) {   // colour images (BAIR): the row-wide variant of the same kernel
+    const int rpw = 8, bands = (H + rpw - 1) / rpw;
+    conv7_in_fwd2c_kernel<<<B * bands, 256, sizeof(float) * Cimg * (rpw + 6) * (W + 8), (hipStream_t)stream>>>(x, w, scale, shift, y, B, Cimg, H, W, rpw, 0);
     VPTR_LAUNCH_CHECK();
     return 0;
   }
@@ -142,10 +228,16 @@ extern "C" int vptr_conv7_in_fwd(const float* x, const float* w, const float* sc
 // row the caller zeroed once; single-channel images only (the second-generation kernel)
 extern "C" int vptr_conv7_in_fwd_planes(const float* x, const float* w, const float* scale, const float* shift, void* planes, int B,
                                         int Cimg, int H, int W, int Cout, vptr_stream_t stream) {
-  VPTR_CHECK(B > 0 && Cimg == 1 && H > 3 && W > 3 && W % 4 == 0 && W <= 1024 && Cout == 64 && planes,
-             "conv7_in_fwd_planes: single-channel images, Cout = 64, W %% 4 == 0");
+  VPTR_CHECK(B > 0 && Cimg >= 1 && Cimg <= 4 && H > 3 && W > 3 && W % 4 == 0 && W <= (Cimg == 1 ? 1024 : 512) && Cout == 64 && planes,
+             "conv7_in_fwd_planes: 1 - 4 image channels, Cout = 64, W %% 4 == 0");
   VPTR_CHECK((reinterpret_cast<uintptr_t>(planes) & 127) == 0, "conv7_in_fwd_planes: the plane buffer must be 128-byte aligned");
   const int rpw = 8, bands = (H + rpw - 1) / rpw;
+  if (Cimg > 1) {
+    conv7_in_fwd2c_kernel<<<B * bands, 256, sizeof(float) * Cimg * (rpw + 6) * (W + 8), (hipStream_t)stream>>>(x, w, scale, shift, reinterpret_cast<float*>(planes), B,
+                                                                                                             Cimg, H, W, rpw, 1);
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
   conv7_in_fwd2_kernel<<<B * bands, 256, sizeof(float) * (rpw + 6) * (W + 8), (hipStream_t)stream>>>(x, w, scale, shift, reinterpret_cast<float*>(planes), B, H, W,
                                                                                                    rpw, 1);
   VPTR_LAUNCH_CHECK();
@@ -216,6 +308,8 @@ __global__ __launch_bounds__(256) void conv7_out_fwd_kernel(const float* __restr
 // reads the 10 x 22 input pixel vectors of the patch once (3.4 coalesced loads per output instead of 7) and finishes all 64 outputs
 // with ONE transposing reduction (63 shuffles: after step s a lane keeps the half of the values whose index bit equals its lane
 // bit) instead of 64 full wave reductions; lane l then owns output l of the patch.
+// Several output channels (BAIR: 3): gridDim.y = output channel -- the same patch is computed once per channel (the input vectors come
+// from L2 the second and third time; keeping 3 x 64 accumulators per lane instead would not fit the register file).
 __global__ __launch_bounds__(256, 2) void conv7_out_fwd2_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
                                                              int out_act) {
@@ -223,6 +317,8 @@ __global__ __launch_bounds__(256, 2) void conv7_out_fwd2_kernel(const float* __r
   const int px = W >> 4, py = H >> 2;
   const int64_t patch = (int64_t)blockIdx.x * 4 + (tid >> 6);
   if (patch >= (int64_t)B * py * px) return;
+  const int co = blockIdx.y, Cimg = gridDim.y;
+  w += (int64_t)co * 64 * 49;
   const int pxi = (int)(patch % px), pyi = (int)((patch / px) % py), b = (int)(patch / ((int64_t)px * py));
   const int x0 = pxi * 16, y0 = pyi * 4;
   float wr[7][7];
@@ -265,19 +361,19 @@ __global__ __launch_bounds__(256, 2) void conv7_out_fwd2_kernel(const float* __r
       acc[i] = keep + __shfl_xor(send, s, 64);
     }
   }
-  float v = acc[0] + bias[0];
+  float v = acc[0] + bias[co];
   if (out_act == 1) v = tanhf(v);
   else if (out_act == 2) v = 1.f / (1.f + __expf(-v));
-  y[((int64_t)b * H + y0 + (lane >> 4)) * W + x0 + (lane & 15)] = v;
+  y[(((int64_t)b * Cimg + co) * H + y0 + (lane >> 4)) * W + x0 + (lane & 15)] = v;
 }
 
 extern "C" int vptr_conv7_out_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
                                   int Cimg, int out_act, vptr_stream_t stream) {
   VPTR_CHECK(B > 0 && H > 3 && W > 3 && Cimg > 0, "conv7_out_fwd: bad arguments");
   VPTR_CHECK(Cin == 64, "conv7_out_fwd: Cin must be 64 (ngf of the reference decoder), got %d", Cin);
-  if (Cimg == 1 && H % 4 == 0 && W % 16 == 0) {
+  if (Cimg <= 4 && H % 4 == 0 && W % 16 == 0) {
     const int64_t patches = (int64_t)B * (H / 4) * (W / 16);
-    conv7_out_fwd2_kernel<<<cdiv(patches, 4), 256, 0, (hipStream_t)stream>>>(x, w, bias, y, B, H, W, out_act);
+    conv7_out_fwd2_kernel<<<dim3((unsigned)cdiv(patches, 4), Cimg), 256, 0, (hipStream_t)stream>>>(x, w, bias, y, B, H, W, out_act);
     VPTR_LAUNCH_CHECK();
     return 0;
   }
@@ -359,28 +455,32 @@ __global__ __launch_bounds__(256) void conv7_out_bwd_data_kernel(const float* __
 template <int WT>
 __global__ __launch_bounds__(256, 2) void conv7_out_bwd_data2_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                      const float* __restrict__ w, float* __restrict__ dx, int B, int H,
-                                                                     int out_act, int rows_per_wg) {
-  extern __shared__ __attribute__((aligned(16))) float c7_sgd[];   // [H + 12][GW]: row t = output row t - 6, column c = output column c - 8
+                                                                     int out_act, int rows_per_wg, int Cimg) {
+  extern __shared__ __attribute__((aligned(16))) float c7_sgd[];   // [Cimg][H + 12][GW]: row t = output row t - 6, column c = output column c - 8
   constexpr int PC = WT + 6, NG = (PC + 3) / 4, GW = 4 * NG + 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bands = (H + rows_per_wg - 1) / rows_per_wg;
   const int b = blockIdx.x / bands, band = blockIdx.x % bands;
   const int iy_a = band * rows_per_wg, iy_b = min(H, iy_a + rows_per_wg);
-  for (int i = tid; i < (H + 12) * GW; i += 256) {
-    const int t = i / GW, c = i - t * GW;
+  const int tsz = (H + 12) * GW;
+  for (int i = tid; i < Cimg * tsz; i += 256) {
+    const int co = i / tsz, r = i - co * tsz;
+    const int t = r / GW, c = r - t * GW;
     const int oy = t - 6, ox = c - 8;
     float g = 0.f;
     if (oy >= 0 && oy < H && ox >= 0 && ox < WT) {
-      const int64_t o = ((int64_t)b * H + oy) * WT + ox;
+      const int64_t o = (((int64_t)b * Cimg + co) * H + oy) * WT + ox;
       g = out_act_grad(dy[o], y[o], out_act);
     }
     c7_sgd[i] = g;
   }
   float wr[7][7];
+  if (Cimg == 1) {
 #pragma unroll
-  for (int ky = 0; ky < 7; ++ky)
+    for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
-    for (int kx = 0; kx < 7; ++kx) wr[ky][kx] = w[lane * 49 + ky * 7 + kx];
+      for (int kx = 0; kx < 7; ++kx) wr[ky][kx] = w[lane * 49 + ky * 7 + kx];
+  }
   __syncthreads();
   for (int iy = iy_a + wave; iy < iy_b; iy += 4) {
     int qs[3], nq = 1;                       // pre-image rows (coordinates of the unpadded image; the padded row is q + 3)
@@ -394,8 +494,15 @@ __global__ __launch_bounds__(256, 2) void conv7_out_bwd_data2_kernel(const float
       float dp[4 * HG];                       // dp[l] = padded column 4 * HG * half + l, summed over pre-image rows and taps
 #pragma unroll
       for (int i = 0; i < 4 * HG; ++i) dp[i] = 0.f;
-      for (int a = 0; a < nq; ++a) {
-        const float* grow = c7_sgd + (qs[a] + 3 + 6) * GW + 4 * HG * half;   // tile row of ky = 0 (output row q + 3); ky steps one row up
+      for (int ca = 0; ca < Cimg * nq; ++ca) {
+        const int co = ca / nq, a = ca - co * nq;
+        if (Cimg > 1 && a == 0) {   // the taps of output channel co (weights [Cimg][64][7][7]); single-channel images keep theirs for the whole kernel
+#pragma unroll
+          for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) wr[ky][kx] = w[(co * 64 + lane) * 49 + ky * 7 + kx];
+        }
+        const float* grow = c7_sgd + co * tsz + (qs[a] + 3 + 6) * GW + 4 * HG * half;   // tile row of ky = 0 (output row q + 3); ky steps one row up
 #pragma unroll
         for (int ky = 0; ky < 7; ++ky) {     // one tile row at a time: its 16-byte reads overlap between neighbouring groups and are shared
 #pragma unroll
@@ -432,10 +539,15 @@ extern "C" int vptr_conv7_out_bwd_data(const float* dy, const float* y, const fl
                                        int Cimg, int out_act, vptr_stream_t stream) {
   VPTR_CHECK(B > 0 && Cin > 0 && Cin % 16 == 0 && 256 % (Cin / 16) == 0 && H > 6 && W > 6 && Cimg > 0,
              "conv7_out_bwd_data: bad arguments");
-  if (Cimg == 1 && Cin == 64 && W == 64 && H <= 256) {
+  const size_t lds2 = sizeof(float) * Cimg * (H + 12) * (4 * ((64 + 6 + 3) / 4) + 8);
+  if (Cimg <= 4 && Cin == 64 && W == 64 && lds2 <= 80 * 1024) {
     const int rpw = 8, bands = (H + rpw - 1) / rpw;
-    const size_t lds2 = sizeof(float) * (H + 12) * (4 * ((64 + 6 + 3) / 4) + 8);
-    conv7_out_bwd_data2_kernel<64><<<B * bands, 256, lds2, (hipStream_t)stream>>>(dy, y, w, dx, B, H, out_act, rpw);
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)conv7_out_bwd_data2_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      attr = true;
+    }
+    conv7_out_bwd_data2_kernel<64><<<B * bands, 256, lds2, (hipStream_t)stream>>>(dy, y, w, dx, B, H, out_act, rpw, Cimg);
     VPTR_LAUNCH_CHECK();
     return 0;
   }

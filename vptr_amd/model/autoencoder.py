@@ -165,12 +165,12 @@ class ResnetEncoder(nn.Module):
         x = x.contiguous().float()
         scale, shift = _bn_eval(m[2])
         ngf = m[1].weight.shape[0]
-        # frozen encoder (stage 2) on single-channel images: the whole down-sampling chain in plane form as well -- the 7x7 kernel writes
+        # frozen encoder (stage 2), 1 - 4 image channels: the whole down-sampling chain in plane form as well -- the 7x7 kernel writes
         # its output as bf16 hi / lo planes, every strided 3x3 convolution reads planes and writes planes (persistent, zero-initialised
         # buffers: pad channels and the all-zero row are never touched), the last one straight into the ResnetBlocks' first buffer
         # (n_downsampling >= 1: the loop below is what produces the fp32 residual `y` of the first ResnetBlock.  The persistent plane /
         # head buffers are per-module scratch keyed on shape: one forward at a time per module, i.e. one stream -- as every caller here)
-        chain = (ops.config.weights_frozen and self.n_downsampling >= 1 and Cimg == 1 and W % 4 == 0 and ngf == 64 and os.environ.get("VPTR_ENC_PLANES", "1") != "0"
+        chain = (ops.config.weights_frozen and self.n_downsampling >= 1 and (Cimg == 1 or (Cimg <= 4 and W <= 512)) and W % 4 == 0 and ngf == 64 and os.environ.get("VPTR_ENC_PLANES", "1") != "0"
                  and os.environ.get("VPTR_ENC_PLANES_HEAD", "1") != "0"
                  and all(m[4 + 3 * i].weight.shape[1] % 32 == 0 and m[4 + 3 * i].weight.shape[0] % 4 == 0 for i in range(self.n_downsampling)))
         y = None

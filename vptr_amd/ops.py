@@ -706,38 +706,58 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
                 subs.append((ap, bp, dp, rp, lda, ldb, ldd, rows_, cols_, M, alpha, flip))
         if p16 and config.wgrad_split:
             subs.sort(key=lambda t: (0 if t[7] >= 128 else 1, -t[7] * t[8], t[1], t[2]))   # full-tile problems first (largest first), remainders last
-        n = len(subs)
-        descs = (GemmDesc * n)()
-        starts = []
-        total = 0
-        for i, (ap, bp, dp, rp, lda, ldb, ldd, rows_, cols_, M, alpha, flip) in enumerate(subs):
-            d = descs[i]
-            d.precision, d.split_k, d.atomic, d.alpha = prec, 1, int(atomic), alpha
-            d.A, d.B, d.D, d.a_rowsum = ap, bp, dp, (rp or None)
-            d.lda, d.ldb, d.ldd = lda, ldb, ldd
-            d.M, d.N, d.K = rows_, cols_, M
-            d.d_transposed = int(flip)
-            d.a_mode, d.b_mode = (A_P16T, B_P16T) if p16 else (1, 1)
-            starts.append(total)
-            total += ((rows_ + 127) // 128) * ((cols_ + cols - 1) // cols)
-        if allow_sync and p16 and atomic and len({sub[9] for sub in subs}) == 1:
-            descs[0].split_k = -1     # every problem walks the same number of tokens: the panel-synchronous launch may serve the group (VPTR_WGRAD_SYNC)
+        def tiles_of(sub):
+            return ((sub[7] + 127) // 128) * ((sub[8] + cols - 1) // cols)
+        # the panel-synchronous persistent launch needs ONE token count per launch (its barrier counts K-blocks): problems are classed by
+        # token count, every class of >= 1024 tiles gets a launch of its own, the rest share a plain launch.  K64 / BAIR: one class.  KTH128
+        # 10 -> 40: encoder layers (10 frames of tokens) and decoder layers (40 frames) = two persistent launches instead of one plain launch
+        # that re-fetched every operand panel 5x over the fabric (80 GB per launch, profiles/r05_cfg5_kernel_stats.md).
+        launches = [(subs, False)]
+        if allow_sync and p16 and atomic:
+            classes = {}
+            for sub in subs:
+                classes.setdefault(sub[9], []).append(sub)
+            if len(classes) == 1:
+                launches = [(subs, True)]
+            else:
+                big = [(t, c) for t, c in classes.items() if sum(tiles_of(x) for x in c) >= 1024]
+                rest = [x for t, c in classes.items() if sum(tiles_of(y) for y in c) < 1024 for x in c]
+                launches = [(c, True) for _, c in sorted(big, key=lambda tc: -tc[0])] + ([(rest, False)] if rest else [])
         dev = grp[0][0].device
         import struct
-        raw = _to_device_async(bytes(descs), dev)
-        st = _to_device_async(struct.pack("%di" % len(starts), *starts), dev)
-        prof = _gemm_prof
-        if prof is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        check(lib.vptr_gemm_grouped(ctypes.byref(descs[0]), ptr(raw), ptr(st), n, total, stream()), "vptr_gemm_grouped")
-        if prof is not None:
-            e1.record()
-            # (which kernel the launcher picks for this group: the panel-synchronous persistent one needs VPTR_WGRAD_SYNC != 0 (default 16), the
-            # uniform-token vouch and >= 1024 tiles -- mirrored here so that bench.py names the kernel rocprofv3 will list)
-            sync = p16 and atomic and descs[0].split_k == -1 and total >= 1024 and os.environ.get("VPTR_WGRAD_SYNC", "16") not in ("0", "")
-            prof.append(((cols // 16, prec, 6 if p16 else 1, 4 if p16 else 1, ("grouped_sync" if sync else "grouped") if atomic else "grouped_split"),
-                         flops, e0, e1))
+        for lsubs, vouch in launches:
+            n = len(lsubs)
+            descs = (GemmDesc * n)()
+            starts = []
+            total = 0
+            lflops = 0.0
+            for i, (ap, bp, dp, rp, lda, ldb, ldd, rows_, cols_, M, alpha, flip) in enumerate(lsubs):
+                d = descs[i]
+                d.precision, d.split_k, d.atomic, d.alpha = prec, 1, int(atomic), alpha
+                d.A, d.B, d.D, d.a_rowsum = ap, bp, dp, (rp or None)
+                d.lda, d.ldb, d.ldd = lda, ldb, ldd
+                d.M, d.N, d.K = rows_, cols_, M
+                d.d_transposed = int(flip)
+                d.a_mode, d.b_mode = (A_P16T, B_P16T) if p16 else (1, 1)
+                starts.append(total)
+                total += tiles_of(lsubs[i])
+                lflops += 2.0 * rows_ * cols_ * M
+            if vouch:
+                descs[0].split_k = -1     # every problem walks the same number of tokens: the panel-synchronous launch may serve the group (VPTR_WGRAD_SYNC)
+            raw = _to_device_async(bytes(descs), dev)
+            st = _to_device_async(struct.pack("%di" % len(starts), *starts), dev)
+            prof = _gemm_prof
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(lib.vptr_gemm_grouped(ctypes.byref(descs[0]), ptr(raw), ptr(st), n, total, stream()), "vptr_gemm_grouped")
+            if prof is not None:
+                e1.record()
+                # (which kernel the launcher picks for this group: the panel-synchronous persistent one needs VPTR_WGRAD_SYNC != 0 (default 16), the
+                # uniform-token vouch and >= 1024 tiles -- mirrored here so that bench.py names the kernel rocprofv3 will list)
+                sync = p16 and atomic and vouch and total >= 1024 and os.environ.get("VPTR_WGRAD_SYNC", "16") not in ("0", "")
+                prof.append(((cols // 16, prec, 6 if p16 else 1, 4 if p16 else 1, ("grouped_sync" if sync else "grouped") if atomic else "grouped_split"),
+                             lflops, e0, e1))
 
 
 def convt_weight_grads(layers, tokens_per_split=2560):
