@@ -424,7 +424,60 @@ def other_configs(dev, dropout, skip=()):
     except Exception as e:  # noqa
         out["drop_in_single_iter"] = {"error": str(e)[:160]}
     torch.cuda.empty_cache()
+    # ---- the same recipe the way the reference's DATA-PARALLEL script drives it: Enc / Dec / transformer wrapped in stock
+    # DistributedDataParallel, the projector reached through `.module` (train_NAR_mp.py:94-118,132-189), here in a ONE-rank RCCL group
+    # (what a one-GPU box can run: DDP's reducer, bucket copies and per-parameter autograd hooks are all live; the all-reduces are no-ops)
+    try:
+        out["drop_in_ddp_single_iter"] = _ddp_script_iter(dev, dropout)
+    except Exception as e:  # noqa
+        out["drop_in_ddp_single_iter"] = {"error": str(e)[:200]}
+    torch.cuda.empty_cache()
     return out
+
+
+def _ddp_script_iter(dev, dropout):
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    import vptr_amd.model as M
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(_free_port())
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        enc, dec, T = build_models(dev, dropout)
+        Enc, Dec = DDP(enc, device_ids=[dev.index]).eval(), DDP(dec, device_ids=[dev.index]).eval()
+        opt = torch.optim.AdamW(T.parameters(), lr=1e-4)
+        TD = DDP(T, device_ids=[dev.index])
+        proj = TD.module.NCE_projector
+        mse, gdl = M.MSELoss(), M.GDL(alpha=1)
+        bp = M.BiPatchNCE(PER_GPU_BATCH, TF, 8, 8, 1.0).to(dev)
+        past, fut = synth_batch(PER_GPU_BATCH, 0, dev)
+
+        def it():
+            with torch.no_grad():
+                pf, ff = Enc(past), Enc(fut)
+            TD.train()
+            TD.zero_grad(set_to_none=True)
+            Dec.zero_grad(set_to_none=True)
+            pred_f = TD(pf)
+            pred = Dec(pred_f)
+            a = proj(pred_f.permute(0, 1, 3, 4, 2)).permute(0, 1, 4, 2, 3)
+            b = proj(ff.permute(0, 1, 3, 4, 2)).permute(0, 1, 4, 2, 3)
+            loss = gdl(fut, pred) + mse(pred, fut) + 0.1 * bp(F.normalize(b, p=2.0, dim=2), F.normalize(a, p=2.0, dim=2))
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(TD.parameters(), max_norm=1.0, norm_type=2)
+            opt.step()
+        ms = _time_steps(it)
+        res = {"ms_per_step": round(ms, 2), "per_gpu_batch": PER_GPU_BATCH, "frames_per_s": round(PER_GPU_BATCH * TF / ms * 1e3, 1),
+               "what": "train_NAR_mp.py:132-189 recipe: DistributedDataParallel(Enc / Dec / VPTRFormerNAR) in a one-rank RCCL group, stock AdamW + "
+                       "clip_grad_norm_ + criterion classes, eager"}
+        del TD, Enc, Dec, opt, T, enc, dec
+        return res
+    finally:
+        if own_group:
+            dist.destroy_process_group()
 
 
 # ---- rank start-up ------------------------------------------------------------------------------------------------------------------

@@ -121,12 +121,25 @@ __device__ __forceinline__ void am_stage_img(unsigned char* img, const float* __
   }
 }
 
+// A / B operand fragment (8 consecutive channels 32 ks + 8 lq .. of row `row`) of one plane, read from a transposable image instead of
+// global memory: the channels of a row are contiguous inside their 16-channel block, so it is one 16-byte read.  Second generation of
+// the score products (round 5): the four query-block waves of a problem used to load and split the SAME K rows from global memory (48
+// 8-byte loads + 288 VALU per wave); now the problem's K (and V, dO) rows are staged once and every wave reads fragments from LDS.
+template <int NDF>
+__device__ __forceinline__ bf16x8 am_img_frag(const unsigned char* img, const int LKP, const int ks, const int plane, const int row, const int lq) {
+  const int df = 2 * ks + (lq >> 1);
+  typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+  u4 v = {0u, 0u, 0u, 0u};
+  if (df < NDF) v = *reinterpret_cast<const u4*>(img + am_img_off(LKP, df, plane, row, (lq & 1) * 8));
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 // S block of one wave: acc[jf] = Q[16 x hd] . K[16 jf .. +15][hd]^T for jf < njf, then bias, masks and the row softmax -> probabilities
 // pr[jf][r] of element (i = 16 qb + 4 lq + r, j = 16 jf + lr) (0 for keys that do not exist); returns nothing else.
-template <int NKS>
+template <int NKS, int NDF = 0>   // NDF > 0: K fragments come from the transposable image `kimg` (LKP rows per block) instead of global memory
 __device__ __forceinline__ void am_scores(const AmGeom& gm, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ table,
                                           const int64_t* __restrict__ rel_index, const int g, const int h, const int qb, const int njf, const int causal,
-                                          const int lr, const int lq, float (&pr)[4][4]) {
+                                          const int lr, const int lq, float (&pr)[4][4], const unsigned char* kimg = nullptr, const int LKP = 0) {
   bf16x8 qh[NKS], ql[NKS];
   {
     const int i = qb * 16 + lr;
@@ -140,12 +153,20 @@ __device__ __forceinline__ void am_scores(const AmGeom& gm, const float* __restr
     acc[jf] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (jf < njf) {
       const int j = jf * 16 + lr;
-      const float* row = k + am_krow(gm, g, min(j, gm.Lk - 1)) * gm.C + h * gm.hd;
+      if (NDF > 0) {   // rows >= Lk and channels >= hd of the image are zero
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        bf16x8 kh, kl;
-        am_load_frag(row, 32 * ks + 8 * lq, gm.hd, j < gm.Lk, kh, kl);
-        acc[jf] = am_mfma3(qh[ks], ql[ks], kh, kl, acc[jf]);
+        for (int ks = 0; ks < NKS; ++ks) {
+          const bf16x8 kh = am_img_frag<NDF>(kimg, LKP, ks, 0, j, lq), kl = am_img_frag<NDF>(kimg, LKP, ks, 1, j, lq);
+          acc[jf] = am_mfma3(qh[ks], ql[ks], kh, kl, acc[jf]);
+        }
+      } else {
+        const float* row = k + am_krow(gm, g, min(j, gm.Lk - 1)) * gm.C + h * gm.hd;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          bf16x8 kh, kl;
+          am_load_frag(row, 32 * ks + 8 * lq, gm.hd, j < gm.Lk, kh, kl);
+          acc[jf] = am_mfma3(qh[ks], ql[ks], kh, kl, acc[jf]);
+        }
       }
     }
   }
@@ -188,6 +209,22 @@ __device__ __forceinline__ void am_scores(const AmGeom& gm, const float* __restr
     for (int r = 0; r < 4; ++r) pr[jf][r] *= sum[r];
 }
 
+// store of a TRANSPOSED output block (operands swapped in the MFMA: C^T[d][i], lane (lr, lq) owns channels 16 df + 4 lq .. + 3 of row
+// lr): two 8-byte pair stores per lane (fp32) or 4 + 4 bytes per P16 plane -- a head of width 66 starts at an even channel, so pairs are
+// aligned and never straddle a P16 granule -- instead of four 4-byte (P16: eight 2-byte) stores in the untransposed layout
+__device__ __forceinline__ void am_store_quad(float* __restrict__ dst, const int64_t rowe, const int d0, const int hd, const f32x4 v, const float scale,
+                                              const int p16) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int d = d0 + 2 * c;
+    if (d < hd) {   // hd even: a pair is valid or invalid as a whole
+      const float a = v[2 * c] * scale, b = v[2 * c + 1] * scale;
+      if (p16) vptr_p16_store2(reinterpret_cast<unsigned char*>(dst), rowe + d, a, b);
+      else *reinterpret_cast<float2*>(dst + rowe + d) = make_float2(a, b);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // forward.  Workgroup = 4 waves; NQBR (1, 2 or 4) consecutive waves serve the query blocks of one problem and share its V image.
 // LDS: [4 / NQBR problem slots][V image: 2 NDF planes x LKP x 32 B]  then  [4 waves][P tile: 2 planes x 16 x pitch]
@@ -206,12 +243,21 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const float* __restr
   const int g = pvalid ? prob / gm.nh : 0, h = pvalid ? prob - g * gm.nh : 0;
   const bool active = pvalid && qb < NQB;
   const int img_bytes = 2 * NDF * LKP * 32, pitch = LKP * 2 + 16;
-  unsigned char* img = am_smem + slot * img_bytes;
-  unsigned char* ptile = am_smem + slots * img_bytes + wave * (2 * 16 * pitch);
+  unsigned char* img = am_smem + slot * 2 * img_bytes;          // V image, then the K image
+  unsigned char* kimg = img + img_bytes;
+  // the P tiles of a problem's waves take over its K image once every wave has its scores (one more barrier, a third less LDS: three
+  // workgroups per CU at 64 keys x 66 channels) when they fit there; otherwise they have a region of their own behind the images
+  const bool tiles_in_kimg = nqbr * 2 * 16 * pitch <= img_bytes;
+  unsigned char* ptile = tiles_in_kimg ? kimg + qb * (2 * 16 * pitch) : am_smem + slots * 2 * img_bytes + wave * (2 * 16 * pitch);
 
-  if (pvalid) am_stage_img(img, v, gm, g, h, LKP, NDF, tid - slot * nqbr * 64, nqbr * 64);
+  if (pvalid) {   // both operands of the problem staged once (all loads of a thread in flight together), shared by its query-block waves
+    am_stage_img(kimg, k, gm, g, h, LKP, NDF, tid - slot * nqbr * 64, nqbr * 64);
+    am_stage_img(img, v, gm, g, h, LKP, NDF, tid - slot * nqbr * 64, nqbr * 64);
+  }
+  __syncthreads();
   float pr[4][4];
-  if (active) am_scores<NKS>(gm, q, k, table, rel_index, g, h, qb, njf, causal, lr, lq, pr);
+  if (active) am_scores<NKS, NDF>(gm, q, k, table, rel_index, g, h, qb, njf, causal, lr, lq, pr, kimg, LKP);
+  if (tiles_in_kimg) __syncthreads();   // workgroup-uniform: nobody reads the K image any more
   if (active) {
     uint64_t seed = 0;
     if (p > 0.f) seed = *seed_dev;
@@ -232,9 +278,9 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const float* __restr
       }
     }
   }
-  __syncthreads();   // V image complete (all waves of the slot), P tile written (own wave)
   if (!active) return;
-  f32x4 oacc[NDF];
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the P tile is wave-private -- its own writes have landed, no barrier needed
+  f32x4 oacc[NDF];                      // O^T blocks (operands swapped: A = V^T fragment, B = P fragment): see am_store_quad
 #pragma unroll
   for (int df = 0; df < NDF; ++df) oacc[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -244,24 +290,15 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const float* __restr
 #pragma unroll
       for (int df = 0; df < NDF; ++df) {
         const bf16x8 vh = am_tr_frag(img, LKP, df, 0, kj, lr, lq), vl = am_tr_frag(img, LKP, df, 1, kj, lr, lq);
-        oacc[df] = am_mfma3(ph, pl, vh, vl, oacc[df]);
+        oacc[df] = am_mfma3(vh, vl, ph, pl, oacc[df]);
       }
     }
   }
+  const int i = qb * 16 + lr;
+  if (i < gm.Lq) {
+    const int64_t rowe = am_qrow(gm, g, i) * gm.C + h * gm.hd;
 #pragma unroll
-  for (int df = 0; df < NDF; ++df) {
-    const int d = df * 16 + lr;
-    if (d < gm.hd) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = qb * 16 + 4 * lq + r;
-        if (i < gm.Lq) {
-          const int64_t e = am_qrow(gm, g, i) * gm.C + h * gm.hd + d;
-          if (p16) vptr_p16_store1(reinterpret_cast<unsigned char*>(o), e, oacc[df][r]);
-          else o[e] = oacc[df][r];
-        }
-      }
-    }
+    for (int df = 0; df < NDF; ++df) am_store_quad(o, rowe, df * 16 + 4 * lq, gm.hd, oacc[df], 1.f, p16);
   }
 }
 
@@ -529,16 +566,21 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_shared_kernel(const float* 
   const bool pvalid = prob < gm.groups * gm.nh;
   const int g = pvalid ? prob / gm.nh : 0, h = pvalid ? prob - g * gm.nh : 0;
   const bool active = pvalid && qb < NQB;
-  const int img_bytes = 2 * NDF * IMR * 32, tab_bytes = dtable ? ((ntab * 4 + 15) & ~15) : 0;
-  const int slot_bytes = img_bytes + tab_bytes, pitch = LKP * 2 + 16, tile_stride = 4 * 16 * pitch;
+  const int img_bytes = 2 * NDF * IMR * 32, vimg_bytes = 2 * NDF * LKP * 32, tab_bytes = dtable ? ((ntab * 4 + 15) & ~15) : 0;
+  const int slot_bytes = img_bytes + vimg_bytes + tab_bytes, pitch = LKP * 2 + 16, tile_stride = 4 * 16 * pitch;
   unsigned char* img = am_smem + slot * slot_bytes;
-  float* stab = reinterpret_cast<float*>(img + img_bytes);
+  unsigned char* vimg = img + img_bytes;                      // V rows for dP = dO V^T (second generation: fragments from LDS, see am_img_frag)
+  float* stab = reinterpret_cast<float*>(vimg + vimg_bytes);
   unsigned char* tiles = am_smem + slots * slot_bytes + slot * nqbr * tile_stride;   // tiles of this problem's query blocks
   unsigned char* mytile = tiles + qb * tile_stride;                                  // [dS hi][dS lo][Pd hi][Pd lo]
   const int stid = tid - slot * nqbr * 64, snthr = nqbr * 64;
 
-  if (pvalid) am_stage_img(img, k, gm, g, h, IMR, NDF, stid, snthr);   // the image region has IMR rows in every phase
+  if (pvalid) {
+    am_stage_img(img, k, gm, g, h, IMR, NDF, stid, snthr);   // the image region has IMR rows in every phase
+    am_stage_img(vimg, v, gm, g, h, LKP, NDF, stid, snthr);
+  }
   for (int e = stid; e < tab_bytes / 4; e += snthr) stab[e] = 0.f;
+  __syncthreads();   // K and V images complete
   float ds[4][4];
 #pragma unroll
   for (int jf = 0; jf < 4; ++jf)
@@ -546,7 +588,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_shared_kernel(const float* 
     for (int r = 0; r < 4; ++r) ds[jf][r] = 0.f;
   if (active) {
     float pr[4][4];
-    am_scores<NKS>(gm, q, k, table, rel_index, g, h, qb, njf, causal, lr, lq, pr);
+    am_scores<NKS, NDF>(gm, q, k, table, rel_index, g, h, qb, njf, causal, lr, lq, pr, img, IMR);
     bf16x8 gh[NKS], gl[NKS];
     {
       const int i = qb * 16 + lr;
@@ -563,12 +605,10 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_shared_kernel(const float* 
       for (int r = 0; r < 4; ++r) pd[jf][r] = 0.f;
       if (jf < njf) {
         const int j = jf * 16 + lr;
-        const float* row = v + am_krow(gm, g, min(j, gm.Lk - 1)) * gm.C + h * gm.hd;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-          bf16x8 vh, vl;
-          am_load_frag(row, 32 * ks + 8 * lq, gm.hd, j < gm.Lk, vh, vl);
+          const bf16x8 vh = am_img_frag<NDF>(vimg, LKP, ks, 0, j, lq), vl = am_img_frag<NDF>(vimg, LKP, ks, 1, j, lq);
           acc = am_mfma3(gh[ks], gl[ks], vh, vl, acc);
         }
 #pragma unroll
@@ -602,7 +642,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_shared_kernel(const float* 
       }
     }
   }
-  __syncthreads();   // K image, zeroed table gradient, tiles of every query block
+  __syncthreads();   // tiles of every query block
   if (active && dtable) {
 #pragma unroll
     for (int jf = 0; jf < 4; ++jf) {
@@ -625,24 +665,15 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_shared_kernel(const float* 
 #pragma unroll
         for (int df = 0; df < NDF; ++df) {
           const bf16x8 kh = am_tr_frag(img, IMR, df, 0, kj, lr, lq), kl = am_tr_frag(img, IMR, df, 1, kj, lr, lq);
-          qacc[df] = am_mfma3(sh, sl, kh, kl, qacc[df]);
+          qacc[df] = am_mfma3(kh, kl, sh, sl, qacc[df]);   // dQ^T block (operands swapped: see am_store_quad)
         }
       }
     }
+    const int i = qb * 16 + lr;
+    if (i < gm.Lq) {
+      const int64_t rowe = am_qrow(gm, g, i) * gm.C + h * gm.hd;
 #pragma unroll
-    for (int df = 0; df < NDF; ++df) {
-      const int d = df * 16 + lr;
-      if (d < gm.hd) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = qb * 16 + 4 * lq + r;
-          if (i < gm.Lq) {
-            const int64_t e = am_qrow(gm, g, i) * gm.C + h * gm.hd + d;
-            if (p16) vptr_p16_store1(reinterpret_cast<unsigned char*>(dq), e, qacc[df][r] * dq_scale);
-            else dq[e] = qacc[df][r] * dq_scale;
-          }
-        }
-      }
+      for (int df = 0; df < NDF; ++df) am_store_quad(dq, rowe, df * 16 + 4 * lq, gm.hd, qacc[df], dq_scale, p16);
     }
   }
   // key-block ownership: dV (A = dropped P tiles, B = dO image) then dK (A = dS tiles, B = Q image)
@@ -666,24 +697,15 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_shared_kernel(const float* 
 #pragma unroll
             for (int df = 0; df < NDF; ++df) {
               const bf16x8 bh = am_tr_frag(img, IMR, df, 0, kq, lr, lq), bl = am_tr_frag(img, IMR, df, 1, kq, lr, lq);
-              acc[df] = am_mfma3(ah, al, bh, bl, acc[df]);
+              acc[df] = am_mfma3(bh, bl, ah, al, acc[df]);   // transposed block: lane (lr, lq) = key row lr, channels 16 df + 4 lq ..
             }
           }
         }
+        const int j = jb * 16 + lr;
+        if (j < gm.Lk) {
+          const int64_t rowe = am_krow(gm, g, j) * gm.C + h * gm.hd;
 #pragma unroll
-        for (int df = 0; df < NDF; ++df) {
-          const int d = df * 16 + lr;
-          if (d < gm.hd) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int j = jb * 16 + 4 * lq + r;
-              if (j < gm.Lk) {
-                const int64_t e = am_krow(gm, g, j) * gm.C + h * gm.hd + d;
-                if (p16) vptr_p16_store1(reinterpret_cast<unsigned char*>(dst), e, acc[df][r]);
-                else dst[e] = acc[df][r];
-              }
-            }
-          }
+          for (int df = 0; df < NDF; ++df) am_store_quad(dst, rowe, df * 16 + 4 * lq, gm.hd, acc[df], 1.f, p16);
         }
       }
     }
@@ -716,7 +738,8 @@ static int am_launch_fwd(const float* q, const float* k, const float* v, const f
                          float p, const uint64_t* seed_dev, uint32_t site, int p16, hipStream_t st) {
   const int NQB = (gm.Lq + 15) / 16, nqbr = NQB == 1 ? 1 : (NQB == 2 ? 2 : 4), slots = 4 / nqbr;
   const int LKP = (gm.Lk + 31) / 32 * 32, pitch = LKP * 2 + 16;
-  const size_t lds = (size_t)slots * 2 * NDF * LKP * 32 + 4 * 2 * 16 * pitch;
+  const size_t img_bytes = (size_t)2 * NDF * LKP * 32;
+  const size_t lds = slots * 2 * img_bytes + ((size_t)nqbr * 2 * 16 * pitch <= img_bytes ? 0 : 4 * 2 * 16 * pitch);   // K and V images per slot (+ P tiles)
   const int nprob = gm.groups * gm.nh;
   auto kern = attn_mfma_fwd_kernel<NKS, NDF>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -746,7 +769,7 @@ static int am_launch_bwd(const float* q, const float* k, const float* v, const f
   const int nprob = gm.groups * gm.nh;
   if (nqbr > 1) {   // several query blocks per problem: the tile-sharing kernel
     const int LQ32 = (gm.Lq + 31) / 32 * 32, IMR = LKP > LQ32 ? LKP : LQ32;
-    const size_t sb = (size_t)2 * NDF * IMR * 32 + (dtable ? ((ntab * 4 + 15) & ~15) : 0);
+    const size_t sb = (size_t)2 * NDF * IMR * 32 + (size_t)2 * NDF * LKP * 32 + (dtable ? ((ntab * 4 + 15) & ~15) : 0);   // K / dO / Q image, V image, table gradient
     const size_t lds2 = slots * sb + 4 * 4 * 16 * pitch;
     auto kern2 = attn_mfma_bwd_shared_kernel<NKS, NDF>;
     if (lds2 > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
