@@ -77,6 +77,20 @@ def grad_floor(norms):
     return 1e-2 * float(np.median(list(norms)))
 
 
+ZERO_CLASS = 1e-4   # a gradient whose reference norm is below ZERO_CLASS x the median gradient norm of the model is ANALYTICALLY zero
+
+
+def analytic_zero(ref_norm, norms):
+    """True for gradients that are zero in exact arithmetic -- the bias of anything that feeds a train-mode BatchNorm only (the NAR
+    encoder's `norm2.bias` and `SpatialFFN.fc1.bias`: BatchNorm subtracts the batch mean, a per-channel constant in front of it cannot
+    move the loss), the k-bias of a softmax.  The reference's own value for such a tensor is its fp32 round-off (2e-6 of the median
+    gradient norm at KTH128 N = 2), ours is the split-bf16 operand round-off (2^-17 per GEMM operand: 1.2e-5 of the median) summed over
+    20 480 tokens whose true contributions cancel exactly.  A RELATIVE error between two noises means nothing; what parity can ask is
+    that ours is zero by the same criterion that classes the reference's as zero: norm < ZERO_CLASS x median gradient norm (8x margin
+    measured).  DESIGN.md section 3 lists this class in the tolerance table."""
+    return float(ref_norm) < ZERO_CLASS * float(np.median(list(norms)))
+
+
 def post_step_params_close(state_dict, z, rel_tol=1e-4, lr=1e-4, max_flip_frac=0.02):
     """Post-step parameters vs the `post:` arrays of a golden step record.  The first AdamW updates are ~lr * sign(g), so
     elements whose gradient is analytically zero move by +-lr on rounding noise alone (and atomics make that noise

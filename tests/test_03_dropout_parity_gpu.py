@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import build_transformer, grad_floor, rel
+from helpers import ZERO_CLASS, analytic_zero, build_transformer, grad_floor, rel
 from oracle import fill
 from oracle import vptr_oracle as O
 
@@ -50,10 +50,10 @@ def test_dropout_and_droppath_masks_match_reference_semantics(dev, far, attn_ker
 def test_dropout_masks_k64_layout(dev):
     """the same check on the bench model's own layout: VPTRFormerNAR(10, 10, 8, 8, 528, 8 heads, 4 encoder + 8 decoder blocks) -- 12
     blocks x 16 call-site ids, 640-token P16 GEMM epilogues, F = 2112 conv-FFN masks -- at batch 1 with dropout 0.1 and DropPath on"""
-    # output and input gradient at the 1e-3 bar; parameter gradients at 2e-3: the worst one (encoder.layers.0.norm2.bias, 12 blocks of
-    # backward away from the loss, batch-1 BatchNorm statistics behind it) measures 1.0e-3 against the fp64 oracle and 1.1e-3 against
-    # the fp32 one -- accumulated split-bf16 operand rounding (2^-17 per GEMM operand), not a mask: a wrong mask shows as O(0.1)
-    _mask_parity(dev, False, N=1, T=10, C=528, n_enc=4, n_dec=8, param_tol=2e-3)
+    # output, input gradient and every parameter gradient at the 1e-3 bar.  (Rounds 3 - 4 ran the parameter gradients at 2e-3 because
+    # encoder.layers.0.norm2.bias measured 1.0e-3 against the floor: that tensor is ANALYTICALLY zero -- a bias in front of a train-mode
+    # BatchNorm -- and is now held to the zero criterion of helpers.analytic_zero instead of a relative error between two round-offs.)
+    _mask_parity(dev, False, N=1, T=10, C=528, n_enc=4, n_dec=8, param_tol=TOL)
 
 
 def _mask_parity(dev, far, N, T, C, n_enc, n_dec, ref_dtype=torch.float32, param_tol=TOL):
@@ -147,11 +147,18 @@ def _mask_parity(dev, far, N, T, C, n_enc, n_dec, ref_dtype=torch.float32, param
     (out * g.float().to(dev)).sum().backward()
     assert rel(xd.grad, xr.grad) < TOL, "input gradient with dropout: %.3e" % rel(xd.grad, xr.grad)
     refg = {k: v.grad for k, v in Pt.items() if v.requires_grad and v.grad is not None}
-    floor = grad_floor(float(v.norm()) for v in refg.values())
+    norms = [float(v.norm()) for v in refg.values()]
+    floor = grad_floor(norms)
+    median = float(np.median(norms))
     worst = ("", 0.0)
+    errs = []
     for k, p in m.named_parameters():
         if k in refg:
+            if analytic_zero(float(refg[k].norm()), norms):    # helpers.analytic_zero: both sides are round-off; ours must class as zero too
+                assert float(p.grad.norm()) < ZERO_CLASS * median, "analytically zero gradient %s: %.3e vs median %.3e" % (k, float(p.grad.norm()), median)
+                continue
             e = rel(p.grad, refg[k], floor)
+            errs.append((e, k))
             if e > worst[1]:
                 worst = (k, e)
-    assert worst[1] < param_tol, "parameter gradient %s with dropout: %.3e" % worst
+    assert worst[1] < param_tol, "parameter gradient %s with dropout: %.3e (next: %s)" % (worst + (sorted(errs, reverse=True)[1:4],))

@@ -323,77 +323,89 @@ struct WgSync {
   bool live;       // false after a timeout
 };
 
-template <int NSTAGE, int SYNC>   // SYNC: 0 = none, else the block length S (a power of two) of the panel-synchronous schedule
+// NW: waves per workgroup.  8 (4 x 2 waves of 32 x 96) is the round 1 - 4 geometry.  4 (2 x 2 waves of 64 x 96, round 5): the same tile and
+// stage, but every A fragment a wave reads from LDS feeds 6 column fragments and every B fragment 4 row fragments -- 40 transposing
+// reads per 72 MFMAs instead of 32 per 36, i.e. LDS read bytes per MFMA down 1.6x (at 8 waves the reads + the DMA writes of a K-step
+// need 1344 LDS cycles per workgroup against 1224 MFMA cycles per SIMD: the LDS, not the matrix pipe, was the binding unit).
+// MI: 16-row fragments per wave (tile rows TR = 16 MI NW / 2).  (NW, MI) = (8, 4): 256 x 176 tiles, 56 KB stages, ONE workgroup per CU --
+// 1.47x the flops per staged byte of the 128-row tile (the elimination builds and the 4-wave A/B both say the launch is bound by what
+// the CU can ingest through the vector-memory path, not by LDS reads or the matrix pipe).
+template <int NSTAGE, int SYNC, int NW = 8, int MI = 16 / NW>   // SYNC: 0 = none, else the block length S (a power of two) of the panel-synchronous schedule
 __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const int tile, unsigned char* p16_smem, WgSync& sy) {
-  constexpr int BN = 176;
+  constexpr int BN = 176, WM = NW / 2, TR = 16 * MI * WM;   // MI row fragments per wave, WM wave rows, TR tile rows
+  constexpr int PA = TR / 8 / NW, PB = 24 / NW;             // DMA pieces per wave and K-step: A, B
+  constexpr int AREG = TR * 128, STG = AREG + 24 * 1024;    // bytes of the A region of a stage / of a stage
   const int NG = p.M, KX = p.N, T = p.K;   // D[NG][KX] += alpha * G[T][NG]^T . X[T][KX]
   const int tiles_n = (KX + BN - 1) / BN;
-  const int m0 = (tile / tiles_n) * GBM, n0 = (tile % tiles_n) * BN;
+  const int m0 = (tile / tiles_n) * TR, n0 = (tile % tiles_n) * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 3, wn = wave >> 2, lr = lane & 15, lq = lane >> 4;   // see vptr_gemm_p16_kernel
+  const int wm = wave % WM, wn = wave / WM, lr = lane & 15, lq = lane >> 4;   // see vptr_gemm_p16_kernel
   const int nk = (T + 31) >> 5;
   const int64_t pg = p.lda * 4, px = p.ldb * 4;
   const unsigned char* Gb = reinterpret_cast<const unsigned char*>(p.A);
   const unsigned char* Xb = reinterpret_cast<const unsigned char*>(p.B);
 
-  // DMA pieces: u = wave + 8 i; A pieces u < 16: granule pair u >> 2, token block u & 3; B pieces v = u - 16 likewise
-  int colA[2], colB[3], trow[5];
+  // DMA pieces: u = wave + NW i; A pieces u < 16: granule pair u >> 2, token block u & 3; B pieces v = u - 16 likewise
+  int colA[PA], colB[PB], trow[PA + PB];
   {
     const int ms = lane >> 4, half = lane & 1, t = (lane & 15) >> 1;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int u = wave + 8 * i;
+    for (int i = 0; i < PA; ++i) {
+      const int u = wave + NW * i;
       const int gran = min((m0 >> 4) + (u >> 2) * 2 + (ms >> 1), (NG >> 4) - 1);
       colA[i] = gran * 64 + (ms & 1) * 32 + half * 16;
       trow[i] = (u & 3) * 8 + t;
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int v = wave + 8 * i;
+    for (int i = 0; i < PB; ++i) {
+      const int v = wave + NW * i;
       const int gran = min((n0 >> 4) + (v >> 2) * 2 + (ms >> 1), (KX >> 4) - 1);
       colB[i] = gran * 64 + (ms & 1) * 32 + half * 16;
-      trow[2 + i] = (v & 3) * 8 + t;
+      trow[PA + i] = (v & 3) * 8 + t;
     }
   }
   auto issue = [&](const int kt, const int stage) {
     const int t0 = kt * 32;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      P16_GLDS((uint32_t)(stage * P16_STAGE + (wave + 8 * i) * 1024), Gb + (int64_t)min(t0 + trow[i], T - 1) * pg + colA[i]);
+    for (int i = 0; i < PA; ++i)
+      P16_GLDS((uint32_t)(stage * STG + (wave + NW * i) * 1024), Gb + (int64_t)min(t0 + trow[i], T - 1) * pg + colA[i]);
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-      P16_GLDS((uint32_t)(stage * P16_STAGE + 16384 + (wave + 8 * i) * 1024), Xb + (int64_t)min(t0 + trow[2 + i], T - 1) * px + colB[i]);
+    for (int i = 0; i < PB; ++i)
+      P16_GLDS((uint32_t)(stage * STG + AREG + (wave + NW * i) * 1024), Xb + (int64_t)min(t0 + trow[PA + i], T - 1) * px + colB[i]);
   };
 
-  f32x4 acc[2][6];
+  f32x4 acc[MI][6];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 6; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // fragment f (granule f of the operand's tile), plane pl: piece (f >> 1) * 4 + lq, mini-subtile (f & 1) * 2 + pl
   const int lane_off = lq * 1024 + (lr >> 2) * 32 + (lr & 3) * 8;
   const int rb0 = (lq & 1) * 128;
-  int offA[2], offB[6];
+  int offA[MI], offB[6];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int f = wm * 2 + mi;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int f = wm * MI + mi;
     offA[mi] = (f >> 1) * 4096 + (f & 1) * 512 + lane_off;
   }
 #pragma unroll
   for (int ni = 0; ni < 6; ++ni) {
     const int f = wn * 6 + ni;
-    offB[ni] = 16384 + (f >> 1) * 4096 + (f & 1) * 512 + lane_off;
+    offB[ni] = AREG + (f >> 1) * 4096 + (f & 1) * 512 + lane_off;
   }
   // bias gradient: column tile 0 only, odd wave column, its 6th (otherwise idle) fragment multiplies by ones: acc[mi][5][r] =
   // sum_t G[t][row] for every column of the fragment
   const bool flip = p.d_transposed != 0;   // D stored transposed; a_rowsum = column sums of B, taken by a wave row beyond M (see vptr_hip.h)
   const bool want_rowsum = !flip && p.a_rowsum != nullptr && n0 == 0 && wn == 1;   // wave-uniform
-  const bool colsum_wave = flip && p.a_rowsum != nullptr && m0 + GBM > NG && wm == (NG - m0 + 31) / 32;   // wave-uniform: first wave row entirely beyond M
+  // column sums of B (flipped problems): the first 16-row FRAGMENT of the tile that lies entirely beyond M multiplies by ones instead
+  const int f0 = (NG - m0 + 15) >> 4;   // (the host admits a flipped problem with a bias only when at least 32 tile rows are free)
+  const bool colsum_wave = flip && p.a_rowsum != nullptr && f0 < TR / 16 && wm == f0 / MI;   // wave-uniform
+  const int cmi = f0 - wm * MI;          // that fragment's index among this wave's
   const __bf16 one = (__bf16)1.0f, zero = (__bf16)0.0f;
   const bf16x8 ones = {one, one, one, one, one, one, one, one};
   const bf16x8 zeros = {zero, zero, zero, zero, zero, zero, zero, zero};
   const bool ttail = (T & 31) != 0;
-  const bool rows_live = m0 + wm * 32 < NG;
+  const bool rows_live = m0 + wm * (16 * MI) < NG;
 
   issue(0, 0);
   if (NSTAGE >= 3 && nk > 1) issue(1, 1);
@@ -415,8 +427,8 @@ __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const in
         }
       }
     }
-    if (NSTAGE >= 4 && kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | 10);
-    else if (NSTAGE >= 3 && kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | 5);   // vmcnt(5): step kt landed, step kt + 1 may still fly
+    if (NSTAGE >= 4 && kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | (2 * (PA + PB)));
+    else if (NSTAGE >= 3 && kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | (PA + PB));   // vmcnt(pieces of one step): step kt landed, step kt + 1 may still fly
     else __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
     if (NSTAGE >= 3) {
@@ -425,15 +437,17 @@ __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const in
       issue(kt + 1, (kt + 1) & 1);
     }
     if (!rows_live && !colsum_wave) continue;   // wave-uniform: this wave's 32 rows lie beyond NG (the last row tile of a 528-row problem keeps 16 of 128)
-    const unsigned char* st = p16_smem + (NSTAGE >= 3 ? kt % NSTAGE : (kt & 1)) * P16_STAGE;
-    bf16x8 ah[2], al[2];
+    const unsigned char* st = p16_smem + (NSTAGE >= 3 ? kt % NSTAGE : (kt & 1)) * STG;
+    bf16x8 ah[MI], al[MI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
       ah[mi] = p16_tr_frag(st, offA[mi], rb0);
       al[mi] = p16_tr_frag(st, offA[mi] + 256, rb0);
     }
-    if (colsum_wave) {   // rows beyond M: a fragment of ONES instead -- acc[0][ni] rows all become sum_t B[t][n]
-      ah[0] = ones; al[0] = zeros; ah[1] = zeros; al[1] = zeros;
+    if (colsum_wave) {   // a fragment of rows beyond M: ONES instead -- its accumulator rows all become sum_t B[t][n]
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        if (mi == cmi) { ah[mi] = ones; al[mi] = zeros; }
     }
     if (ttail && kt == nk - 1) {   // workgroup-uniform: zero the A values of tokens beyond T
       const int tv = T - kt * 32;  // valid tokens of this step
@@ -443,7 +457,7 @@ __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const in
         const int tok = 8 * lq + 4 * ((e >> 2) ^ (lq & 1)) + (e & 3);
         if (tok >= tv) {
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi) { ah[mi][e] = zero; al[mi][e] = zero; }
+          for (int mi = 0; mi < MI; ++mi) { ah[mi][e] = zero; al[mi][e] = zero; }
         }
       }
     }
@@ -464,11 +478,20 @@ __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const in
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (NW == 8) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl[ni & 1], acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
+        for (int mi = 0; mi < MI; ++mi) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl[ni & 1], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
+        }
+      } else {   // two waves per SIMD: nobody else fills the pipe behind a dependent accumulate, so the passes go round the row fragments
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl[ni & 1], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -482,10 +505,10 @@ __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const in
     const int nf = wn * 6 + ni, col = n0 + nf * 16 + lr;
     if (nf < 11 && col < KX) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = m0 + wm * 32 + mi * 16 + lq * 4 + r;
+          const int row = m0 + (wm * MI + mi) * 16 + lq * 4 + r;
           if (row < NG) {
             float* dst = flip ? p.D + (int64_t)col * p.ldd + row : p.D + (int64_t)row * p.ldd + col;
             if (p.atomic) unsafeAtomicAdd(dst, acc[mi][ni][r] * alpha);
@@ -498,23 +521,29 @@ __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const in
 #pragma unroll
     for (int ni = 0; ni < 6; ++ni) {
       const int nf = wn * 6 + ni, col = n0 + nf * 16 + lr;
-      if (nf < 11 && col < KX) unsafeAtomicAdd(p.a_rowsum + col, acc[0][ni][0] * alpha);
+      if (nf < 11 && col < KX) {
+        float cs = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          if (mi == cmi) cs = acc[mi][ni][0];
+        unsafeAtomicAdd(p.a_rowsum + col, cs * alpha);
+      }
     }
   }
   if (want_rowsum && lr == 0) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 32 + mi * 16 + lq * 4 + r;
+        const int row = m0 + (wm * MI + mi) * 16 + lq * 4 + r;
         if (row < NG) unsafeAtomicAdd(p.a_rowsum + row, acc[mi][5][r] * alpha);
       }
   }
 }
 
 
-template <int NSTAGE, int TAG = 0>   // 2: two workgroups per CU; 3: one workgroup per CU with the DMA two K-steps ahead (experiment, VPTR_WGRAD_STAGES=3)
-__global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
+template <int NSTAGE, int TAG = 0, int NW = 8, int MI = 16 / NW>   // 2: two workgroups per CU; 3: one workgroup per CU with the DMA two K-steps ahead (experiment, VPTR_WGRAD_STAGES=3)
+__global__ __launch_bounds__(64 * NW, NSTAGE == 2 ? (NW * MI == 16 && NW == 8 ? 4 : 2) : 2) void vptr_wgrad_p16_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
                                                                 const int count, const int xmode, const int tile_base) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
   const int lg = tile_base + ((xmode & 0xff) == 1 ? (int)blockIdx.x : xcd_logical_block());
@@ -526,7 +555,7 @@ __global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kerne
     else hi = mid - 1;
   }
   WgSync none = {nullptr, 0, 0, false};
-  wgrad_p16_tile<NSTAGE, 0>(descs[lo], lg - tile_start[lo], p16_smem, none);
+  wgrad_p16_tile<NSTAGE, 0, NW, MI>(descs[lo], lg - tile_start[lo], p16_smem, none);
 }
 
 // Persistent form for the panel-synchronous schedule: gridDim.x = 8 * slots workgroups (two per CU), workgroup b serves XCD b & 7 as its
@@ -534,8 +563,8 @@ __global__ __launch_bounds__(GNT, NSTAGE == 2 ? 4 : 2) void vptr_wgrad_p16_kerne
 // tiles.  Requires every problem of the launch to have the same token count (the caller vouches: vptr_gemm_desc.split_k = -S on the
 // prototype).  g_wgrad_sync_ws: 64 ints per XCD (counter at [x * 64], leave counter at [x * 64 + 32]); the kernel leaves them zero.
 __device__ int g_wgrad_sync_ws[8 * 64];   // module-scope, zero at load; one launch of the kernel at a time (launches on ONE stream serialise)
-template <int S>
-__global__ __launch_bounds__(GNT, 4) void vptr_wgrad_p16_sync_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
+template <int S, int NW = 8, int MI = 16 / NW>
+__global__ __launch_bounds__(64 * NW, NW * MI == 16 && NW == 8 ? 4 : 2) void vptr_wgrad_p16_sync_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
                                                                     const int count, const int total_tiles) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
   int* const ws = g_wgrad_sync_ws;
@@ -556,7 +585,7 @@ __global__ __launch_bounds__(GNT, 4) void vptr_wgrad_p16_sync_kernel(const vptr_
     sy.base = r * slots * per_tile;
     sy.n = min(slots, mine - r * slots);
     if (r > 0) __syncthreads();   // the previous tile's last stage is still being read by slower waves
-    wgrad_p16_tile<2, S>(descs[lo], lg - tile_start[lo], p16_smem, sy);
+    wgrad_p16_tile<2, S, NW, MI>(descs[lo], lg - tile_start[lo], p16_smem, sy);
   }
   if (threadIdx.x == 0) {   // the last workgroup of this XCD to leave puts the two words back to zero for the next launch
     int* done = ws + xcd * 64 + 32;
@@ -752,8 +781,41 @@ int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* des
                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vptr_wgrad_p16_sync_kernel<16>, GNT, 2 * P16_STAGE) != hipSuccess || per_cu < 2))
       sync_s = 0;
   }
+  // VPTR_WGRAD_WAVES=4: the four-wave geometry (64 x 96 wave tiles; see wgrad_p16_tile) for the two-stage launches; default 8
+  static int waves = -1;
+  if (waves < 0) {
+    const char* e = getenv("VPTR_WGRAD_WAVES");
+    waves = (e && atoi(e) == 4) ? 4 : 8;
+    if (waves == 4 && (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_sync_kernel<16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
+                       hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<2, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
+                       hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<2, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess))
+      waves = 8;
+  }
+  // 256-row tiles (split_k -2: panel-synchronous, -3: plain; the host counted this launch's tiles with 256 rows): one workgroup per CU
+  if (proto->split_k == -2 || proto->split_k == -3) {
+    constexpr int STG256 = 256 * 128 + 24 * 1024;
+    static bool attr256 = false;
+    if (!attr256) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_sync_kernel<16, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STG256) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<2, 0, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STG256) != hipSuccess) {
+        vptr_set_error("vptr_gemm_grouped(p16): cannot reserve LDS for 256-row tiles");
+        return -1;
+      }
+      attr256 = true;
+    }
+    VPTR_CHECK(proto->atomic, "vptr_gemm_grouped(p16): 256-row tiles accumulate with atomics only");
+    if (proto->split_k == -2 && sync_s && total_tiles >= 512 && vptr_cu_count() > 0 && vptr_cu_count() % 8 == 0)
+      vptr_wgrad_p16_sync_kernel<16, 8, 4><<<vptr_cu_count(), GNT, 2 * STG256, st>>>(descs_dev, tile_start_dev, count, total_tiles);
+    else
+      vptr_wgrad_p16_kernel<2, 0, 8, 4><<<total_tiles, GNT, 2 * STG256, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), 0);
+    return 0;
+  }
   if (sync_s && proto->split_k == -1 && proto->atomic && total_tiles >= 1024 && vptr_cu_count() > 0 && vptr_cu_count() % 4 == 0) {
     const int grid = 2 * vptr_cu_count();   // two workgroups per CU (80 KB of LDS each), a multiple of 8
+    if (waves == 4) {
+      vptr_wgrad_p16_sync_kernel<16, 4><<<grid, 256, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, total_tiles);
+      return 0;
+    }
     if (sync_s == 8) vptr_wgrad_p16_sync_kernel<8><<<grid, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, total_tiles);
     else if (sync_s == 32) vptr_wgrad_p16_sync_kernel<32><<<grid, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, total_tiles);
     else vptr_wgrad_p16_sync_kernel<16><<<grid, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, total_tiles);
@@ -766,6 +828,8 @@ int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* des
     const int nt = total_tiles - base < per ? total_tiles - base : per;
     if (stages == 4) vptr_wgrad_p16_kernel<4><<<nt, GNT, 4 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), base);
     else if (stages == 3) vptr_wgrad_p16_kernel<3><<<nt, GNT, 3 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), base);
+    else if (waves == 4 && !proto->atomic) vptr_wgrad_p16_kernel<2, 1, 4><<<nt, 256, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), base);
+    else if (waves == 4) vptr_wgrad_p16_kernel<2, 0, 4><<<nt, 256, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), base);
     else if (!proto->atomic) vptr_wgrad_p16_kernel<2, 1><<<nt, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), base);
     else vptr_wgrad_p16_kernel<2><<<nt, GNT, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), base);
   }

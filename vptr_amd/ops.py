@@ -36,6 +36,10 @@ class _Config:
     wgrad_flip = os.environ.get("VPTR_WGRAD_FLIP", "1") != "0"
     # partly filled last row tiles as separate problems launched after all full tiles (equal-duration tiles stay in step); 0 = A/B switch
     wgrad_split = os.environ.get("VPTR_WGRAD_SPLIT", "0") != "0"   # measured: no change (7.03 vs 7.05 ms bare launch): off
+    wgrad_token_split = os.environ.get("VPTR_WGRAD_TOKEN_SPLIT", "1") != "0"   # small weight-gradient groups cut into token ranges (stock-DDP / autograd.grad paths)
+    # tall weight-gradient problems on 256 x 176 tiles (round 5; profiles/r05_wgrad_rows_ab.log: 352 vs 300 TFLOP/s on the 2112- / 1584-row
+    # problems, the grouped launch of the K64 step 7.10 vs 7.39 ms); VPTR_WGRAD_ROWS=128 restores 128-row tiles everywhere
+    wgrad_rows256 = os.environ.get("VPTR_WGRAD_ROWS", "256") == "256"
     # stride-2 3x3 transposed convolutions as four parity-class gathers (ops.SubpixelWeights) instead of one 9-tap gather form; 0 = A/B
     subpixel_convt = os.environ.get("VPTR_SUBPIXEL_CONVT", "1") != "0"
     weights_frozen = False  # set by the frozen_weights scope only
@@ -693,6 +697,16 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
             else:
                 a, b, rows_, cols_, lda, ldb = g, x, N, K, g.stride(0), x.stride(0)
             ap, bp, dp, rp, ldd = a.data_ptr(), b.data_ptr(), dW.data_ptr(), (db.data_ptr() if db is not None else 0), dW.stride(0)
+            if p16 and atomic and config.wgrad_rows256 and rows_ >= 1024 and (rows_ // 256) * 256 >= 0.85 * rows_:
+                # tall problems on 256 x 176 tiles (1.47x the flops per staged byte, one workgroup per CU): the multiple-of-256 part
+                # goes to the 256-row launch, the rest of the rows stays a 128-row problem (and keeps the bias gradient of a flipped one)
+                full = (rows_ // 256) * 256
+                rem256 = rows_ - full
+                subs.append((ap, bp, dp, 0 if (flip and rem256) else rp, lda, ldb, ldd, full, cols_, M, alpha, flip, 256))
+                if rem256:
+                    subs.append((ap + full * 4, bp, dp + (full * 4 if flip else full * ldd * 4), (rp + (0 if flip else full * 4)) if rp else 0,
+                                 lda, ldb, ldd, rem256, cols_, M, alpha, flip, 128))
+                continue
             rem = rows_ % 128
             if p16 and config.wgrad_split and rem and rows_ > 128:
                 # the partly filled last row tile of every problem becomes a problem of its own, launched after all full tiles: full
@@ -706,23 +720,56 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
                 subs.append((ap, bp, dp, rp, lda, ldb, ldd, rows_, cols_, M, alpha, flip))
         if p16 and config.wgrad_split:
             subs.sort(key=lambda t: (0 if t[7] >= 128 else 1, -t[7] * t[8], t[1], t[2]))   # full-tile problems first (largest first), remainders last
+        def trows(sub):
+            return sub[12] if len(sub) > 12 else 128
+
         def tiles_of(sub):
-            return ((sub[7] + 127) // 128) * ((sub[8] + cols - 1) // cols)
+            return ((sub[7] + trows(sub) - 1) // trows(sub)) * ((sub[8] + cols - 1) // cols)
         # the panel-synchronous persistent launch needs ONE token count per launch (its barrier counts K-blocks): problems are classed by
         # token count, every class of >= 1024 tiles gets a launch of its own, the rest share a plain launch.  K64 / BAIR: one class.  KTH128
         # 10 -> 40: encoder layers (10 frames of tokens) and decoder layers (40 frames) = two persistent launches instead of one plain launch
         # that re-fetched every operand panel 5x over the fabric (80 GB per launch, profiles/r05_cfg5_kernel_stats.md).
-        launches = [(subs, False)]
+        if p16 and atomic and config.wgrad_token_split:
+            # a SMALL group (one layer's weight: the launches a torch.distributed job / torch.autograd.grad make, where every gradient must be
+            # complete when its autograd node returns) is 15 - 60 tiles with a K loop over every token: 6 - 25 % of the CUs for the whole
+            # launch.  Its problems are cut into token ranges that accumulate into the same (zero-initialised) destination, enough of them
+            # to put ~2 workgroups on every CU -- what ops.convt_weight_grads does for the decoder (stock-DDP step: see bench.py
+            # other_configs.drop_in_ddp_single_iter)
+            tot = sum(tiles_of(x) for x in subs)
+            if 0 < tot < 384:
+                want = (512 + tot - 1) // tot
+                cut = []
+                for sub in subs:
+                    Mtok = sub[9]
+                    S = max(1, min(want, Mtok // 512))
+                    if S == 1:
+                        cut.append(sub)
+                        continue
+                    chunk = (((Mtok + S - 1) // S + 31) // 32) * 32
+                    t0 = 0
+                    while t0 < Mtok:
+                        n_t = min(chunk, Mtok - t0)
+                        cut.append((sub[0] + t0 * sub[4] * 4, sub[1] + t0 * sub[5] * 4) + tuple(sub[2:9]) + (n_t,) + tuple(sub[10:]))
+                        t0 += n_t
+                subs = cut
+        tall = [x for x in subs if trows(x) == 256]
+        subs = [x for x in subs if trows(x) != 256]
+        launches = [(subs, False)] if subs else []
         if allow_sync and p16 and atomic:
             classes = {}
             for sub in subs:
                 classes.setdefault(sub[9], []).append(sub)
             if len(classes) == 1:
                 launches = [(subs, True)]
-            else:
+            elif classes:
                 big = [(t, c) for t, c in classes.items() if sum(tiles_of(x) for x in c) >= 1024]
                 rest = [x for t, c in classes.items() if sum(tiles_of(y) for y in c) < 1024 for x in c]
                 launches = [(c, True) for _, c in sorted(big, key=lambda tc: -tc[0])] + ([(rest, False)] if rest else [])
+        if tall:   # one 256-row launch per token count (panel-synchronous when allowed), ahead of the 128-row launches
+            tclasses = {}
+            for sub in tall:
+                tclasses.setdefault(sub[9], []).append(sub)
+            launches = [(c, bool(allow_sync)) for _, c in sorted(tclasses.items(), key=lambda tc: -tc[0])] + launches
         dev = grp[0][0].device
         import struct
         for lsubs, vouch in launches:
@@ -731,7 +778,9 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
             starts = []
             total = 0
             lflops = 0.0
-            for i, (ap, bp, dp, rp, lda, ldb, ldd, rows_, cols_, M, alpha, flip) in enumerate(lsubs):
+            tr = trows(lsubs[0])
+            for i, sub in enumerate(lsubs):
+                (ap, bp, dp, rp, lda, ldb, ldd, rows_, cols_, M, alpha, flip) = sub[:12]
                 d = descs[i]
                 d.precision, d.split_k, d.atomic, d.alpha = prec, 1, int(atomic), alpha
                 d.A, d.B, d.D, d.a_rowsum = ap, bp, dp, (rp or None)
@@ -742,7 +791,9 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
                 starts.append(total)
                 total += tiles_of(lsubs[i])
                 lflops += 2.0 * rows_ * cols_ * M
-            if vouch:
+            if tr == 256:
+                descs[0].split_k = -2 if vouch else -3   # 256-row tiles: panel-synchronous / plain (include/vptr_hip.h)
+            elif vouch:
                 descs[0].split_k = -1     # every problem walks the same number of tokens: the panel-synchronous launch may serve the group (VPTR_WGRAD_SYNC)
             raw = _to_device_async(bytes(descs), dev)
             st = _to_device_async(struct.pack("%di" % len(starts), *starts), dev)
@@ -755,8 +806,8 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
                 e1.record()
                 # (which kernel the launcher picks for this group: the panel-synchronous persistent one needs VPTR_WGRAD_SYNC != 0 (default 16), the
                 # uniform-token vouch and >= 1024 tiles -- mirrored here so that bench.py names the kernel rocprofv3 will list)
-                sync = p16 and atomic and vouch and total >= 1024 and os.environ.get("VPTR_WGRAD_SYNC", "16") not in ("0", "")
-                prof.append(((cols // 16, prec, 6 if p16 else 1, 4 if p16 else 1, ("grouped_sync" if sync else "grouped") if atomic else "grouped_split"),
+                sync = p16 and atomic and vouch and total >= (512 if tr == 256 else 1024) and os.environ.get("VPTR_WGRAD_SYNC", "16") not in ("0", "")
+                prof.append(((cols // 16, prec, 6 if p16 else 1, 4 if p16 else 1, (("grouped_sync256" if tr == 256 else "grouped_sync") if sync else "grouped") if atomic else "grouped_split"),
                              lflops, e0, e1))
 
 
