@@ -429,11 +429,19 @@ def other_configs(dev, dropout, skip=()):
     # ---- the same recipe the way the reference's DATA-PARALLEL script drives it: Enc / Dec / transformer wrapped in stock
     # DistributedDataParallel, the projector reached through `.module` (train_NAR_mp.py:94-118,132-189), here in a ONE-rank RCCL group
     # (what a one-GPU box can run: DDP's reducer, bucket copies and per-parameter autograd hooks are all live; the all-reduces are no-ops)
+    # (in a process of its own: an RCCL / DDP failure there must not cost the bench its result line)
     try:
-        out["drop_in_ddp_single_iter"] = _ddp_script_iter(dev, dropout)
+        import subprocess
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--ddp-probe", "--dropout", str(dropout)], env=env, capture_output=True,
+                           text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and lines:
+            out["drop_in_ddp_single_iter"] = json.loads(lines[-1])
+        else:
+            out["drop_in_ddp_single_iter"] = {"error": "probe process exited with code %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
     except Exception as e:  # noqa
         out["drop_in_ddp_single_iter"] = {"error": str(e)[:200]}
-    torch.cuda.empty_cache()
     return out
 
 
@@ -568,9 +576,18 @@ def main():
                     help="one GPU only: bring up a ONE-rank RCCL process group and run the step through the multi-rank code path (chunked "
                          "weight-gradient launches + asynchronous all-reduces of the gradient slab on c10d's RCCL stream)")
     ap.add_argument("--global-batch", type=int, default=64, help="global batch of --scaling strong (train_FAR_mp.py:300 uses 64)")
+    ap.add_argument("--ddp-probe", action="store_true", help=argparse.SUPPRESS)   # internal: other_configs' DDP-wrapped iteration, own process
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.ddp_probe:
+        import faulthandler
+        faulthandler.enable()
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        print(json.dumps(_ddp_script_iter(dev, args.dropout)))
+        sys.stdout.flush()
+        return
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args.gpus, sys.argv[1:])       # does not return

@@ -622,6 +622,7 @@ def _auto_flush_wgrads():
 
 
 _pin_pool = {"slots": [], "next": 0}
+_pin_pool_small = {"slots": [], "next": 0}
 _graph_keepalive = []   # pinned upload sources of captured launches (must outlive every replay)
 _graph_reserve = []     # pinned buffers set aside for the next capture
 
@@ -659,11 +660,14 @@ def _to_device_async(host_bytes, dev):
         buf[:n].copy_(torch.frombuffer(bytearray(host_bytes), dtype=torch.uint8))
         _graph_keepalive.append(buf)
         return buf[:n].to(dev, non_blocking=True)
-    pool = _pin_pool
-    i = pool["next"] % 16
+    # two rotating pools: 1024 small buffers (descriptor tables of one-layer launches: a torch.distributed job makes ~200 of those per
+    # backward pass, and with 16 buffers the host had to wait for the device every 8 launches -- it could never run ahead) and 16 large ones
+    small = n <= 8192
+    pool = _pin_pool_small if small else _pin_pool
+    i = pool["next"] % (1024 if small else 16)
     pool["next"] += 1
     while len(pool["slots"]) <= i:
-        pool["slots"].append([torch.empty(1 << 16, dtype=torch.uint8).pin_memory(), None])
+        pool["slots"].append([torch.empty(8192 if small else (1 << 16), dtype=torch.uint8).pin_memory(), None])
     slot = pool["slots"][i]
     if slot[1] is not None:
         slot[1].synchronize()  # the copy that last used this staging buffer (16 transfers ago) must have completed
@@ -697,7 +701,8 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
             else:
                 a, b, rows_, cols_, lda, ldb = g, x, N, K, g.stride(0), x.stride(0)
             ap, bp, dp, rp, ldd = a.data_ptr(), b.data_ptr(), dW.data_ptr(), (db.data_ptr() if db is not None else 0), dW.stride(0)
-            if p16 and atomic and config.wgrad_rows256 and rows_ >= 1024 and (rows_ // 256) * 256 >= 0.85 * rows_:
+            small_group = p16 and atomic and config.wgrad_token_split and len(grp) <= 3   # one layer's launch: token ranges on 128-row tiles (below)
+            if p16 and atomic and config.wgrad_rows256 and not small_group and rows_ >= 1024 and (rows_ // 256) * 256 >= 0.85 * rows_:
                 # tall problems on 256 x 176 tiles (1.47x the flops per staged byte, one workgroup per CU): the multiple-of-256 part
                 # goes to the 256-row launch, the rest of the rows stays a 128-row problem (and keeps the bias gradient of a flipped one)
                 full = (rows_ // 256) * 256
@@ -737,11 +742,11 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
             # other_configs.drop_in_ddp_single_iter)
             tot = sum(tiles_of(x) for x in subs)
             if 0 < tot < 384:
-                want = (512 + tot - 1) // tot
+                want = (512 + tot - 1) // tot      # ~2 workgroups per CU; every range >= 1024 tokens (each range pays a full atomic epilogue)
                 cut = []
                 for sub in subs:
                     Mtok = sub[9]
-                    S = max(1, min(want, Mtok // 512))
+                    S = max(1, min(want, Mtok // 1024))
                     if S == 1:
                         cut.append(sub)
                         continue
