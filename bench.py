@@ -242,7 +242,9 @@ def gemm_roofline(trainer, past, fut, precision):
             return "vptr_gemm_p16_kernel<%d, %d>" % (key[5], key[6])
         if am == 6:   # the end-of-backward launch into the gradient slab / the plain-store launches of token-range sub-problems
             if len(key) > 4 and key[4] == "grouped_sync256":   # the same on 256 x 176 tiles (VPTR_WGRAD_ROWS=256)
-                return "vptr_wgrad_p16_sync_kernel<16, 8, 4>"
+                return "vptr_wgrad_p16_sync_kernel<16, 8, 4, 2>"
+            if len(key) > 4 and key[4] == "grouped_sync192":   # ... on 192 x 176 tiles, three stages (VPTR_WGRAD_ROWS=192)
+                return "vptr_wgrad_p16_sync_kernel<16, 8, 3, 3>"
             if len(key) > 4 and key[4] == "grouped_sync":   # the panel-synchronous persistent launch (default)
                 return "vptr_wgrad_p16_sync_kernel<%s>" % (os.environ.get("VPTR_WGRAD_SYNC", "16") if os.environ.get("VPTR_WGRAD_SYNC", "16") in ("8", "32") else "16")
             return "vptr_wgrad_p16_kernel<2, 1>" if (len(key) > 4 and key[4] == "grouped_split") else "vptr_wgrad_p16_kernel<2, 0>"

@@ -436,6 +436,9 @@ __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const in
     } else if (kt + 1 < nk) {
       issue(kt + 1, (kt + 1) & 1);
     }
+#ifdef VPTR_TN_DMA_ONLY   // elimination build (WRONG results): staging, waits and barriers only -- what the launch costs when the CUs do nothing
+    continue;              // but ingest their operand tiles (tools/build_variant.sh dmaonly -DVPTR_TN_DMA_ONLY; profiles/r05_ingest_roofline.log)
+#endif
     if (!rows_live && !colsum_wave) continue;   // wave-uniform: this wave's 32 rows lie beyond NG (the last row tile of a 528-row problem keeps 16 of 128)
     const unsigned char* st = p16_smem + (NSTAGE >= 3 ? kt % NSTAGE : (kt & 1)) * STG;
     bf16x8 ah[MI], al[MI];
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(64 * NW, NSTAGE == 2 ? (NW * MI == 16 && NW == 8 ? 
 // tiles.  Requires every problem of the launch to have the same token count (the caller vouches: vptr_gemm_desc.split_k = -S on the
 // prototype).  g_wgrad_sync_ws: 64 ints per XCD (counter at [x * 64], leave counter at [x * 64 + 32]); the kernel leaves them zero.
 __device__ int g_wgrad_sync_ws[8 * 64];   // module-scope, zero at load; one launch of the kernel at a time (launches on ONE stream serialise)
-template <int S, int NW = 8, int MI = 16 / NW>
+template <int S, int NW = 8, int MI = 16 / NW, int NST = 2>
 __global__ __launch_bounds__(64 * NW, NW * MI == 16 && NW == 8 ? 4 : 2) void vptr_wgrad_p16_sync_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
                                                                     const int count, const int total_tiles) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(64 * NW, NW * MI == 16 && NW == 8 ? 4 : 2) void vpt
     sy.base = r * slots * per_tile;
     sy.n = min(slots, mine - r * slots);
     if (r > 0) __syncthreads();   // the previous tile's last stage is still being read by slower waves
-    wgrad_p16_tile<2, S, NW, MI>(descs[lo], lg - tile_start[lo], p16_smem, sy);
+    wgrad_p16_tile<NST, S, NW, MI>(descs[lo], lg - tile_start[lo], p16_smem, sy);
   }
   if (threadIdx.x == 0) {   // the last workgroup of this XCD to leave puts the two words back to zero for the next launch
     int* done = ws + xcd * 64 + 32;
@@ -808,6 +811,26 @@ int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* des
       vptr_wgrad_p16_sync_kernel<16, 8, 4><<<vptr_cu_count(), GNT, 2 * STG256, st>>>(descs_dev, tile_start_dev, count, total_tiles);
     else
       vptr_wgrad_p16_kernel<2, 0, 8, 4><<<total_tiles, GNT, 2 * STG256, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), 0);
+    return 0;
+  }
+  // 192-row tiles, three 46 KB stages (split_k -4: panel-synchronous, -5: plain): one workgroup per CU with TWO K-steps of operands in
+  // flight (92 KB, more than the two 40 KB workgroups of the 128-row geometry keep) and 1.25x the flops per staged byte; 2112 = 11 x 192
+  if (proto->split_k == -4 || proto->split_k == -5) {
+    constexpr int STG192 = 192 * 128 + 24 * 1024;
+    static bool attr192 = false;
+    if (!attr192) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_sync_kernel<16, 8, 3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STG192) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<3, 0, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STG192) != hipSuccess) {
+        vptr_set_error("vptr_gemm_grouped(p16): cannot reserve LDS for 192-row tiles");
+        return -1;
+      }
+      attr192 = true;
+    }
+    VPTR_CHECK(proto->atomic, "vptr_gemm_grouped(p16): 192-row tiles accumulate with atomics only");
+    if (proto->split_k == -4 && sync_s && total_tiles >= 512 && vptr_cu_count() > 0 && vptr_cu_count() % 8 == 0)
+      vptr_wgrad_p16_sync_kernel<16, 8, 3, 3><<<vptr_cu_count(), GNT, 3 * STG192, st>>>(descs_dev, tile_start_dev, count, total_tiles);
+    else
+      vptr_wgrad_p16_kernel<3, 0, 8, 3><<<total_tiles, GNT, 3 * STG192, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), 0);
     return 0;
   }
   if (sync_s && proto->split_k == -1 && proto->atomic && total_tiles >= 1024 && vptr_cu_count() > 0 && vptr_cu_count() % 4 == 0) {

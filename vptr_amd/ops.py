@@ -37,9 +37,9 @@ class _Config:
     # partly filled last row tiles as separate problems launched after all full tiles (equal-duration tiles stay in step); 0 = A/B switch
     wgrad_split = os.environ.get("VPTR_WGRAD_SPLIT", "0") != "0"   # measured: no change (7.03 vs 7.05 ms bare launch): off
     wgrad_token_split = os.environ.get("VPTR_WGRAD_TOKEN_SPLIT", "1") != "0"   # small weight-gradient groups cut into token ranges (stock-DDP / autograd.grad paths)
-    # tall weight-gradient problems on 256 x 176 tiles (round 5; profiles/r05_wgrad_rows_ab.log: 352 vs 300 TFLOP/s on the 2112- / 1584-row
-    # problems, the grouped launch of the K64 step 7.10 vs 7.39 ms); VPTR_WGRAD_ROWS=128 restores 128-row tiles everywhere
-    wgrad_rows256 = os.environ.get("VPTR_WGRAD_ROWS", "256") == "256"
+    # tile rows of the grouped weight-gradient launches: 128 (rounds 1 - 4), 256 (tall problems on 256 x 176 tiles, one workgroup per CU:
+    # 352 vs 300 TFLOP/s on the 2112- / 1584-row problems) or 192 (three stages); profiles/r05_wgrad_rows_ab.log
+    wgrad_rows = int(os.environ.get("VPTR_WGRAD_ROWS", "256"))
     # stride-2 3x3 transposed convolutions as four parity-class gathers (ops.SubpixelWeights) instead of one 9-tap gather form; 0 = A/B
     subpixel_convt = os.environ.get("VPTR_SUBPIXEL_CONVT", "1") != "0"
     weights_frozen = False  # set by the frozen_weights scope only
@@ -702,7 +702,27 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
                 a, b, rows_, cols_, lda, ldb = g, x, N, K, g.stride(0), x.stride(0)
             ap, bp, dp, rp, ldd = a.data_ptr(), b.data_ptr(), dW.data_ptr(), (db.data_ptr() if db is not None else 0), dW.stride(0)
             small_group = p16 and atomic and config.wgrad_token_split and len(grp) <= 3   # one layer's launch: token ranges on 128-row tiles (below)
-            if p16 and atomic and config.wgrad_rows256 and not small_group and rows_ >= 1024 and (rows_ // 256) * 256 >= 0.85 * rows_:
+            if p16 and atomic and config.wgrad_rows == 192 and not small_group and rows_ >= 384:
+                # 192 x 176 tiles (three stages, one workgroup per CU): 2112 = 11 x 192 exactly, 528 = 2.75 (three tiles, the last 3/4 full,
+                # against 4.125 128-row tiles); a remainder that pads a 128-row tile less than a 192-row one joins the 128-row launch
+                rem = rows_ % 192
+                to128 = 0      # trailing rows handed to the 128-row launch
+                if flip and rp:   # the column sums of a flipped problem need a free 16-row fragment in the tile that holds its last rows
+                    if rem == 0:
+                        to128 = 192
+                    elif 192 - rem < 16:
+                        to128 = rem
+                elif rem and (192 - rem) > ((rem + 127) // 128) * 128 - rem:
+                    to128 = rem
+                if to128:
+                    full = rows_ - to128
+                    subs.append((ap, bp, dp, 0 if flip else rp, lda, ldb, ldd, full, cols_, M, alpha, flip, 192))
+                    subs.append((ap + full * 4, bp, dp + (full * 4 if flip else full * ldd * 4), (rp + (0 if flip else full * 4)) if rp else 0,
+                                 lda, ldb, ldd, to128, cols_, M, alpha, flip, 128))
+                else:
+                    subs.append((ap, bp, dp, rp, lda, ldb, ldd, rows_, cols_, M, alpha, flip, 192))
+                continue
+            if p16 and atomic and config.wgrad_rows == 256 and not small_group and rows_ >= 1024 and (rows_ // 256) * 256 >= 0.85 * rows_:
                 # tall problems on 256 x 176 tiles (1.47x the flops per staged byte, one workgroup per CU): the multiple-of-256 part
                 # goes to the 256-row launch, the rest of the rows stays a 128-row problem (and keeps the bias gradient of a flipped one)
                 full = (rows_ // 256) * 256
@@ -757,8 +777,8 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
                         cut.append((sub[0] + t0 * sub[4] * 4, sub[1] + t0 * sub[5] * 4) + tuple(sub[2:9]) + (n_t,) + tuple(sub[10:]))
                         t0 += n_t
                 subs = cut
-        tall = [x for x in subs if trows(x) == 256]
-        subs = [x for x in subs if trows(x) != 256]
+        tall = [x for x in subs if trows(x) != 128]
+        subs = [x for x in subs if trows(x) == 128]
         launches = [(subs, False)] if subs else []
         if allow_sync and p16 and atomic:
             classes = {}
@@ -798,6 +818,8 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
                 lflops += 2.0 * rows_ * cols_ * M
             if tr == 256:
                 descs[0].split_k = -2 if vouch else -3   # 256-row tiles: panel-synchronous / plain (include/vptr_hip.h)
+            elif tr == 192:
+                descs[0].split_k = -4 if vouch else -5   # 192-row tiles, three stages
             elif vouch:
                 descs[0].split_k = -1     # every problem walks the same number of tokens: the panel-synchronous launch may serve the group (VPTR_WGRAD_SYNC)
             raw = _to_device_async(bytes(descs), dev)
@@ -811,8 +833,8 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
                 e1.record()
                 # (which kernel the launcher picks for this group: the panel-synchronous persistent one needs VPTR_WGRAD_SYNC != 0 (default 16), the
                 # uniform-token vouch and >= 1024 tiles -- mirrored here so that bench.py names the kernel rocprofv3 will list)
-                sync = p16 and atomic and vouch and total >= (512 if tr == 256 else 1024) and os.environ.get("VPTR_WGRAD_SYNC", "16") not in ("0", "")
-                prof.append(((cols // 16, prec, 6 if p16 else 1, 4 if p16 else 1, (("grouped_sync256" if tr == 256 else "grouped_sync") if sync else "grouped") if atomic else "grouped_split"),
+                sync = p16 and atomic and vouch and total >= (512 if tr != 128 else 1024) and os.environ.get("VPTR_WGRAD_SYNC", "16") not in ("0", "")
+                prof.append(((cols // 16, prec, 6 if p16 else 1, 4 if p16 else 1, (("grouped_sync%d" % tr if tr != 128 else "grouped_sync") if sync else "grouped") if atomic else "grouped_split"),
                              lflops, e0, e1))
 
 
