@@ -4,9 +4,9 @@
 # MI355X_MICROARCH.md), (3) MFMA utilisation / wait / LDS counters of the top kernels (own passes, --kernel-trace only).
 # Writes gpurun_out/r02/*; copy the summaries into profiles/.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=${R:-r04}; export R
+R=${R:-r05}; export R
 OUT=gpurun_out/$R; rm -rf $OUT; mkdir -p $OUT
-BENCH="python bench.py --graph 0 --no-cpu-baseline --no-other-configs"   # eager launches: one traced kernel per launch
+BENCH="python bench.py --graph 0 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs"   # eager launches: one traced kernel per launch
 SHORT="python bench.py --graph 0 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o b --output-format csv -- $BENCH > $OUT/bench_stdout.log 2>&1
 tail -1 $OUT/bench_stdout.log > $OUT/bench_line.json
@@ -24,6 +24,7 @@ def short(n): return n.split("(")[0].replace("void ", "")
 def fam(n):   # PMC tables: the instantiations of the P16 kernels as one family (bench.py looks the dominant kernel up by this name)
     s = short(n)
     if s.startswith("vptr_gemm_p16_kernel"): return "vptr_gemm_p16_kernel"   # (the two wgrad instantiations stay separate rows: slab launch / sub-problem launches)
+    if s.startswith("vptr_wgrad_p16_sync_kernel"): return s.replace("<16, 8, 2, 2>", "<16>")   # the 128-row persistent launch keeps its round-4 name
     return s
 # ---- (1) kernel stats
 rows = list(csv.DictReader(open(OUT + "/stats/b_kernel_stats.csv")))
@@ -31,7 +32,7 @@ steps = 28.0   # 5 warm-up + 20 timed + 3 instrumented
 tot = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6 / steps
 gemm = sum(float(r["TotalDurationNs"]) for r in rows if "gemm" in r["Name"] or "conv_planes" in r["Name"] or "wgrad" in r["Name"]) / 1e6 / steps
 with open(OUT + "/%s_bench_kernel_stats.md" % R, "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --graph 0 --no-cpu-baseline --no-other-configs   (eager, N=16, bf16x3, dropout 0.1;\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --graph 0 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs   (eager, N=16, bf16x3, dropout 0.1;\n")
     f.write("# 5 warm-up + 20 timed + 3 instrumented steps = 28 steps; per-step figures = totals / 28)\n")
     f.write("# kernel time %.1f ms/step: MFMA GEMM kernels %.1f, everything else %.1f\n\n" % (tot, gemm, tot - gemm))
     f.write("| kernel | calls/step | ms/step | avg us | % |\n|---|---|---|---|---|\n")

@@ -39,7 +39,8 @@ class _Config:
     wgrad_token_split = os.environ.get("VPTR_WGRAD_TOKEN_SPLIT", "1") != "0"   # small weight-gradient groups cut into token ranges (stock-DDP / autograd.grad paths)
     # tile rows of the grouped weight-gradient launches: 128 (rounds 1 - 4), 256 (tall problems on 256 x 176 tiles, one workgroup per CU:
     # 352 vs 300 TFLOP/s on the 2112- / 1584-row problems) or 192 (three stages); profiles/r05_wgrad_rows_ab.log
-    wgrad_rows = int(os.environ.get("VPTR_WGRAD_ROWS", "256"))
+    # "auto" (default): per problem set, whichever of 128 / 256 measured faster (see _launch_wgrad_group)
+    wgrad_rows = (lambda v: v if v == "auto" else int(v))(os.environ.get("VPTR_WGRAD_ROWS", "auto"))
     # stride-2 3x3 transposed convolutions as four parity-class gathers (ops.SubpixelWeights) instead of one 9-tap gather form; 0 = A/B
     subpixel_convt = os.environ.get("VPTR_SUBPIXEL_CONVT", "1") != "0"
     weights_frozen = False  # set by the frozen_weights scope only
@@ -623,6 +624,7 @@ def _auto_flush_wgrads():
 
 _pin_pool = {"slots": [], "next": 0}
 _pin_pool_small = {"slots": [], "next": 0}
+_wgrad_tune = {}    # problem-set signature -> {"ms": {tile rows: best ms}, "pending": (rows, e0, e1) | None, "choice": rows | None}
 _graph_keepalive = []   # pinned upload sources of captured launches (must outlive every replay)
 _graph_reserve = []     # pinned buffers set aside for the next capture
 
@@ -681,12 +683,50 @@ def _to_device_async(host_bytes, dev):
     return out
 
 
+def _wgrad_tune_book(tune):
+    r_, e0_, e1_ = tune["pending"]
+    tune["ms"][r_] = min(tune["ms"].get(r_, 1e30), e0_.elapsed_time(e1_))
+    tune["pending"] = None
+    if len(tune["ms"]) == 2:
+        tune["choice"] = min(tune["ms"], key=tune["ms"].get)
+
+
+def wgrad_tune_settle():
+    """book every timed weight-gradient flush that is still in flight (device synchronisation); the trainers call it between their
+    eager warm-up steps and a graph capture, where events can no longer be queried"""
+    if any(t["pending"] is not None for t in _wgrad_tune.values()):
+        torch.cuda.synchronize()
+        for t in _wgrad_tune.values():
+            if t["pending"] is not None:
+                _wgrad_tune_book(t)
+
+
 def _launch_wgrad_group(its, atomic=1, allow_sync=True):
     groups = {}
     for it in its:
         p16 = it[9]
         groups.setdefault((176 if p16 else int(lib.vptr_gemm_tile_cols(it[4])), it[6], p16), []).append(it)
     for (cols, prec, p16), grp in groups.items():
+        # tile rows of this flush: a fixed setting, or -- VPTR_WGRAD_ROWS=auto, the default -- whichever of 128 / 256 ran faster on THIS set
+        # of problems (measured once per problem set with HIP events on the launch stream, during the eager warm-up steps every caller
+        # runs before it times or captures anything: the two settings trade a better tile for a second launch with a tail of its own, and
+        # which side wins depends on the model -- K64 7.06 vs 7.25 ms, KTH128 11.0 vs 12.2, BAIR FAR 16.7 vs 15.0)
+        rows_mode = config.wgrad_rows
+        tune = None
+        if rows_mode == "auto":
+            rows_mode = 128
+            if p16 and atomic and len(grp) > 3:
+                sig = (allow_sync,) + tuple(sorted((it[3], it[4], it[5]) for it in grp))
+                tune = _wgrad_tune.setdefault(sig, {"ms": {}, "pending": None, "choice": None})
+                capturing = torch.cuda.is_current_stream_capturing()     # (no event queries under capture: wgrad_tune_settle ran before it)
+                if not capturing and tune["pending"] is not None and tune["pending"][2].query():     # the timed flush has finished: book it
+                    _wgrad_tune_book(tune)
+                if tune["choice"] is not None:
+                    rows_mode, tune = tune["choice"], None
+                elif capturing or tune["pending"] is not None:
+                    rows_mode, tune = (min(tune["ms"], key=tune["ms"].get) if tune["ms"] else 128), None   # no timing now: best known so far
+                else:
+                    rows_mode = 256 if 128 in tune["ms"] else 128
         # sub-problems: (A ptr, B ptr, D ptr, rowsum ptr, lda, ldb, ldd, rows, cols, tokens, alpha, transposed)
         subs = []
         flops = 0.0
@@ -701,8 +741,8 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
             else:
                 a, b, rows_, cols_, lda, ldb = g, x, N, K, g.stride(0), x.stride(0)
             ap, bp, dp, rp, ldd = a.data_ptr(), b.data_ptr(), dW.data_ptr(), (db.data_ptr() if db is not None else 0), dW.stride(0)
-            small_group = p16 and atomic and config.wgrad_token_split and len(grp) <= 3   # one layer's launch: token ranges on 128-row tiles (below)
-            if p16 and atomic and config.wgrad_rows == 192 and not small_group and rows_ >= 384:
+            small_group = p16 and atomic and config.wgrad_token_split and not config.deterministic and len(grp) <= 3   # one layer's launch: token ranges on 128-row tiles (below)
+            if p16 and atomic and rows_mode == 192 and not small_group and rows_ >= 384:
                 # 192 x 176 tiles (three stages, one workgroup per CU): 2112 = 11 x 192 exactly, 528 = 2.75 (three tiles, the last 3/4 full,
                 # against 4.125 128-row tiles); a remainder that pads a 128-row tile less than a 192-row one joins the 128-row launch
                 rem = rows_ % 192
@@ -722,7 +762,7 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
                 else:
                     subs.append((ap, bp, dp, rp, lda, ldb, ldd, rows_, cols_, M, alpha, flip, 192))
                 continue
-            if p16 and atomic and config.wgrad_rows == 256 and not small_group and rows_ >= 1024 and (rows_ // 256) * 256 >= 0.85 * rows_:
+            if p16 and atomic and rows_mode == 256 and not small_group and rows_ >= 1024 and (rows_ // 256) * 256 >= 0.85 * rows_:
                 # tall problems on 256 x 176 tiles (1.47x the flops per staged byte, one workgroup per CU): the multiple-of-256 part
                 # goes to the 256-row launch, the rest of the rows stays a 128-row problem (and keeps the bias gradient of a flipped one)
                 full = (rows_ // 256) * 256
@@ -754,7 +794,7 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
         # token count, every class of >= 1024 tiles gets a launch of its own, the rest share a plain launch.  K64 / BAIR: one class.  KTH128
         # 10 -> 40: encoder layers (10 frames of tokens) and decoder layers (40 frames) = two persistent launches instead of one plain launch
         # that re-fetched every operand panel 5x over the fabric (80 GB per launch, profiles/r05_cfg5_kernel_stats.md).
-        if p16 and atomic and config.wgrad_token_split:
+        if p16 and atomic and config.wgrad_token_split and not config.deterministic:   # (several adders per destination: not bit-reproducible)
             # a SMALL group (one layer's weight: the launches a torch.distributed job / torch.autograd.grad make, where every gradient must be
             # complete when its autograd node returns) is 15 - 60 tiles with a K loop over every token: 6 - 25 % of the CUs for the whole
             # launch.  Its problems are cut into token ranges that accumulate into the same (zero-initialised) destination, enough of them
@@ -797,6 +837,9 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
             launches = [(c, bool(allow_sync)) for _, c in sorted(tclasses.items(), key=lambda tc: -tc[0])] + launches
         dev = grp[0][0].device
         import struct
+        if tune is not None:
+            t_e0, t_e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t_e0.record()
         for lsubs, vouch in launches:
             n = len(lsubs)
             descs = (GemmDesc * n)()
@@ -836,6 +879,9 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
                 sync = p16 and atomic and vouch and total >= (512 if tr != 128 else 1024) and os.environ.get("VPTR_WGRAD_SYNC", "16") not in ("0", "")
                 prof.append(((cols // 16, prec, 6 if p16 else 1, 4 if p16 else 1, (("grouped_sync%d" % tr if tr != 128 else "grouped_sync") if sync else "grouped") if atomic else "grouped_split"),
                              lflops, e0, e1))
+        if tune is not None:
+            t_e1.record()
+            tune["pending"] = (rows_mode, t_e0, t_e1)
 
 
 def convt_weight_grads(layers, tokens_per_split=2560):

@@ -466,7 +466,8 @@ class NARTrainer:
         torch.cuda.current_stream().wait_stream(s)
         # the captured step uploads as many host-built tables as the last warm-up step did (grouped launches: 2 per group, more with
         # the GAN branch or non-P16 groups); each gets a pinned buffer of its own that lives as long as the graph
-        ops.reserve_graph_staging(count=ops._upload_stats["count"] + 2, nbytes=max(1 << 16, 2 * ops._upload_stats["max_bytes"]))
+        ops.reserve_graph_staging(count=ops._upload_stats["count"] + 4, nbytes=max(1 << 16, 2 * ops._upload_stats["max_bytes"]))
+        ops.wgrad_tune_settle()   # the tile geometry of the grouped weight-gradient launch is chosen from the warm-up steps' timings
         g = torch.cuda.CUDAGraph(keep_graph=True)
         with torch.cuda.graph(g):
             self._static_out = self._step_impl(self._static_past, self._static_future)
@@ -499,7 +500,8 @@ class NARTrainer:
                     ops._upload_stats.update(count=0, max_bytes=0)
                 self._step_impl(self._static_past, self._static_future)
         torch.cuda.current_stream().wait_stream(s)
-        ops.reserve_graph_staging(count=ops._upload_stats["count"] + 2, nbytes=max(1 << 16, 2 * ops._upload_stats["max_bytes"]))
+        ops.reserve_graph_staging(count=ops._upload_stats["count"] + 4, nbytes=max(1 << 16, 2 * ops._upload_stats["max_bytes"]))
+        ops.wgrad_tune_settle()
         # c10d's RCCL watchdog thread polls the events of earlier collectives (hipEventQuery): under the default GLOBAL capture mode
         # that call, made while THIS thread captures, aborts the process ("operation not permitted when stream is capturing").  Drain
         # the device first (no work left to poll) and capture in thread-local mode (other threads' calls stay legal).
