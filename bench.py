@@ -298,6 +298,7 @@ def gemm_roofline(trainer, past, fut, precision):
                      "achieved": round(tot_f / (tot_ms * 1e-3) / 1e12, 2), "alg_gflop_per_step": round(tot_f / 1e9, 1)},
         "per_kernel": {k: {"launches": d[0], "ms_per_step": round(d[2], 3), "achieved": round(d[1] / (d[2] * 1e-3) / 1e12, 1)}
                        for k, d in per_kernel.items()},
+        "operand_stream": operand_stream_roof(kname, ach),
         "hbm_side": hbm_roofline(opt_recs), "infinity_cache_side": infinity_cache_rate(),
         "note": "algorithmic FLOPs = 2*M*N*K per launch (HIP events on the launch stream around every GEMM launch of three instrumented "
                 "steps, averaged); the split-bf16 kernels issue 3 bf16 MFMA passes per algorithmic FLOP (fp32-class accuracy), so their ceiling "
@@ -306,6 +307,21 @@ def gemm_roofline(trainer, past, fut, precision):
 
 
 HBM_PEAK_GBS = 8000.0
+L2_TO_CU_TBPS = 9.2    # measured: the DMA-only build of the grouped weight-gradient launch stages 61.5 GB in 6.66 ms (profiles/r05_ingest_roofline.log)
+
+
+def operand_stream_roof(kname, achieved_tflops):
+    """The roof that binds the P16 GEMMs: algorithmic flops per byte a tile stages per K-step (TM x TN x 32:
+    2 TM TN 32 flop against (TM + TN) x 128 B of bf16 hi + lo operands) x the measured bandwidth of the L2 -> CU operand path."""
+    if "p16" not in kname:
+        return None
+    tm = 256 if ("sync_kernel<16, 8, 4" in kname or "wgrad_p16_kernel<2, 0, 8, 4>" in kname) else 128
+    tn = 176
+    fpb = 2.0 * tm * tn * 32 / ((tm + tn) * 128.0)
+    roof = fpb * L2_TO_CU_TBPS
+    return {"tile": "%d x %d x 32" % (tm, tn), "flop_per_staged_byte": round(fpb, 2), "l2_to_cu_TBps": L2_TO_CU_TBPS, "roof": round(roof, 1),
+            "unit": "TFLOP/s", "frac": round(achieved_tflops / roof, 4),
+            "source": "profiles/r05_ingest_roofline.log (DMA-only elimination build; a committed measurement, not a counter of this run)"}
 
 
 def hbm_roofline(opt_recs, root=ROOT):
