@@ -291,6 +291,140 @@ __global__ __launch_bounds__(GNT, NST >= 3 ? 2 : 4) void vptr_gemm_p16_kernel(co
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// nt kernel on 256 x 176 x 32 tiles (round 5).  The P16 GEMMs are bound by the L2 -> CU operand stream: a tile of
+// TM x TN stages (TM + TN) x 128 B per K-step for 2 TM TN 32 flop, so 256 rows give 1.47x the flops per staged byte of 128.  Same stage
+// layout and fragment reads as vptr_gemm_p16_kernel with a 32 KB A region (32 pieces; 4 A + 3 B pieces per wave), two 56 KB stages, ONE
+// workgroup per CU (256 registers per lane).  Wave (wm, wn) owns rows s * 128 + wm * 32 + (mi & 1) * 16, s = mi >> 1: the tile is two
+// stacked 128-row sub-tiles with the wave layout of the 128-row kernel, so every epilogue of gemm_shared.h runs unchanged, once per sub-tile.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int P16_STAGE256 = 56 * 1024;
+template <int EPI>   // EPI as in vptr_gemm_p16_kernel
+__global__ __launch_bounds__(GNT, 2) void vptr_gemm_p16_kernel256(const vptr_gemm_desc p, const int epi_rows_) {
+  constexpr int NFN = 11, BN = 176, TR = 256, AREG = TR * 128;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int epi_rows = epi_rows_ & 0xff;
+  const int wm = wave & 3, wn = wave >> 2, lr = lane & 15, lq = lane >> 4;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles = tiles_n * ((p.M + TR - 1) / TR);
+  const int lg = xcd_logical_block();
+  const int grp = lg / tiles, tile = lg - grp * tiles;
+  const Member mb = member_of(p, p.batch > 1 ? grp : 0);
+  const int m0 = (tile / tiles_n) * TR, n0 = (tile % tiles_n) * BN;
+  const int nk = (p.K + 31) >> 5;
+  const bool ktail = (p.K & 16) != 0;
+  const int nseg = p.ksegs > 1 ? p.ksegs : 1;
+  const int64_t pa = p.lda * 4, pb = p.ldb * 4;
+  const unsigned char* Ab = reinterpret_cast<const unsigned char*>(mb.A);
+  const unsigned char* Bb = reinterpret_cast<const unsigned char*>(mb.B);
+  const int64_t sA1 = nseg > 1 ? (p.A_x1 - p.A) * 4 : 0, sA2 = nseg > 2 ? (p.A_x2 - p.A) * 4 : 0;
+  const int64_t sB1 = nseg > 1 ? (p.B_x1 - p.B) * 4 : 0, sB2 = nseg > 2 ? (p.B_x2 - p.B) * 4 : 0;
+  const unsigned char* srcA[4];
+  const unsigned char* srcB[3];
+  int tadj;
+  {
+    const int pch = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int prow = (wave + 8 * i) * 8 + (lane >> 3);
+      const int c = pch ^ ((prow >> 1) & 7);
+      srcA[i] = Ab + (int64_t)min(m0 + prow, p.M - 1) * pa + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int prow = (wave + 8 * i) * 8 + (lane >> 3);
+      const int c = pch ^ ((prow >> 1) & 7);
+      srcB[i] = Bb + (int64_t)min(n0 + prow, p.N - 1) * pb + c * 16;
+    }
+    const int c = pch ^ (((lane >> 4) + 4 * wave) & 7);
+    tadj = c >= 4 ? -64 : 0;
+  }
+  auto issue = [&](const int kt, const int stage) {
+    const int sg = (int)(kt >= nk) + (int)(kt >= 2 * nk);
+    const int kk = kt - sg * nk;
+    const int64_t off = (int64_t)kk * 128 + ((ktail && kk == nk - 1) ? tadj : 0);
+    const int64_t oa = (sg == 0 ? (int64_t)0 : (sg == 1 ? sA1 : sA2)) + off, ob = (sg == 0 ? (int64_t)0 : (sg == 1 ? sB1 : sB2)) + off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) P16_GLDS((uint32_t)(stage * P16_STAGE256 + (wave + 8 * i) * 1024), srcA[i] + oa);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) P16_GLDS((uint32_t)(stage * P16_STAGE256 + AREG + (wave + 8 * i) * 1024), srcB[i] + ob);
+  };
+  f32x4 acc[2][2][6];   // [sub-tile][row fragment][column fragment]
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 6; ++ni) acc[s2][mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int offAh[4], offBh[6];
+  const int ch = (lq >> 1) * 4 + (lq & 1);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int r = (mi >> 1) * 128 + wm * 32 + (mi & 1) * 16 + lr, f = (r >> 1) & 7;
+    offAh[mi] = r * 128 + ((ch ^ f) << 4);
+  }
+#pragma unroll
+  for (int ni = 0; ni < 6; ++ni) {
+    const int r = (wn * 6 + ni) * 16 + lr, f = (r >> 1) & 7;
+    offBh[ni] = AREG + r * 128 + ((ch ^ f) << 4);
+  }
+  const int nkt = nk * nseg;
+  issue(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+    const unsigned char* st = p16_smem + (kt & 1) * P16_STAGE256;
+    bf16x8 ah[4], al[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      ah[mi] = *reinterpret_cast<const bf16x8*>(st + offAh[mi]);
+      al[mi] = *reinterpret_cast<const bf16x8*>(st + (offAh[mi] ^ 32));
+    }
+    if (ktail) {
+      const int sg = (int)(kt >= nk) + (int)(kt >= 2 * nk);
+      if (kt - sg * nk == nk - 1 && lq >= 2) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          ah[mi] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          al[mi] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+      }
+    }
+    bf16x8 bh[2], bl[2];
+    bh[0] = *reinterpret_cast<const bf16x8*>(st + offBh[0]);
+    bl[0] = *reinterpret_cast<const bf16x8*>(st + (offBh[0] ^ 32));
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) {
+      if (ni == 5 && wn == 1) break;   // wave-uniform: fragment 11 of the tile does not exist
+      if (ni + 1 < 6 && !(ni + 1 == 5 && wn == 1)) {
+        bh[(ni + 1) & 1] = *reinterpret_cast<const bf16x8*>(st + offBh[ni + 1]);
+        bl[(ni + 1) & 1] = *reinterpret_cast<const bf16x8*>(st + (offBh[ni + 1] ^ 32));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // two waves per SIMD: the three passes go round the four row fragments (no back-to-back MFMAs on one accumulator)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) acc[mi >> 1][mi & 1][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh[ni & 1], acc[mi >> 1][mi & 1][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) acc[mi >> 1][mi & 1][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl[ni & 1], acc[mi >> 1][mi & 1][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) acc[mi >> 1][mi & 1][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh[ni & 1], acc[mi >> 1][mi & 1][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  constexpr bool LEAN = EPI != 0;
+  float* const sE = reinterpret_cast<float*>(p16_smem);
+  const bool vec = LEAN || ((epi_rows || p.d_p16) && !p.atomic && epi_vec_ok(p));   // kernel-uniform
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    if (m0 + s2 * 128 >= p.M) break;   // workgroup-uniform: the second sub-tile of the last row tile may not exist
+    __syncthreads();                  // the last stage / the previous sub-tile's LDS tile is still being read by slower waves
+    if (vec) gemm_epilogue_rows_halves_batched<NFN, EPI>(p, mb, acc[s2], sE, m0 + s2 * 128, n0, wm, wn, lr, lq, tid, true, false);
+    else gemm_epilogue_serial<NFN>(p, mb, acc[s2], m0 + s2 * 128, n0, wm, wn, lr, lq, true, p.atomic != 0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // tn kernel (grouped weight gradients).  Per K-step (32 tokens) and operand the stage holds, for every PAIR of granules of the
 // tile, 4 pieces of [8 tokens][128 B]; a piece is laid out as 4 mini-subtiles [8 tokens][16 channels] (g0 hi, g0 lo, g1 hi,
 // g1 lo; 256 B each, 32-byte channel rows): DMA lane L fetches chunk (L >> 4) * 2 + (L & 1) of token row (L & 15) >> 1 -- whole
@@ -727,17 +861,48 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
   if (d.frame_stats)   // served by the lean epilogue only: no fallback
     VPTR_CHECK(d.frame_rows >= 64 && d.frame_rows % 64 == 0 && d.M % 64 == 0 && !d.act_grad_src && lean && d.batch == 1,
                "vptr_gemm(p16): frame_stats needs frame_rows %% 64 == 0, M %% 64 == 0 and a plain launch (bias / alpha / residual only)");
+  // 256 x 176 tiles (vptr_gemm_p16_kernel256: 1.47x the flops per staged byte, one workgroup per CU) where they fill the chip at least as
+  // well as 128-row tiles fill it with two workgroups per CU: whole-round efficiency x 1.17 (the gain measured on the tn side).
+  // VPTR_GEMM_ROWS=model enables that rule, =256 forces them for every grid of more than one round; default: off (round-5 A/B: with K loops of
+  // 17 - 66 steps the lone workgroup's prologue and four half-tile epilogue passes cost more than the operand stream saves).
+  bool use256 = false;
+  {
+    static int rows_mode = -1;
+    if (rows_mode < 0) {
+      const char* e = getenv("VPTR_GEMM_ROWS");
+      rows_mode = e ? (atoi(e) == 256 ? 2 : (e[0] == 'm' ? 1 : 0)) : 0;   // default OFF: measured slower at the model's K (17 / 66 K-steps), tools/rejected/README.md
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel256<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE256) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel256<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE256) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel256<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE256) != hipSuccess)
+        rows_mode = 0;
+    }
+    const int cus = vptr_cu_count();
+    const int t256 = ((d.M + 255) / 256) * ((d.N + 175) / 176) * d.batch;
+    // (lean / lean3 / activation-gradient epilogues only: the full epilogue next to 96 accumulator registers spills)
+    if (rows_mode > 0 && cus > 0 && d.M >= 512 && t256 > cus && (lean || lean3 || d.act_grad_src)) {
+      const double e256 = 1.17 * t256 / (double)(((t256 + cus - 1) / cus) * cus);
+      const double e128 = tiles / (double)(((tiles + 2 * cus - 1) / (2 * cus)) * 2 * cus);
+      use256 = rows_mode == 2 || e256 > 1.03 * e128;
+    }
+  }
   if (d.act_grad_src) {   // activation-gradient epilogue: its own instantiation, no fallback
     VPTR_CHECK(!d.colscale && !d.Dpre && !d.rowscale && !d.residual && !d.bias && !d.act_after && !d.atomic && d.batch == 1 && d.ksegs == 1 &&
                    d.act != VPTR_ACT_NONE && ((ebits | reinterpret_cast<uintptr_t>(d.act_grad_src)) & 15) == 0 && (d.N & 3) == 0 && (d.ldd & 3) == 0,
                "vptr_gemm(p16): act_grad_src combines with alpha / dropout / P16 output only and needs 16-byte aligned operands, N, ldd multiples of 4");
-    if (lone4) vptr_gemm_p16_kernel<2, 4><<<tiles, GNT, 4 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
+    if (use256) vptr_gemm_p16_kernel256<2><<<((d.M + 255) / 256) * ((d.N + 175) / 176), GNT, 2 * P16_STAGE256, st>>>(d, 1);
+    else if (lone4) vptr_gemm_p16_kernel<2, 4><<<tiles, GNT, 4 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
     else if (lone) vptr_gemm_p16_kernel<2, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
     else vptr_gemm_p16_kernel<2, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
     return 0;
   }
   if (d.batch_accum)
     VPTR_CHECK(lean && d.batch > 1 && !d.d_p16 && (d.batch_accum >> d.batch) == 0, "vptr_gemm(p16): batch_accum is an option of plain fp32-output batch launches");
+  if (use256) {
+    const int t256 = ((d.M + 255) / 256) * ((d.N + 175) / 176) * d.batch;
+    if (lean3) vptr_gemm_p16_kernel256<3><<<t256, GNT, 2 * P16_STAGE256, st>>>(d, 1);
+    else vptr_gemm_p16_kernel256<1><<<t256, GNT, 2 * P16_STAGE256, st>>>(d, rows);
+    return 0;
+  }
   if (lean3 && lone4) vptr_gemm_p16_kernel<3, 4><<<tiles, GNT, 4 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
   else if (lean && lone4) vptr_gemm_p16_kernel<1, 4><<<tiles, GNT, 4 * P16_STAGE, st>>>(d, rows | p16_prio_flag());
   else if (!lean3 && !lean && lone4) vptr_gemm_p16_kernel<0, 4><<<tiles, GNT, 4 * P16_STAGE, st>>>(d, rows | p16_prio_flag());
