@@ -105,14 +105,34 @@ __device__ __forceinline__ void am_stage_img(unsigned char* img, const float* __
                                              const int NDF, const int tid, const int nthr, const bool query_rows = false) {
   const int NP = NDF * 8;   // channel pairs per row including the zero padding up to 16 NDF
   const int L = query_rows ? gm.Lq : gm.Lk;
-  for (int idx = tid; idx < L * NP; idx += nthr) {
-    const int j = idx / NP, dp = idx - j * NP, d = 2 * dp;
-    const bool ok = d < gm.hd;
-    const float2 v = *reinterpret_cast<const float2*>(src + (query_rows ? am_qrow(gm, g, j) : am_krow(gm, g, j)) * gm.C + h * gm.hd + min(d, gm.hd - 2));
-    uint32_t hi, lo;
-    vptr_split2(ok ? v.x : 0.f, ok ? v.y : 0.f, hi, lo);
-    *reinterpret_cast<uint32_t*>(img + am_img_off(LKP, d >> 4, 0, j, d & 15)) = hi;
-    *reinterpret_cast<uint32_t*>(img + am_img_off(LKP, d >> 4, 1, j, d & 15)) = lo;
+  const int total = L * NP;
+  // BATCHES of loads (round 5): the loop used to be load -> wait -> split -> write per item, i.e. up to 10 - 40 serialised memory round
+  // trips per thread and staged tensor (the trip count is not a compile-time constant, so nothing was unrolled); now up to AM_STAGE_U
+  // unconditional loads (clamped index) are in flight before the first one is consumed
+  constexpr int U = 10;
+  const float* const hbase = src + h * gm.hd;
+  for (int base = tid; base < total; base += nthr * U) {
+    float2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (base - tid + u * nthr < total) {   // slot-uniform: batches beyond the tensor issue nothing (a 10-row key tensor is 2 items per thread)
+        const int idx = min(base + u * nthr, total - 1);
+        const int j = idx / NP, d = 2 * (idx - j * NP);
+        v[u] = *reinterpret_cast<const float2*>(hbase + (query_rows ? am_qrow(gm, g, j) : am_krow(gm, g, j)) * gm.C + min(d, gm.hd - 2));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * nthr;
+      if (idx < total) {
+        const int j = idx / NP, d = 2 * (idx - j * NP);
+        const bool ok = d < gm.hd;
+        uint32_t hi, lo;
+        vptr_split2(ok ? v[u].x : 0.f, ok ? v[u].y : 0.f, hi, lo);
+        *reinterpret_cast<uint32_t*>(img + am_img_off(LKP, d >> 4, 0, j, d & 15)) = hi;
+        *reinterpret_cast<uint32_t*>(img + am_img_off(LKP, d >> 4, 1, j, d & 15)) = lo;
+      }
+    }
   }
   const int ppb = (LKP - L) * 2;   // 16-byte pieces of the pad rows of one (df, plane) block (32 B per row)
   for (int idx = tid; idx < 2 * NDF * ppb; idx += nthr) {
@@ -120,6 +140,10 @@ __device__ __forceinline__ void am_stage_img(unsigned char* img, const float* __
     *reinterpret_cast<uint4*>(img + (blk * LKP + L) * 32 + rem * 16) = make_uint4(0u, 0u, 0u, 0u);
   }
 }
+
+// (Measured and dropped, same-box A/B in profiles/r05_attn64_ab.log: requesting the dO / Q rows of the later key-block phases at kernel start
+// (registers) and staging K and V as one batch -- 285 / 248 us against 265 / 237 us for the 64-token window / T = 29 backward: the 40 - 80
+// extra live registers cost more than the hidden round trips buy.)
 
 // A / B operand fragment (8 consecutive channels 32 ks + 8 lq .. of row `row`) of one plane, read from a transposable image instead of
 // global memory: the channels of a row are contiguous inside their 16-channel block, so it is one 16-byte read.  Second generation of
@@ -251,8 +275,9 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const float* __restr
   unsigned char* ptile = tiles_in_kimg ? kimg + qb * (2 * 16 * pitch) : am_smem + slots * 2 * img_bytes + wave * (2 * 16 * pitch);
 
   if (pvalid) {   // both operands of the problem staged once (all loads of a thread in flight together), shared by its query-block waves
-    am_stage_img(kimg, k, gm, g, h, LKP, NDF, tid - slot * nqbr * 64, nqbr * 64);
-    am_stage_img(img, v, gm, g, h, LKP, NDF, tid - slot * nqbr * 64, nqbr * 64);
+    const int stid = tid - slot * nqbr * 64, snthr = nqbr * 64;
+    am_stage_img(kimg, k, gm, g, h, LKP, NDF, stid, snthr);
+    am_stage_img(img, v, gm, g, h, LKP, NDF, stid, snthr);
   }
   __syncthreads();
   float pr[4][4];
