@@ -9,6 +9,9 @@ struct AmGeom {
   int Lq, Lk;          // rows per problem
   int C, nh, hd;
   int groups;          // windows, or N * HW pixels
+  // derived by the launchers of attn_mfma.hip (callers leave them zero)
+  int ws_shift;        // log2(ws) when ws is a power of two, else -1
+  int idx32;           // 1: groups * nh * Lq * Lk < 2^32 -- dropout element indices fit 32 bits (same hash, cheaper index arithmetic)
 };
 
 // true when the MFMA kernels cover the geometry (otherwise the fp32 vector kernels of attn.hip run); VPTR_ATTN_MFMA=0 disables them

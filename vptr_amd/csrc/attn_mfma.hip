@@ -25,22 +25,41 @@ typedef __attribute__((ext_vector_type(2))) uint32_t am_u32x2;
 #define AM_MAXL 64
 
 // window row of token l of window `win` (ws x ws windows, row-major over (frame, qh, qw))
+// Row of sequence element l of problem g = base(g) + off(l): the base is workgroup-uniform (scalar unit), the per-lane part is a shift and a
+// mask for power-of-two windows (round 5: the divisions by ws / nqw / HW per call were a sixth of the kernels' 2 - 4 k VALU instructions
+// per wave).  All tensors the launchers admit have fewer than 2^31 elements, so row * C stays in 32 bits.
 __device__ __forceinline__ int am_win_row(int win, int l, int H, int W, int ws, int nqh, int nqw) {
   const int b = win / (nqh * nqw), r = win - b * (nqh * nqw);
   const int qh = r / nqw, qw = r - qh * nqw;
   const int ph = l / ws, pw = l - ph * ws;
   return (b * H + qh * ws + ph) * W + qw * ws + pw;
 }
-
-__device__ __forceinline__ int64_t am_qrow(const AmGeom& gm, int g, int i) {
-  if (gm.mode == 0) return am_win_row(g, i, gm.H, gm.W, gm.ws, gm.H / gm.ws, gm.W / gm.ws);
-  const int n = g / gm.HW, pix = g - n * gm.HW;
-  return (int64_t)(n * gm.Tq + i) * gm.HW + pix;
+__device__ __forceinline__ int am_row_off(const AmGeom& gm, const int l, const bool key) {
+  if (gm.mode == 0) {
+    if (gm.ws_shift >= 0) return (l >> gm.ws_shift) * gm.W + (l & (gm.ws - 1));
+    const int ph = l / gm.ws;
+    return ph * gm.W + (l - ph * gm.ws);
+  }
+  return l * gm.HW;
 }
-__device__ __forceinline__ int64_t am_krow(const AmGeom& gm, int g, int j) {
-  if (gm.mode == 0) return am_win_row(g, j, gm.H, gm.W, gm.ws, gm.H / gm.ws, gm.W / gm.ws);
+__device__ __forceinline__ int am_row_base(const AmGeom& gm, const int g, const bool key) {   // uniform
+  if (gm.mode == 0) return am_win_row(g, 0, gm.H, gm.W, gm.ws, gm.H / gm.ws, gm.W / gm.ws);
   const int n = g / gm.HW, pix = g - n * gm.HW;
-  return (int64_t)(n * gm.Tk + j) * gm.HW + pix;
+  return n * (key ? gm.Tk : gm.Tq) * gm.HW + pix;
+}
+__device__ __forceinline__ int am_qrow(const AmGeom& gm, int g, int i) { return am_row_base(gm, g, false) + am_row_off(gm, i, false); }
+__device__ __forceinline__ int am_krow(const AmGeom& gm, int g, int j) { return am_row_base(gm, g, true) + am_row_off(gm, j, true); }
+// dropout scale of score element `idx` (flat index of the tensor the reference drops): the 32-bit form of vptr_drop_scale for indices below
+// 2^32 (vptr_hash3 adds (idx >> 32) * const = 0 there: the SAME hash, without the 64-bit index arithmetic)
+__device__ __forceinline__ float am_drop_scale(const AmGeom& gm, const uint64_t seed, const uint32_t site, const int prob, const int i, const int j, const float p) {
+  if (gm.idx32) {
+    const uint32_t idx = ((uint32_t)prob * (uint32_t)gm.Lq + (uint32_t)i) * (uint32_t)gm.Lk + (uint32_t)j;
+    const uint32_t key = vptr_mix32((uint32_t)seed ^ vptr_mix32((uint32_t)(seed >> 32) + (site + 1u) * 0x9E3779B9u));
+    const uint32_t hsh = vptr_mix32(idx ^ key);
+    const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+    return (hsh >= thr) ? 1.0f / (1.0f - p) : 0.0f;
+  }
+  return vptr_drop_scale(seed, site, ((uint64_t)prob * gm.Lq + i) * gm.Lk + j, p);
 }
 
 // 8 consecutive channels d0 .. d0+7 of one row -> bf16 hi / lo fragments; channels >= hd and rows that do not exist read as zero
@@ -294,7 +313,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const float* __restr
         for (int r = 0; r < 4; ++r) {
           const int il = 4 * lq + r, i = qb * 16 + il;
           float x = pr[jf][r];
-          if (p > 0.f && i < gm.Lq && j < gm.Lk) x *= vptr_drop_scale(seed, site, ((uint64_t)prob * gm.Lq + i) * gm.Lk + j, p);
+          if (p > 0.f && i < gm.Lq && j < gm.Lk) x *= am_drop_scale(gm, seed, site, prob, i, j, p);
           uint32_t hi, lo;
           vptr_split2(x, 0.f, hi, lo);
           *reinterpret_cast<uint16_t*>(ptile + il * pitch + j * 2) = (uint16_t)hi;
@@ -321,7 +340,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const float* __restr
   }
   const int i = qb * 16 + lr;
   if (i < gm.Lq) {
-    const int64_t rowe = am_qrow(gm, g, i) * gm.C + h * gm.hd;
+    const int64_t rowe = (int64_t)(am_qrow(gm, g, i) * gm.C + h * gm.hd);
 #pragma unroll
     for (int df = 0; df < NDF; ++df) am_store_quad(o, rowe, df * 16 + 4 * lq, gm.hd, oacc[df], 1.f, p16);
   }
@@ -414,7 +433,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const float* __restr
         for (int r = 0; r < 4; ++r) {
           const int i = qb * 16 + 4 * lq + r;
           float sc = 1.f;
-          if (p > 0.f && i < gm.Lq && j < gm.Lk) sc = vptr_drop_scale(seed, site, ((uint64_t)prob * gm.Lq + i) * gm.Lk + j, p);
+          if (p > 0.f && i < gm.Lq && j < gm.Lk) sc = am_drop_scale(gm, seed, site, prob, i, j, p);
           pd[jf][r] = pr[jf][r] * sc;
           ds[jf][r] = acc[r] * sc;          // dP
           delta[r] += pr[jf][r] * ds[jf][r];
@@ -640,7 +659,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_shared_kernel(const float* 
         for (int r = 0; r < 4; ++r) {
           const int i = qb * 16 + 4 * lq + r;
           float sc = 1.f;
-          if (p > 0.f && i < gm.Lq && j < gm.Lk) sc = vptr_drop_scale(seed, site, ((uint64_t)prob * gm.Lq + i) * gm.Lk + j, p);
+          if (p > 0.f && i < gm.Lq && j < gm.Lk) sc = am_drop_scale(gm, seed, site, prob, i, j, p);
           pd[jf][r] = i < gm.Lq ? pr[jf][r] * sc : 0.f;
           ds[jf][r] = acc[r] * sc;
           delta[r] += pr[jf][r] * ds[jf][r];
@@ -696,7 +715,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_shared_kernel(const float* 
     }
     const int i = qb * 16 + lr;
     if (i < gm.Lq) {
-      const int64_t rowe = am_qrow(gm, g, i) * gm.C + h * gm.hd;
+      const int64_t rowe = (int64_t)(am_qrow(gm, g, i) * gm.C + h * gm.hd);
 #pragma unroll
       for (int df = 0; df < NDF; ++df) am_store_quad(dq, rowe, df * 16 + 4 * lq, gm.hd, qacc[df], dq_scale, p16);
     }
@@ -728,7 +747,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_shared_kernel(const float* 
         }
         const int j = jb * 16 + lr;
         if (j < gm.Lk) {
-          const int64_t rowe = am_krow(gm, g, j) * gm.C + h * gm.hd;
+          const int64_t rowe = (int64_t)(am_krow(gm, g, j) * gm.C + h * gm.hd);
 #pragma unroll
           for (int df = 0; df < NDF; ++df) am_store_quad(dst, rowe, df * 16 + 4 * lq, gm.hd, acc[df], 1.f, p16);
         }
@@ -772,8 +791,25 @@ static int am_launch_fwd(const float* q, const float* k, const float* v, const f
   return 0;
 }
 
-int vptr_attn_mfma_fwd(const float* q, const float* k, const float* v, const float* table, const int64_t* rel_index, float* o, const AmGeom& gm, int causal,
+// fields the kernels derive their index arithmetic from; refuses tensors whose element offsets leave 31 bits
+static int am_derive(const AmGeom& in, AmGeom& gm) {
+  gm = in;
+  gm.ws_shift = -1;
+  if (gm.mode == 0 && gm.ws > 0 && (gm.ws & (gm.ws - 1)) == 0) {
+    gm.ws_shift = 0;
+    while ((1 << gm.ws_shift) < gm.ws) ++gm.ws_shift;
+  }
+  const int64_t rows_q = (int64_t)gm.groups * (gm.mode == 0 ? gm.Lq : gm.Tq), rows_k = (int64_t)gm.groups * (gm.mode == 0 ? gm.Lk : gm.Tk);
+  const int64_t rows = rows_q > rows_k ? rows_q : rows_k;
+  VPTR_CHECK(rows * gm.C < ((int64_t)1 << 31), "attn_mfma: tensors of 2^31 or more elements are not supported (%lld rows x %d)", (long long)rows, gm.C);
+  gm.idx32 = ((int64_t)gm.groups * gm.nh * gm.Lq * gm.Lk < ((int64_t)1 << 32)) ? 1 : 0;
+  return 0;
+}
+
+int vptr_attn_mfma_fwd(const float* q, const float* k, const float* v, const float* table, const int64_t* rel_index, float* o, const AmGeom& gm_in, int causal,
                        float p, const uint64_t* seed_dev, uint32_t site, int p16, hipStream_t st) {
+  AmGeom gm;
+  if (am_derive(gm_in, gm)) return -1;
   const int nks = (gm.hd + 31) / 32, ndf = (gm.hd + 15) / 16;
 #define AM_CASE(NKS, NDF) if (nks == NKS && ndf == NDF) return am_launch_fwd<NKS, NDF>(q, k, v, table, rel_index, o, gm, causal, p, seed_dev, site, p16, st);
   AM_CASE(1, 1) AM_CASE(1, 2) AM_CASE(2, 3) AM_CASE(2, 4) AM_CASE(3, 5) AM_CASE(3, 6)
@@ -809,8 +845,10 @@ static int am_launch_bwd(const float* q, const float* k, const float* v, const f
 }
 
 int vptr_attn_mfma_bwd(const float* q, const float* k, const float* v, const float* table, const int64_t* rel_index, const float* dout, float* dq, float* dk,
-                       float* dv, float* dtable, const AmGeom& gm, int causal, float p, const uint64_t* seed_dev, uint32_t site, float dq_scale, int p16,
+                       float* dv, float* dtable, const AmGeom& gm_in, int causal, float p, const uint64_t* seed_dev, uint32_t site, float dq_scale, int p16,
                        hipStream_t st) {
+  AmGeom gm;
+  if (am_derive(gm_in, gm)) return -1;
   const int nks = (gm.hd + 31) / 32, ndf = (gm.hd + 15) / 16;
 #define AM_CASE(NKS, NDF) if (nks == NKS && ndf == NDF) return am_launch_bwd<NKS, NDF>(q, k, v, table, rel_index, dout, dq, dk, dv, dtable, gm, causal, p, seed_dev, site, dq_scale, p16, st);
   AM_CASE(1, 1) AM_CASE(1, 2) AM_CASE(2, 3) AM_CASE(2, 4) AM_CASE(3, 5) AM_CASE(3, 6)
