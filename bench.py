@@ -386,7 +386,7 @@ def infinity_cache_rate():
         return {"error": str(ex)[:160]}
 
 
-def _time_steps(step, warm=2, timed=3):
+def _time_steps(step, warm=3, timed=5):
     """median of `timed` individually synchronised steps (a one-off allocator stall in a fresh configuration would otherwise
     dominate a 3-step mean: one default run once reported 131 ms for a 54 ms step)"""
     for _ in range(warm):
@@ -418,9 +418,15 @@ def other_configs(dev, dropout, skip=()):
             job = JOBS[name]
             enc, dec, T, cls, kw, past, fut, _ = build_job(name, dev, dropout, job["batch"], 0)
             tr = cls(enc, dec, T, lr=1e-4, max_grad_norm=1.0, **kw)
+            launch = "eager"
+            try:     # the same launch mode as the headline line (an eager step of these models is host-bound on slow hosts: 1000 - 1450 launches)
+                tr.capture(past, fut, warmup=2)
+                launch = "hipGraph (not re-verified here: `bench.py --config %s` runs verify_graph on it)" % name
+            except Exception:  # noqa
+                tr._graph = None
             ms = _time_steps(lambda: tr.step(past, fut))
             out[key] = {"ms_per_step": round(ms, 2), "per_gpu_batch": job["batch"], "frames_per_s": round(job["batch"] * job["frames"] / ms * 1e3, 1),
-                        "step_tflops": round(job["gf"] * job["batch"] / 1e3 / (ms * 1e-3), 1)}
+                        "step_tflops": round(job["gf"] * job["batch"] / 1e3 / (ms * 1e-3), 1), "launch": launch}
             tr.opt.close()
             del tr, enc, dec, T, past, fut
         except Exception as e:  # noqa

@@ -5,7 +5,7 @@
 # Writes gpurun_out/r02/*; copy the summaries into profiles/.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 R=${R:-r05}; export R
-OUT=gpurun_out/$R; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/$R; mkdir -p $OUT; rm -rf $OUT/stats $OUT/pmc $OUT/rccl
 BENCH="python bench.py --graph 0 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs"   # eager launches: one traced kernel per launch
 SHORT="python bench.py --graph 0 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o b --output-format csv -- $BENCH > $OUT/bench_stdout.log 2>&1
