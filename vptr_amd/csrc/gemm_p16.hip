@@ -96,7 +96,7 @@ extern "C" int vptr_weight_planes(const vptr_wplane_entry* table_dev, const int*
 // the CU hides a stall): NST stages with the DMA NST - 1 K-steps ahead, its pieces issued between the MFMA groups instead of in a
 // burst after the barrier (cache-cold 10 240 x 528 x 2112: 79.7 -> 73.1 us in tools/gemm_p16_probe with three stages; four stages = the
 // CU's whole 160 KB: 77.9 -> 74.0 us inside the step, VPTR_GEMM_LONE_STAGES=3 restores three).  Chosen by the launcher.
-template <int EPI, int NST>   // EPI: 0 every epilogue option, 1 lean, 2 activation gradient, 3 lean + row scale + dropout (gemm_shared.h)
+template <int EPI, int NST>   // EPI: 0 every epilogue option, 1 lean, 2 activation gradient, 3 lean + row scale + dropout, 4 activation + Dpre + dropout (gemm_shared.h)
 __global__ __launch_bounds__(GNT, NST >= 3 ? 2 : 4) void vptr_gemm_p16_kernel(const vptr_gemm_desc p, const int epi_rows_) {
   constexpr int NFN = 11, BN = 176;
   extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
@@ -773,6 +773,12 @@ static bool p16_no_epi3() {   // VPTR_GEMM_NO_EPI3 (A/B switch), read once
   return v != 0;
 }
 
+static bool p16_no_epi4() {   // VPTR_GEMM_NO_EPI4 (A/B switch), read once
+  static int v = -1;
+  if (v < 0) v = getenv("VPTR_GEMM_NO_EPI4") != nullptr;
+  return v != 0;
+}
+
 static int p16_epi_rows_flag() {
   static int v = -1;
   if (v < 0) {
@@ -827,7 +833,9 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P16_STAGE) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P16_STAGE) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P16_STAGE) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P16_STAGE) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P16_STAGE) != hipSuccess) {
       vptr_set_error("vptr_gemm(p16): cannot reserve %d bytes of LDS", 2 * P16_STAGE);
       return -1;
     }
@@ -848,6 +856,11 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
   const bool lean3 = !lean && (p16_epi_rows_flag() & 4) == 0 && !d.colscale && dpre_ok && (d.rowscale || d.dropout_p > 0.f) && d.act == VPTR_ACT_NONE &&
                      !d.act_after && !d.atomic && !d.frame_stats && (ebits & 15) == 0 && (d.N & 3) == 0 && (d.ldd & 3) == 0 && (d.ldr & 3) == 0 &&
                      !p16_no_epi3();
+  // activation (+ saved pre-activation, dropout, P16 output) and nothing else: linear1 of the MLP blocks -- the full epilogue's ~20 k
+  // instructions of skipped branches cost these launches a quarter of their time (213 vs 290 TFLOP/s at 29 696 x 2112 x 528)
+  const bool lean4 = !lean && !lean3 && (p16_epi_rows_flag() & 4) == 0 && !d.colscale && !d.rowscale && !d.residual && !d.act_after && !d.atomic &&
+                     d.act != VPTR_ACT_NONE && !d.act_grad_src && !d.frame_stats && d.batch == 1 && !d.batch_accum &&
+                     ((ebits | reinterpret_cast<uintptr_t>(d.Dpre)) & 15) == 0 && (d.N & 3) == 0 && (d.ldd & 3) == 0 && !p16_no_epi4();
   static int lone_stages = 0, force_lone = 0;
   if (!lone_stages) {
     const char* e = getenv("VPTR_GEMM_LONE_STAGES");
@@ -903,7 +916,9 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
     else vptr_gemm_p16_kernel256<1><<<t256, GNT, 2 * P16_STAGE256, st>>>(d, rows);
     return 0;
   }
-  if (lean3 && lone4) vptr_gemm_p16_kernel<3, 4><<<tiles, GNT, 4 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
+  if (lean4 && lone4) vptr_gemm_p16_kernel<4, 4><<<tiles, GNT, 4 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
+  else if (lean4 && !lone) vptr_gemm_p16_kernel<4, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
+  else if (lean3 && lone4) vptr_gemm_p16_kernel<3, 4><<<tiles, GNT, 4 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
   else if (lean && lone4) vptr_gemm_p16_kernel<1, 4><<<tiles, GNT, 4 * P16_STAGE, st>>>(d, rows | p16_prio_flag());
   else if (!lean3 && !lean && lone4) vptr_gemm_p16_kernel<0, 4><<<tiles, GNT, 4 * P16_STAGE, st>>>(d, rows | p16_prio_flag());
   else if (lean3 && lone) vptr_gemm_p16_kernel<3, 3><<<tiles, GNT, 3 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());

@@ -334,12 +334,12 @@ __device__ __forceinline__ void gemm_epilogue_rows_halves_batched(const vptr_gem
                                                           const int m0, const int n0, const int wm, const int wn, const int lr, const int lq,
                                                           const int tid, const bool first_split, const bool use_atomic_in, long long* tm = nullptr) {
   constexpr int NFW = (NFN + 1) / 2, BN = 16 * NFN, PITCH = BN + 4, C4 = BN / 4, HR = GBM / 2, NPIECE = HR * C4;
-  constexpr bool LEAN = EPI != 0, GRAD = EPI == 2;
+  constexpr bool LEAN = EPI != 0, GRAD = EPI == 2;   // EPI 4 (round 5): lean + activation + saved pre-activation (Dpre) + dropout -- linear1 of every MLP
   const bool has_res = !GRAD && mb.res && first_split;
   const bool has_bias = !GRAD && mb.bias && first_split;
   const bool use_atomic = !LEAN && use_atomic_in;
   const float* const colscale = LEAN ? nullptr : p.colscale;
-  float* const Dpre = LEAN ? nullptr : p.Dpre;
+  float* const Dpre = (LEAN && EPI != 4) ? nullptr : p.Dpre;
   const float* const rowscale = (LEAN && EPI != 3) ? nullptr : p.rowscale;
   const auto D_planes = LEAN ? decltype(p.D_planes)(nullptr) : p.D_planes;
   const int act = (EPI == 1 || EPI == 3) ? VPTR_ACT_NONE : p.act;

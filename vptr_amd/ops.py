@@ -219,7 +219,9 @@ def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None
             lean3 = (not lean and colscale is None and Dpre is None and act == ACT_NONE and not act_after and not atomic and frame_stats is None)
             tiles = ((M + 127) // 128) * ((N + 175) // 176) * max(d.batch, 1)
             cus = torch.cuda.get_device_properties(A.device).multi_processor_count
-            key = key + ("p16", 2 if act_grad_src is not None else (3 if lean3 else int(lean)),
+            lean4 = (not lean and not lean3 and act_grad_src is None and colscale is None and rowscale is None and residual is None and act != ACT_NONE
+                     and not act_after and not atomic and frame_stats is None and os.environ.get("VPTR_GEMM_NO_EPI4") is None)
+            key = key + ("p16", 2 if act_grad_src is not None else (4 if lean4 else (3 if lean3 else int(lean))),
                          (3 if os.environ.get("VPTR_GEMM_LONE_STAGES") == "3" else 4) if tiles <= cus else 2)
         elif a_mode != 3:     # register-staged kernels: pipelined loop below 384 workgroups (csrc/gemm.hip launch_one), else single-image
             cols = 16 * gemm_nfn(N)
