@@ -508,3 +508,81 @@ def test_bench_refuses_fewer_devices_than_asked():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("rows_mode", [128, 256, 192])
+@pytest.mark.parametrize("allow_sync", [True, False])
+def test_wgrad_launch_plan_partitions_every_problem(rows_mode, allow_sync):
+    """host logic of the grouped weight-gradient flush (vptr_amd.ops.plan_wgrad_launches, pure): whatever tile geometry is chosen, the
+    sub-problems of the launches cover every (row, token) of every weight's gradient exactly once, with consistent operand / destination /
+    bias-gradient addresses; a launch vouched for the panel-synchronous kernel walks one token count; the column sums of a flipped
+    problem land in exactly one row range whose last tile has a free 16-row fragment."""
+    from vptr_amd import ops
+    F, C = 2112, 528
+    shapes = [(F, C), (C, F), (C, C), (3 * C, C), (C, C), (F, C)]          # (N, K) of dW = dY^T X: fc1, fc2, projections, packed in_proj, ...
+    probs, meta = [], {}
+    addr = 1 << 20
+    for li, tokens in enumerate((10240, 10240, 5120)):                      # two token counts: encoder / decoder layers of KTH128
+        for (N, K) in shapes:
+            flip = N < K and N % 176 == 0 and K % 128 != 0 and 128 - K % 128 >= 32      # the rule of ops._launch_wgrad_group
+            rows, cols = (K, N) if flip else (N, K)
+            ap, bp, dp, rp = addr, addr + (1 << 30), addr + (2 << 30), addr + (3 << 30)
+            addr += 1 << 24
+            lda, ldb, ldd = rows, cols, K                                    # token-major operands, dW [N][K]
+            probs.append((ap, bp, dp, rp, lda, ldb, ldd, rows, cols, tokens, 1.0, flip))
+            meta[dp] = (ap, bp, dp, rp, lda, ldb, ldd, rows, cols, tokens, flip)
+    launches = ops.plan_wgrad_launches(probs, 176, True, 1, allow_sync, rows_mode)
+    assert launches
+    cover = {dp: [] for dp in meta}
+    for subs, vouch in launches:
+        trs = {(s[12] if len(s) > 12 else 128) for s in subs}
+        assert len(trs) == 1, "one tile geometry per launch"
+        tr = trs.pop()
+        if vouch:
+            assert allow_sync and len({s[9] for s in subs}) == 1, "a vouched launch walks one token count"
+        for s in subs:
+            (ap, bp, dp, rp, lda, ldb, ldd, rows, cols, tokens, alpha, flip) = s[:12]
+            owner = max(k for k in meta if k <= dp)
+            (ap0, bp0, dp0, rp0, lda0, ldb0, ldd0, rows0, cols0, tokens0, flip0) = meta[owner]
+            assert (lda, ldb, ldd, cols, flip) == (lda0, ldb0, ldd0, cols0, flip0)
+            r0 = ((dp - dp0) // 4) if flip else ((dp - dp0) // (4 * ldd))
+            assert dp - dp0 == (r0 * 4 if flip else r0 * ldd * 4)
+            da = ap - ap0                                                    # = token offset * lda * 4 + row offset * 4
+            t0, rr = divmod(da // 4, lda)
+            assert rr == r0 and da % 4 == 0 and bp - bp0 == t0 * ldb * 4
+            assert 0 <= r0 and r0 + rows <= rows0 and 0 <= t0 and t0 + tokens <= tokens0 and t0 % 32 == 0
+            if rp:
+                assert rp == rp0 + (0 if flip else r0 * 4)
+                if flip:   # column sums: the tile that holds the last rows of this range must have a free 16-row fragment
+                    assert r0 + rows == rows0 and ((rows + tr - 1) // tr) * tr - rows >= 16, (rows, tr)
+            elif not flip:
+                raise AssertionError("a row range of a non-flipped problem lost its bias gradient")
+            cover[owner].append((r0, rows, t0, tokens, bool(rp)))
+    for dp0, pieces in cover.items():
+        rows0, tokens0, flip0 = meta[dp0][7], meta[dp0][9], meta[dp0][10]
+        assert sum(r * t for (_, r, _, t, _) in pieces) == rows0 * tokens0, "rows x tokens not covered exactly once"
+        cells = set()
+        for (r0, r, t0, t, _) in pieces:
+            key = (r0, r, t0, t)
+            assert key not in cells
+            cells.add(key)
+        row_ranges = sorted({(r0, r) for (r0, r, _, _, _) in pieces})
+        assert row_ranges[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(row_ranges, row_ranges[1:])) and sum(r for _, r in row_ranges) == rows0
+        for (r0, r) in row_ranges:
+            toks = sorted((t0, t) for (a, b, t0, t, _) in pieces if (a, b) == (r0, r))
+            assert toks[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(toks, toks[1:])) and sum(t for _, t in toks) == tokens0
+        if flip0:   # exactly one row range carries the column sums (once per token range)
+            assert len({(r0, r) for (r0, r, _, _, has) in pieces if has}) == 1
+
+
+def test_wgrad_launch_plan_cuts_small_groups_into_token_ranges():
+    """one layer's weight (the launches of a torch.distributed job / torch.autograd.grad): 15 tiles become ~500 by token ranges of >= 1024
+    tokens, all accumulating into the same destination"""
+    from vptr_amd import ops
+    C, tokens = 528, 10240
+    prob = (1 << 20, 1 << 30, 2 << 30, 3 << 30, C, C, C, C, C, tokens, 1.0, False)
+    (subs, vouch), = ops.plan_wgrad_launches([prob], 176, True, 1, True, 256)
+    assert len(subs) == 10 and not any(len(s) > 12 and s[12] != 128 for s in subs)
+    assert all(s[2] == prob[2] and s[3] == prob[3] for s in subs) and sum(s[9] for s in subs) == tokens and min(s[9] for s in subs) >= 1024
+    (subs1, _), = ops.plan_wgrad_launches([prob], 176, True, 1, True, 256, token_split=False)
+    assert len(subs1) == 1

@@ -703,6 +703,114 @@ def wgrad_tune_settle():
                 _wgrad_tune_book(t)
 
 
+def plan_wgrad_launches(probs, cols, p16, atomic, allow_sync, rows_mode, split_rem=False, token_split=True):
+    """Pure planning step of the grouped weight-gradient flush (no tensors, no launches: tests/test_cpu.py drives it with made-up
+    addresses).  probs: (A ptr, B ptr, D ptr, rowsum ptr, lda, ldb, ldd, rows, cols, tokens, alpha, transposed) per weight, pointers as
+    integers, leading dimensions in floats.  Returns [(sub-problems, vouch)]: one entry per kernel launch, every sub-problem the same
+    tuple + its tile rows as a 13th element where they are not 128; `vouch` = every sub-problem of the launch walks the same number of
+    tokens (the panel-synchronous persistent kernel may serve it).  Rows of a problem are cut between a 256- (or 192-) row launch and
+    the 128-row launch; a small group is cut into token ranges that accumulate into one destination; problems of different token
+    counts go to different persistent launches."""
+    subs = []
+    for (ap, bp, dp, rp, lda, ldb, ldd, rows_, cols_, M, alpha, flip) in probs:
+        small_group = p16 and atomic and token_split and len(probs) <= 3   # one layer's launch: token ranges on 128-row tiles (below)
+        if p16 and atomic and rows_mode == 192 and not small_group and rows_ >= 384:
+            # 192 x 176 tiles (three stages, one workgroup per CU): 2112 = 11 x 192 exactly, 528 = 2.75 (three tiles, the last 3/4 full,
+            # against 4.125 128-row tiles); a remainder that pads a 128-row tile less than a 192-row one joins the 128-row launch
+            rem = rows_ % 192
+            to128 = 0      # trailing rows handed to the 128-row launch
+            if flip and rp:   # the column sums of a flipped problem need a free 16-row fragment in the tile that holds its last rows
+                if rem == 0:
+                    to128 = 192
+                elif 192 - rem < 16:
+                    to128 = rem
+            elif rem and (192 - rem) > ((rem + 127) // 128) * 128 - rem:
+                to128 = rem
+            if to128:
+                full = rows_ - to128
+                subs.append((ap, bp, dp, 0 if flip else rp, lda, ldb, ldd, full, cols_, M, alpha, flip, 192))
+                subs.append((ap + full * 4, bp, dp + (full * 4 if flip else full * ldd * 4), (rp + (0 if flip else full * 4)) if rp else 0,
+                             lda, ldb, ldd, to128, cols_, M, alpha, flip, 128))
+            else:
+                subs.append((ap, bp, dp, rp, lda, ldb, ldd, rows_, cols_, M, alpha, flip, 192))
+            continue
+        if p16 and atomic and rows_mode == 256 and not small_group and rows_ >= 1024 and (rows_ // 256) * 256 >= 0.85 * rows_:
+            # tall problems on 256 x 176 tiles (1.47x the flops per staged byte, one workgroup per CU): the multiple-of-256 part
+            # goes to the 256-row launch, the rest of the rows stays a 128-row problem (and keeps the bias gradient of a flipped one)
+            full = (rows_ // 256) * 256
+            rem256 = rows_ - full
+            subs.append((ap, bp, dp, 0 if (flip and rem256) else rp, lda, ldb, ldd, full, cols_, M, alpha, flip, 256))
+            if rem256:
+                subs.append((ap + full * 4, bp, dp + (full * 4 if flip else full * ldd * 4), (rp + (0 if flip else full * 4)) if rp else 0,
+                             lda, ldb, ldd, rem256, cols_, M, alpha, flip, 128))
+            continue
+        rem = rows_ % 128
+        if p16 and split_rem and rem and rows_ > 128:
+            # the partly filled last row tile of every problem becomes a problem of its own, launched after all full tiles: full
+            # tiles then all take the same time, so the tiles that share an operand panel stay in step (and in one L2), instead
+            # of being scattered by the short tiles that used to finish early between them
+            full = rows_ - rem
+            subs.append((ap, bp, dp, 0 if flip else rp, lda, ldb, ldd, full, cols_, M, alpha, flip))
+            subs.append((ap + full * 4, bp, dp + (full * 4 if flip else full * ldd * 4), (rp + (0 if flip else full * 4)) if rp else 0,
+                         lda, ldb, ldd, rem, cols_, M, alpha, flip))
+        else:
+            subs.append((ap, bp, dp, rp, lda, ldb, ldd, rows_, cols_, M, alpha, flip))
+
+    if p16 and split_rem:
+        subs.sort(key=lambda t: (0 if t[7] >= 128 else 1, -t[7] * t[8], t[1], t[2]))   # full-tile problems first (largest first), remainders last
+    def trows(sub):
+        return sub[12] if len(sub) > 12 else 128
+
+    def tiles_of(sub):
+        return ((sub[7] + trows(sub) - 1) // trows(sub)) * ((sub[8] + cols - 1) // cols)
+    # the panel-synchronous persistent launch needs ONE token count per launch (its barrier counts K-blocks): problems are classed by
+    # token count, every class of >= 1024 tiles gets a launch of its own, the rest share a plain launch.  K64 / BAIR: one class.  KTH128
+    # 10 -> 40: encoder layers (10 frames of tokens) and decoder layers (40 frames) = two persistent launches instead of one plain launch
+    # that re-fetched every operand panel 5x over the fabric (80 GB per launch, profiles/r05_cfg5_kernel_stats.md).
+    if p16 and atomic and token_split:   # (several adders per destination: not bit-reproducible)
+        # a SMALL group (one layer's weight: the launches a torch.distributed job / torch.autograd.grad make, where every gradient must be
+        # complete when its autograd node returns) is 15 - 60 tiles with a K loop over every token: 6 - 25 % of the CUs for the whole
+        # launch.  Its problems are cut into token ranges that accumulate into the same (zero-initialised) destination, enough of them
+        # to put ~2 workgroups on every CU -- what ops.convt_weight_grads does for the decoder (stock-DDP step: see bench.py
+        # other_configs.drop_in_ddp_single_iter)
+        tot = sum(tiles_of(x) for x in subs)
+        if 0 < tot < 384:
+            want = (512 + tot - 1) // tot      # ~2 workgroups per CU; every range >= 1024 tokens (each range pays a full atomic epilogue)
+            cut = []
+            for sub in subs:
+                Mtok = sub[9]
+                S = max(1, min(want, Mtok // 1024))
+                if S == 1:
+                    cut.append(sub)
+                    continue
+                chunk = (((Mtok + S - 1) // S + 31) // 32) * 32
+                t0 = 0
+                while t0 < Mtok:
+                    n_t = min(chunk, Mtok - t0)
+                    cut.append((sub[0] + t0 * sub[4] * 4, sub[1] + t0 * sub[5] * 4) + tuple(sub[2:9]) + (n_t,) + tuple(sub[10:]))
+                    t0 += n_t
+            subs = cut
+    tall = [x for x in subs if trows(x) != 128]
+    subs = [x for x in subs if trows(x) == 128]
+    launches = [(subs, False)] if subs else []
+    if allow_sync and p16 and atomic:
+        classes = {}
+        for sub in subs:
+            classes.setdefault(sub[9], []).append(sub)
+        if len(classes) == 1:
+            launches = [(subs, True)]
+        elif classes:
+            big = [(t, c) for t, c in classes.items() if sum(tiles_of(x) for x in c) >= 1024]
+            rest = [x for t, c in classes.items() if sum(tiles_of(y) for y in c) < 1024 for x in c]
+            launches = [(c, True) for _, c in sorted(big, key=lambda tc: -tc[0])] + ([(rest, False)] if rest else [])
+    if tall:   # one 256-row launch per token count (panel-synchronous when allowed), ahead of the 128-row launches
+        tclasses = {}
+        for sub in tall:
+            tclasses.setdefault(sub[9], []).append(sub)
+        launches = [(c, bool(allow_sync)) for _, c in sorted(tclasses.items(), key=lambda tc: -tc[0])] + launches
+    return launches
+
+
 def _launch_wgrad_group(its, atomic=1, allow_sync=True):
     groups = {}
     for it in its:
@@ -729,8 +837,9 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
                     rows_mode, tune = (min(tune["ms"], key=tune["ms"].get) if tune["ms"] else 128), None   # no timing now: best known so far
                 else:
                     rows_mode = 256 if 128 in tune["ms"] else 128
-        # sub-problems: (A ptr, B ptr, D ptr, rowsum ptr, lda, ldb, ldd, rows, cols, tokens, alpha, transposed)
-        subs = []
+        # problems: (A ptr, B ptr, D ptr, rowsum ptr, lda, ldb, ldd, rows, cols, tokens, alpha, transposed); plan_wgrad_launches cuts them
+        # into the sub-problems of one or more launches
+        probs = []
         flops = 0.0
         for (g, x, dW, N, K, M, _, db, alpha, _p) in grp:
             flops += 2.0 * M * N * K
@@ -743,100 +852,15 @@ def _launch_wgrad_group(its, atomic=1, allow_sync=True):
             else:
                 a, b, rows_, cols_, lda, ldb = g, x, N, K, g.stride(0), x.stride(0)
             ap, bp, dp, rp, ldd = a.data_ptr(), b.data_ptr(), dW.data_ptr(), (db.data_ptr() if db is not None else 0), dW.stride(0)
-            small_group = p16 and atomic and config.wgrad_token_split and not config.deterministic and len(grp) <= 3   # one layer's launch: token ranges on 128-row tiles (below)
-            if p16 and atomic and rows_mode == 192 and not small_group and rows_ >= 384:
-                # 192 x 176 tiles (three stages, one workgroup per CU): 2112 = 11 x 192 exactly, 528 = 2.75 (three tiles, the last 3/4 full,
-                # against 4.125 128-row tiles); a remainder that pads a 128-row tile less than a 192-row one joins the 128-row launch
-                rem = rows_ % 192
-                to128 = 0      # trailing rows handed to the 128-row launch
-                if flip and rp:   # the column sums of a flipped problem need a free 16-row fragment in the tile that holds its last rows
-                    if rem == 0:
-                        to128 = 192
-                    elif 192 - rem < 16:
-                        to128 = rem
-                elif rem and (192 - rem) > ((rem + 127) // 128) * 128 - rem:
-                    to128 = rem
-                if to128:
-                    full = rows_ - to128
-                    subs.append((ap, bp, dp, 0 if flip else rp, lda, ldb, ldd, full, cols_, M, alpha, flip, 192))
-                    subs.append((ap + full * 4, bp, dp + (full * 4 if flip else full * ldd * 4), (rp + (0 if flip else full * 4)) if rp else 0,
-                                 lda, ldb, ldd, to128, cols_, M, alpha, flip, 128))
-                else:
-                    subs.append((ap, bp, dp, rp, lda, ldb, ldd, rows_, cols_, M, alpha, flip, 192))
-                continue
-            if p16 and atomic and rows_mode == 256 and not small_group and rows_ >= 1024 and (rows_ // 256) * 256 >= 0.85 * rows_:
-                # tall problems on 256 x 176 tiles (1.47x the flops per staged byte, one workgroup per CU): the multiple-of-256 part
-                # goes to the 256-row launch, the rest of the rows stays a 128-row problem (and keeps the bias gradient of a flipped one)
-                full = (rows_ // 256) * 256
-                rem256 = rows_ - full
-                subs.append((ap, bp, dp, 0 if (flip and rem256) else rp, lda, ldb, ldd, full, cols_, M, alpha, flip, 256))
-                if rem256:
-                    subs.append((ap + full * 4, bp, dp + (full * 4 if flip else full * ldd * 4), (rp + (0 if flip else full * 4)) if rp else 0,
-                                 lda, ldb, ldd, rem256, cols_, M, alpha, flip, 128))
-                continue
-            rem = rows_ % 128
-            if p16 and config.wgrad_split and rem and rows_ > 128:
-                # the partly filled last row tile of every problem becomes a problem of its own, launched after all full tiles: full
-                # tiles then all take the same time, so the tiles that share an operand panel stay in step (and in one L2), instead
-                # of being scattered by the short tiles that used to finish early between them
-                full = rows_ - rem
-                subs.append((ap, bp, dp, 0 if flip else rp, lda, ldb, ldd, full, cols_, M, alpha, flip))
-                subs.append((ap + full * 4, bp, dp + (full * 4 if flip else full * ldd * 4), (rp + (0 if flip else full * 4)) if rp else 0,
-                             lda, ldb, ldd, rem, cols_, M, alpha, flip))
-            else:
-                subs.append((ap, bp, dp, rp, lda, ldb, ldd, rows_, cols_, M, alpha, flip))
-        if p16 and config.wgrad_split:
-            subs.sort(key=lambda t: (0 if t[7] >= 128 else 1, -t[7] * t[8], t[1], t[2]))   # full-tile problems first (largest first), remainders last
+            probs.append((ap, bp, dp, rp, lda, ldb, ldd, rows_, cols_, M, alpha, flip))
+        launches = plan_wgrad_launches(probs, cols, p16, atomic, allow_sync, rows_mode, split_rem=config.wgrad_split,
+                                       token_split=config.wgrad_token_split and not config.deterministic)
+
         def trows(sub):
             return sub[12] if len(sub) > 12 else 128
 
         def tiles_of(sub):
             return ((sub[7] + trows(sub) - 1) // trows(sub)) * ((sub[8] + cols - 1) // cols)
-        # the panel-synchronous persistent launch needs ONE token count per launch (its barrier counts K-blocks): problems are classed by
-        # token count, every class of >= 1024 tiles gets a launch of its own, the rest share a plain launch.  K64 / BAIR: one class.  KTH128
-        # 10 -> 40: encoder layers (10 frames of tokens) and decoder layers (40 frames) = two persistent launches instead of one plain launch
-        # that re-fetched every operand panel 5x over the fabric (80 GB per launch, profiles/r05_cfg5_kernel_stats.md).
-        if p16 and atomic and config.wgrad_token_split and not config.deterministic:   # (several adders per destination: not bit-reproducible)
-            # a SMALL group (one layer's weight: the launches a torch.distributed job / torch.autograd.grad make, where every gradient must be
-            # complete when its autograd node returns) is 15 - 60 tiles with a K loop over every token: 6 - 25 % of the CUs for the whole
-            # launch.  Its problems are cut into token ranges that accumulate into the same (zero-initialised) destination, enough of them
-            # to put ~2 workgroups on every CU -- what ops.convt_weight_grads does for the decoder (stock-DDP step: see bench.py
-            # other_configs.drop_in_ddp_single_iter)
-            tot = sum(tiles_of(x) for x in subs)
-            if 0 < tot < 384:
-                want = (512 + tot - 1) // tot      # ~2 workgroups per CU; every range >= 1024 tokens (each range pays a full atomic epilogue)
-                cut = []
-                for sub in subs:
-                    Mtok = sub[9]
-                    S = max(1, min(want, Mtok // 1024))
-                    if S == 1:
-                        cut.append(sub)
-                        continue
-                    chunk = (((Mtok + S - 1) // S + 31) // 32) * 32
-                    t0 = 0
-                    while t0 < Mtok:
-                        n_t = min(chunk, Mtok - t0)
-                        cut.append((sub[0] + t0 * sub[4] * 4, sub[1] + t0 * sub[5] * 4) + tuple(sub[2:9]) + (n_t,) + tuple(sub[10:]))
-                        t0 += n_t
-                subs = cut
-        tall = [x for x in subs if trows(x) != 128]
-        subs = [x for x in subs if trows(x) == 128]
-        launches = [(subs, False)] if subs else []
-        if allow_sync and p16 and atomic:
-            classes = {}
-            for sub in subs:
-                classes.setdefault(sub[9], []).append(sub)
-            if len(classes) == 1:
-                launches = [(subs, True)]
-            elif classes:
-                big = [(t, c) for t, c in classes.items() if sum(tiles_of(x) for x in c) >= 1024]
-                rest = [x for t, c in classes.items() if sum(tiles_of(y) for y in c) < 1024 for x in c]
-                launches = [(c, True) for _, c in sorted(big, key=lambda tc: -tc[0])] + ([(rest, False)] if rest else [])
-        if tall:   # one 256-row launch per token count (panel-synchronous when allowed), ahead of the 128-row launches
-            tclasses = {}
-            for sub in tall:
-                tclasses.setdefault(sub[9], []).append(sub)
-            launches = [(c, bool(allow_sync)) for _, c in sorted(tclasses.items(), key=lambda tc: -tc[0])] + launches
         dev = grp[0][0].device
         import struct
         if tune is not None:
