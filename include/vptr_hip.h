@@ -199,7 +199,7 @@ int vptr_weight_planes(const vptr_wplane_entry* table_dev, const int* tile_start
                        vptr_stream_t stream);
 
 /* Column width of the output tile vptr_gemm / vptr_gemm_grouped use for an N-column problem (64, 128 or 176);
- * the row height is always 128.  Host-side helper for building vptr_gemm_grouped's tile table. */
+ * the row height is 128 (vptr_gemm_grouped: see proto->split_k below).  Host-side helper for building vptr_gemm_grouped's tile table. */
 int vptr_gemm_tile_cols(int N);
 
 /* Grouped GEMM: `count` independent problems in ONE launch, each tile running its problem's full K range (no split-K).
@@ -213,7 +213,14 @@ int vptr_gemm_tile_cols(int N);
  *                  class of N (vptr_gemm_tile_cols) are taken from it and must be common to the group
  *   descs_dev      DEVICE array [count] of descriptors (split_k ignored; atomic = 1 accumulates into D)
  *   tile_start_dev DEVICE int[count]: first tile index of problem g; problem g owns
- *                  ceil(M/128) * ceil(N/tile_cols) consecutive tiles; total_tiles = sum over the group */
+ *                  ceil(M/TR) * ceil(N/tile_cols) consecutive tiles, TR = tile rows (128 unless proto->split_k says otherwise);
+ *                  total_tiles = sum over the group
+ * Token-major P16 groups: proto->split_k selects the launch geometry (the caller counted the tiles accordingly; atomic = 1):
+ *      1   plain launch, 128 x 176 tiles, two workgroups per CU
+ *     -1   panel-synchronous persistent launch, 128 x 176 tiles (needs equal token counts and >= 1024 tiles; see the contract above)
+ *     -2 / -3   256 x 176 tiles, one workgroup per CU (1.47x the flops per staged operand byte): persistent (>= 512 tiles) / plain
+ *     -4 / -5   192 x 176 tiles, three stages, one workgroup per CU: persistent / plain (measured slower; tools/rejected/README.md)
+ * vptr_amd.ops.plan_wgrad_launches is the worked example of cutting a backward pass's problems into such launches. */
 int vptr_gemm_grouped(const vptr_gemm_desc* proto, const vptr_gemm_desc* descs_dev, const int* tile_start_dev, int count,
                       int total_tiles, vptr_stream_t stream);
 
