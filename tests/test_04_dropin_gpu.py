@@ -119,9 +119,12 @@ def test_script_mode_state_is_released_with_the_model(dev):
     base, nbytes = st.grad_arena.buf.data_ptr(), st.grad_arena.buf.numel() * 4
     assert base <= p0.grad.data_ptr() < base + nbytes, ".grad is not a view of the model's arena"
     refs = (weakref.ref(st), weakref.ref(st.grad_arena))
+    prefs = [weakref.ref(p) for p in T.parameters()]       # a process-wide cache of AccumulateGrad nodes pinned every leaf
     del st, p0, opt, T
     gc.collect()
     assert refs[0]() is None and refs[1]() is None, "store / arena outlived the model"
+    assert all(r() is None for r in prefs), "%d parameters outlived their model" % sum(r() is not None for r in prefs)
+    assert not ops._acc_nodes["nodes"], "AccumulateGrad nodes cached beyond their backward pass"
     assert all(r() is not None for r in ops._wplane_stores) or True
     live = [k for k, e in ops._grad_arenas.items() if e[1]() is not None]
     assert not live, "arena entries of a dead model are still live"

@@ -18,6 +18,7 @@
 // 128-byte lines on the global side), <= 128 VGPRs: two workgroups per CU.  tools/gemm_p16_probe.hip is the stand-alone
 // study (nt 290-315 TFLOP/s, tn 230-265 TFLOP/s at the model's shapes vs 200-237 / 159 for the register-staged kernels).
 #include "gemm_shared.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -291,6 +292,188 @@ __global__ __launch_bounds__(GNT, NST >= 3 ? 2 : 4) void vptr_gemm_p16_kernel(co
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// nt kernel, REGISTER-staged (round 6; VPTR_GEMM_RS).  Same tile, stage image, fragment reads, MFMA order and epilogues as
+// vptr_gemm_p16_kernel; only the operand path differs: every lane fetches its five 16-byte chunks of a K-step with plain
+// global_load_dwordx4 (the chunk that belongs at its linear LDS position under the swizzle -- the address map of the DMA pieces) NRS
+// K-steps ahead into registers and stores them with ds_write_b128, interleaved piece by piece between the MFMA groups.  Why: rounds 4 - 5
+// located the bound of the DMA-staged kernels in the global_load_lds path itself (the DMA-only build takes 89 % of the full launch, ~15 B
+// per cycle and CU; two thirds of that cost is per DMA INSTRUCTION, independent of bytes and of where they come from), while ordinary
+// vector loads from L2 are priced at ~56 B per cycle and CU and ds_write_b128 at ~79 (MI355X_MICROARCH.md).  P16 operands need no
+// conversion, so the register path costs 4 VGPRs per piece and set, no VALU.  Two LDS stages, ONE barrier per K-step: the stores of step
+// kt + 1 go to the stage whose last readers (step kt - 1) all passed this step's barrier; they are read after the next one.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+template <int EPI, int NRS, int WGS>   // NRS: register sets (K-steps the global loads run ahead of their LDS stores); WGS: workgroups per CU built for
+__global__ __launch_bounds__(GNT, WGS == 1 ? 2 : 4) void vptr_gemm_p16_rs_kernel(const vptr_gemm_desc p, const int epi_rows_) {
+  static_assert(NRS == 1 || NRS == 2, "one or two register sets");
+  constexpr int NFN = 11, BN = 176;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int epi_rows = epi_rows_ & 0xff;
+  const int wm = wave & 3, wn = wave >> 2, lr = lane & 15, lq = lane >> 4;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles = tiles_n * ((p.M + GBM - 1) / GBM);
+  const int lg = xcd_logical_block();
+  const int grp = lg / tiles, tile = lg - grp * tiles;
+  const Member mb = member_of(p, p.batch > 1 ? grp : 0);
+  const int m0 = (tile / tiles_n) * GBM, n0 = (tile % tiles_n) * BN;
+  const int nk = (p.K + 31) >> 5;
+  const bool ktail = (p.K & 16) != 0;
+  const int nseg = p.ksegs > 1 ? p.ksegs : 1;
+  const int nkt = nk * nseg;
+  const int64_t pa = p.lda * 4, pb = p.ldb * 4;
+  const unsigned char* Ab = reinterpret_cast<const unsigned char*>(mb.A);
+  const unsigned char* Bb = reinterpret_cast<const unsigned char*>(mb.B);
+  const int64_t sA1 = nseg > 1 ? (p.A_x1 - p.A) * 4 : 0, sA2 = nseg > 2 ? (p.A_x2 - p.A) * 4 : 0;
+  const int64_t sB1 = nseg > 1 ? (p.B_x1 - p.B) * 4 : 0, sB2 = nseg > 2 ? (p.B_x2 - p.B) * 4 : 0;
+
+  const unsigned char* src[5];   // pieces 0, 1 = A rows 8 (wave + 8 i) + (lane >> 3); 2 .. 4 = B rows likewise
+  int tadj;
+  {
+    const int pch = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int prow = (wave + 8 * i) * 8 + (lane >> 3);
+      src[i] = Ab + (int64_t)min(m0 + prow, p.M - 1) * pa + (pch ^ ((prow >> 1) & 7)) * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int prow = (wave + 8 * i) * 8 + (lane >> 3);
+      src[2 + i] = Bb + (int64_t)min(n0 + prow, p.N - 1) * pb + (pch ^ ((prow >> 1) & 7)) * 16;
+    }
+    const int c = pch ^ (((lane >> 4) + 4 * wave) & 7);
+    tadj = c >= 4 ? -64 : 0;
+  }
+  // LDS position of this lane's chunk of piece i inside a stage (the DMA's linear order: piece * 1024 + lane * 16)
+  const int dstA = wave * 1024 + lane * 16, dstB = 16384 + wave * 1024 + lane * 16;
+  // byte offsets of K-step kt relative to src[]: wave-uniform (A, B) + this lane's tail adjustment.  Steps beyond the last are CLAMPED to
+  // it (a redundant, L2-resident fetch): every step then issues exactly five loads, so the compiler's vmcnt bookkeeping is static
+  // (conditional loads made it drain vmcnt(0) before a step's first LDS store)
+  auto step_off = [&](const int kt_, int64_t& oa, int64_t& ob) {
+    const int kt = min(kt_, nkt - 1);
+    const int sg = (int)(kt >= nk) + (int)(kt >= 2 * nk);
+    const int kk = kt - sg * nk;
+    const int64_t off = (int64_t)kk * 128 + ((ktail && kk == nk - 1) ? tadj : 0);
+    oa = (sg == 0 ? (int64_t)0 : (sg == 1 ? sA1 : sA2)) + off;
+    ob = (sg == 0 ? (int64_t)0 : (sg == 1 ? sB1 : sB2)) + off;
+  };
+  auto fetch = [&](const int i, const int64_t oa, const int64_t ob) -> u32x4 {
+    return *reinterpret_cast<const u32x4*>(src[i] + (i < 2 ? oa : ob));
+  };
+  auto put = [&](const int stage, const int i, const u32x4 v) {
+    *reinterpret_cast<u32x4*>(p16_smem + stage * P16_STAGE + (i < 2 ? dstA + i * 8192 : dstB + (i - 2) * 8192)) = v;
+  };
+
+  f32x4 acc[2][6];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int offAh[2], offBh[6];
+  const int ch = (lq >> 1) * 4 + (lq & 1);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int r = wm * 32 + mi * 16 + lr, f = (r >> 1) & 7;
+    offAh[mi] = r * 128 + ((ch ^ f) << 4);
+  }
+#pragma unroll
+  for (int ni = 0; ni < 6; ++ni) {
+    const int r = (wn * 6 + ni) * 16 + lr, f = (r >> 1) & 7;
+    offBh[ni] = 16384 + r * 128 + ((ch ^ f) << 4);
+  }
+  u32x4 rg[NRS][5];   // rg[s]: the chunks of step kt + 1 + s (s = (kt + 1 + s') & (NRS - 1) with the loop unrolled by NRS: compile-time indices)
+  // prologue: step 0 straight into stage 0, steps 1 .. NRS into the register sets
+  {
+    u32x4 t0[5];
+    int64_t oa, ob;
+    step_off(0, oa, ob);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) t0[i] = fetch(i, oa, ob);
+#pragma unroll
+    for (int s = 0; s < NRS; ++s) {
+      step_off(1 + s, oa, ob);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) rg[(1 + s) % NRS][i] = fetch(i, oa, ob);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) put(0, i, t0[i]);
+  }
+  auto step = [&](const int kt, auto SET_) {
+    constexpr int SET = decltype(SET_)::value;     // register set that holds step kt + 1 (= (kt + 1) % NRS)
+    __syncthreads();   // stage kt & 1 is complete (every wave's stores of step kt), stage (kt + 1) & 1 is free (every wave's reads of step kt - 1)
+    const unsigned char* st = p16_smem + (kt & 1) * P16_STAGE;
+    const int sn = (kt + 1) & 1;
+    int64_t oa, ob;
+    step_off(kt + 1 + NRS, oa, ob);
+    bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      ah[mi] = *reinterpret_cast<const bf16x8*>(st + offAh[mi]);
+      al[mi] = *reinterpret_cast<const bf16x8*>(st + (offAh[mi] ^ 32));
+    }
+    if (ktail) {
+      const int sg = (int)(kt >= nk) + (int)(kt >= 2 * nk);
+      if (kt - sg * nk == nk - 1 && lq >= 2) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          ah[mi] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          al[mi] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+      }
+    }
+    bf16x8 bh[2], bl[2];
+    bh[0] = *reinterpret_cast<const bf16x8*>(st + offBh[0]);
+    bl[0] = *reinterpret_cast<const bf16x8*>(st + (offBh[0] ^ 32));
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) {
+      if (ni == 5 && wn == 1) break;   // wave-uniform: fragment 11 of the tile does not exist
+      if (ni + 1 < 6 && !(ni + 1 == 5 && wn == 1)) {
+        bh[(ni + 1) & 1] = *reinterpret_cast<const bf16x8*>(st + offBh[ni + 1]);
+        bl[(ni + 1) & 1] = *reinterpret_cast<const bf16x8*>(st + (offBh[ni + 1] ^ 32));
+      }
+#ifndef VPTR_RS_NOSTAGE   // elimination build: no operand movement after the prologue
+      if (ni < 5) {                    // piece ni of step kt + 1: registers -> the other stage; its register then takes step kt + 1 + NRS
+        put(sn, ni, rg[SET][ni]);      // (in the last step: a clamped copy of itself into the stage nobody reads any more)
+        rg[SET][ni] = fetch(ni, oa, ob);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef VPTR_RS_NOMFMA    // elimination build: operand movement, fragment reads and barriers only
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl[ni & 1], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh[ni & 1], acc[mi][ni], 0, 0, 0);
+      }
+#else
+      asm volatile("" ::"v"(ah[0]), "v"(al[0]), "v"(ah[1]), "v"(al[1]), "v"(bh[ni & 1]), "v"(bl[ni & 1]));
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  int kt = 0;
+  for (; kt + NRS <= nkt; kt += NRS) {
+    step(kt, std::integral_constant<int, 1 % NRS>());
+    if (NRS >= 2) step(kt + 1, std::integral_constant<int, 2 % NRS>());
+  }
+  if (NRS >= 2 && kt < nkt) step(kt, std::integral_constant<int, 1 % NRS>());
+
+  constexpr bool LEAN = EPI != 0;
+  if (LEAN) {
+    __syncthreads();  // the last stage is still being read by slower waves
+    gemm_epilogue_rows_halves_batched<NFN, EPI>(p, mb, acc, reinterpret_cast<float*>(p16_smem), m0, n0, wm, wn, lr, lq, tid, true, false);
+  } else if (WGS == 1 && (epi_rows || p.d_p16) && !p.atomic && epi_vec_ok(p)) {
+    __syncthreads();
+    gemm_epilogue_rows_halves_batched<NFN, 0>(p, mb, acc, reinterpret_cast<float*>(p16_smem), m0, n0, wm, wn, lr, lq, tid, true, false);
+  } else if ((epi_rows || p.d_p16) && !p.atomic && epi_vec_ok(p)) {
+    __syncthreads();
+    gemm_epilogue_rows_halves<NFN>(p, mb, acc, reinterpret_cast<float*>(p16_smem), m0, n0, wm, wn, lr, lq, tid, true, false);
+  } else {
+    gemm_epilogue_serial<NFN>(p, mb, acc, m0, n0, wm, wn, lr, lq, true, p.atomic != 0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // nt kernel on 256 x 176 x 32 tiles (round 5).  The P16 GEMMs are bound by the L2 -> CU operand stream: a tile of
 // TM x TN stages (TM + TN) x 128 B per K-step for 2 TM TN 32 flop, so 256 rows give 1.47x the flops per staged byte of 128.  Same stage
 // layout and fragment reads as vptr_gemm_p16_kernel with a 32 KB A region (32 pieces; 4 A + 3 B pieces per wave), two 56 KB stages, ONE
@@ -464,8 +647,12 @@ struct WgSync {
 // MI: 16-row fragments per wave (tile rows TR = 16 MI NW / 2).  (NW, MI) = (8, 4): 256 x 176 tiles, 56 KB stages, ONE workgroup per CU --
 // 1.47x the flops per staged byte of the 128-row tile (the elimination builds and the 4-wave A/B both say the launch is bound by what
 // the CU can ingest through the vector-memory path, not by LDS reads or the matrix pipe).
-template <int NSTAGE, int SYNC, int NW = 8, int MI = 16 / NW>   // SYNC: 0 = none, else the block length S (a power of two) of the panel-synchronous schedule
+// RS = 1 (round 6, VPTR_WGRAD_RS): the operand pieces travel global -> registers -> LDS (global_load_dwordx4 one K-step ahead of their
+// ds_write_b128, same lane <-> chunk map as the DMA pieces, interleaved between the MFMA groups) instead of global_load_lds: see
+// vptr_gemm_p16_rs_kernel.  Two LDS stages, one barrier per K-step.
+template <int NSTAGE, int SYNC, int NW = 8, int MI = 16 / NW, int RS = 0>   // SYNC: 0 = none, else the block length S (a power of two) of the panel-synchronous schedule
 __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const int tile, unsigned char* p16_smem, WgSync& sy) {
+  static_assert(RS == 0 || NSTAGE == 2, "the register-staged loop has two LDS stages");
   constexpr int BN = 176, WM = NW / 2, TR = 16 * MI * WM;   // MI row fragments per wave, WM wave rows, TR tile rows
   constexpr int PA = TR / 8 / NW, PB = 24 / NW;             // DMA pieces per wave and K-step: A, B
   constexpr int AREG = TR * 128, STG = AREG + 24 * 1024;    // bytes of the A region of a stage / of a stage
@@ -507,6 +694,19 @@ __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const in
     for (int i = 0; i < PB; ++i)
       P16_GLDS((uint32_t)(stage * STG + AREG + (wave + NW * i) * 1024), Xb + (int64_t)min(t0 + trow[PA + i], T - 1) * px + colB[i]);
   };
+  // register-staged variant: this lane's chunk of piece j (j < PA: A, else B) of K-step kt (clamped to the last: a redundant L2-resident
+  // fetch keeps the number of loads per step constant, so the compiler's vmcnt bookkeeping stays static)
+  auto rs_load = [&](const int kt_, const int j) -> u32x4 {
+    const int t0 = min(kt_, ((T + 31) >> 5) - 1) * 32;
+    const unsigned char* a = j < PA ? Gb + (int64_t)min(t0 + trow[j], T - 1) * pg + colA[j < PA ? j : 0]
+                                    : Xb + (int64_t)min(t0 + trow[j], T - 1) * px + colB[j < PA ? 0 : j - PA];
+    return *reinterpret_cast<const u32x4*>(a);
+  };
+  auto rs_put = [&](const int stage, const int j, const u32x4 v) {
+    const int off = j < PA ? (wave + NW * j) * 1024 : AREG + (wave + NW * (j - PA)) * 1024;
+    *reinterpret_cast<u32x4*>(p16_smem + stage * STG + off + lane * 16) = v;
+  };
+  u32x4 rg[RS ? PA + PB : 1];
 
   f32x4 acc[MI][6];
 #pragma unroll
@@ -541,9 +741,19 @@ __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const in
   const bool ttail = (T & 31) != 0;
   const bool rows_live = m0 + wm * (16 * MI) < NG;
 
-  issue(0, 0);
-  if (NSTAGE >= 3 && nk > 1) issue(1, 1);
-  if (NSTAGE >= 4 && nk > 2) issue(2, 2);
+  if (RS) {
+    u32x4 t0[PA + PB];
+#pragma unroll
+    for (int j = 0; j < PA + PB; ++j) t0[j] = rs_load(0, j);
+#pragma unroll
+    for (int j = 0; j < PA + PB; ++j) rg[j] = rs_load(1, j);
+#pragma unroll
+    for (int j = 0; j < PA + PB; ++j) rs_put(0, j, t0[j]);
+  } else {
+    issue(0, 0);
+    if (NSTAGE >= 3 && nk > 1) issue(1, 1);
+    if (NSTAGE >= 4 && nk > 2) issue(2, 2);
+  }
   for (int kt = 0; kt < nk; ++kt) {
     if (SYNC > 0 && kt > 0 && (kt & (SYNC / 2 - 1)) == 0 && threadIdx.x == 0) {   // wave 0 reaches this step's barrier late if it has to wait: the other waves wait there
       const int ph = kt & (SYNC - 1);
@@ -561,19 +771,26 @@ __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const in
         }
       }
     }
-    if (NSTAGE >= 4 && kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | (2 * (PA + PB)));
+    if (RS) {
+      // stage kt & 1 is complete once every wave's stores of step kt have landed (lgkmcnt(0) precedes the barrier); stage (kt + 1) & 1
+      // was last read in step kt - 1, i.e. before this barrier
+    } else if (NSTAGE >= 4 && kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | (2 * (PA + PB)));
     else if (NSTAGE >= 3 && kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | (PA + PB));   // vmcnt(pieces of one step): step kt landed, step kt + 1 may still fly
     else __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
-    if (NSTAGE >= 3) {
+    if (RS) {
+    } else if (NSTAGE >= 3) {
       if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
     } else if (kt + 1 < nk) {
       issue(kt + 1, (kt + 1) & 1);
     }
 #ifdef VPTR_TN_DMA_ONLY   // elimination build (WRONG results): staging, waits and barriers only -- what the launch costs when the CUs do nothing
-    continue;              // but ingest their operand tiles (tools/build_variant.sh dmaonly -DVPTR_TN_DMA_ONLY; profiles/r05_ingest_roofline.log)
+    if (!RS) continue;     // but ingest their operand tiles (tools/build_variant.sh dmaonly -DVPTR_TN_DMA_ONLY; profiles/r05_ingest_roofline.log)
 #endif
-    if (!rows_live && !colsum_wave) continue;   // wave-uniform: this wave's 32 rows lie beyond NG (the last row tile of a 528-row problem keeps 16 of 128)
+    // wave-uniform: this wave's 32 rows lie beyond NG (the last row tile of a 528-row problem keeps 16 of 128).  Not under RS: the wave has
+    // its share of the operand pieces to move, and a second code path with loads of its own costs the compiler its static vmcnt bookkeeping
+    // (it then drains vmcnt(0) before every step's first LDS store); the dead rows' products are masked by the epilogue
+    if (!RS && !rows_live && !colsum_wave) continue;
     const unsigned char* st = p16_smem + (NSTAGE >= 3 ? kt % NSTAGE : (kt & 1)) * STG;
     bf16x8 ah[MI], al[MI];
 #pragma unroll
@@ -612,6 +829,13 @@ __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const in
         } else {
           bh[(ni + 1) & 1] = p16_tr_frag(st, offB[ni + 1], rb0);
           bl[(ni + 1) & 1] = p16_tr_frag(st, offB[ni + 1] + 256, rb0);
+        }
+      }
+      if (RS && ni < 5) {   // pieces ni, ni + 5, ... of step kt + 1: registers -> the other stage; the registers then take step kt + 2
+#pragma unroll
+        for (int j = ni; j < PA + PB; j += 5) {
+          rs_put((kt + 1) & 1, j, rg[j]);
+          rg[j] = rs_load(kt + 2, j);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -679,8 +903,8 @@ __device__ __forceinline__ void wgrad_p16_tile(const vptr_gemm_desc& p, const in
 }
 
 
-template <int NSTAGE, int TAG = 0, int NW = 8, int MI = 16 / NW>   // 2: two workgroups per CU; 3: one workgroup per CU with the DMA two K-steps ahead (experiment, VPTR_WGRAD_STAGES=3)
-__global__ __launch_bounds__(64 * NW, NSTAGE == 2 ? (NW * MI == 16 && NW == 8 ? 4 : 2) : 2) void vptr_wgrad_p16_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
+template <int NSTAGE, int TAG = 0, int NW = 8, int MI = 16 / NW, int RS = 0>   // 2: two workgroups per CU; 3: one workgroup per CU with the DMA two K-steps ahead (experiment, VPTR_WGRAD_STAGES=3)
+__global__ __launch_bounds__(64 * NW, NSTAGE == 2 ? (NW * MI == 16 && NW == 8 && !RS ? 4 : 2) : 2) void vptr_wgrad_p16_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
                                                                 const int count, const int xmode, const int tile_base) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
   const int lg = tile_base + ((xmode & 0xff) == 1 ? (int)blockIdx.x : xcd_logical_block());
@@ -692,7 +916,7 @@ __global__ __launch_bounds__(64 * NW, NSTAGE == 2 ? (NW * MI == 16 && NW == 8 ? 
     else hi = mid - 1;
   }
   WgSync none = {nullptr, 0, 0, false};
-  wgrad_p16_tile<NSTAGE, 0, NW, MI>(descs[lo], lg - tile_start[lo], p16_smem, none);
+  wgrad_p16_tile<NSTAGE, 0, NW, MI, RS>(descs[lo], lg - tile_start[lo], p16_smem, none);
 }
 
 // Persistent form for the panel-synchronous schedule: gridDim.x = 8 * slots workgroups (two per CU), workgroup b serves XCD b & 7 as its
@@ -700,8 +924,8 @@ __global__ __launch_bounds__(64 * NW, NSTAGE == 2 ? (NW * MI == 16 && NW == 8 ? 
 // tiles.  Requires every problem of the launch to have the same token count (the caller vouches: vptr_gemm_desc.split_k = -S on the
 // prototype).  g_wgrad_sync_ws: 64 ints per XCD (counter at [x * 64], leave counter at [x * 64 + 32]); the kernel leaves them zero.
 __device__ int g_wgrad_sync_ws[8 * 64];   // module-scope, zero at load; one launch of the kernel at a time (launches on ONE stream serialise)
-template <int S, int NW = 8, int MI = 16 / NW, int NST = 2>
-__global__ __launch_bounds__(64 * NW, NW * MI == 16 && NW == 8 ? 4 : 2) void vptr_wgrad_p16_sync_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
+template <int S, int NW = 8, int MI = 16 / NW, int NST = 2, int RS = 0>
+__global__ __launch_bounds__(64 * NW, NW * MI == 16 && NW == 8 && !RS ? 4 : 2) void vptr_wgrad_p16_sync_kernel(const vptr_gemm_desc* __restrict__ descs, const int* __restrict__ tile_start,
                                                                     const int count, const int total_tiles) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char p16_smem[];
   int* const ws = g_wgrad_sync_ws;
@@ -722,7 +946,7 @@ __global__ __launch_bounds__(64 * NW, NW * MI == 16 && NW == 8 ? 4 : 2) void vpt
     sy.base = r * slots * per_tile;
     sy.n = min(slots, mine - r * slots);
     if (r > 0) __syncthreads();   // the previous tile's last stage is still being read by slower waves
-    wgrad_p16_tile<NST, S, NW, MI>(descs[lo], lg - tile_start[lo], p16_smem, sy);
+    wgrad_p16_tile<NST, S, NW, MI, RS>(descs[lo], lg - tile_start[lo], p16_smem, sy);
   }
   if (threadIdx.x == 0) {   // the last workgroup of this XCD to leave puts the two words back to zero for the next launch
     int* done = ws + xcd * 64 + 32;
@@ -916,6 +1140,32 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
     else vptr_gemm_p16_kernel256<1><<<t256, GNT, 2 * P16_STAGE256, st>>>(d, rows);
     return 0;
   }
+  // register-staged operand path (round 6): VPTR_GEMM_RS = 0 off, 1 grids of at most one workgroup per CU, 2 every grid;
+  // VPTR_GEMM_RS_SETS = 1 | 2 register sets for the lone grids
+  static int rs_mode = -1, rs_sets = 2;
+  if (rs_mode < 0) {
+    const char* e = getenv("VPTR_GEMM_RS");
+    rs_mode = e ? atoi(e) : 0;
+    const char* f = getenv("VPTR_GEMM_RS_SETS");
+    rs_sets = (f && atoi(f) == 1) ? 1 : 2;
+    bool ok = true;
+#define RS_ATTR(E, R, W) ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_gemm_p16_rs_kernel<E, R, W>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) == hipSuccess
+    RS_ATTR(0, 1, 1); RS_ATTR(1, 1, 1); RS_ATTR(3, 1, 1); RS_ATTR(4, 1, 1);
+    RS_ATTR(0, 2, 1); RS_ATTR(1, 2, 1); RS_ATTR(3, 2, 1); RS_ATTR(4, 2, 1);
+    RS_ATTR(0, 1, 2); RS_ATTR(1, 1, 2); RS_ATTR(3, 1, 2); RS_ATTR(4, 1, 2);
+#undef RS_ATTR
+    if (!ok) rs_mode = 0;
+  }
+  if ((rs_mode == 2 || (rs_mode == 1 && lone)) && !(lean4 && lone && !lone4)) {
+    const int e = lean4 ? 4 : (lean3 ? 3 : (lean ? 1 : 0));
+    const int arg = (e == 1 || e == 0 ? rows : 1) | p16_prio_flag();
+#define RS_GO(E, R, W) vptr_gemm_p16_rs_kernel<E, R, W><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, arg)
+    if (lone && rs_sets == 2) { if (e == 4) RS_GO(4, 2, 1); else if (e == 3) RS_GO(3, 2, 1); else if (e == 1) RS_GO(1, 2, 1); else RS_GO(0, 2, 1); }
+    else if (lone)            { if (e == 4) RS_GO(4, 1, 1); else if (e == 3) RS_GO(3, 1, 1); else if (e == 1) RS_GO(1, 1, 1); else RS_GO(0, 1, 1); }
+    else                      { if (e == 4) RS_GO(4, 1, 2); else if (e == 3) RS_GO(3, 1, 2); else if (e == 1) RS_GO(1, 1, 2); else RS_GO(0, 1, 2); }
+#undef RS_GO
+    return 0;
+  }
   if (lean4 && lone4) vptr_gemm_p16_kernel<4, 4><<<tiles, GNT, 4 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
   else if (lean4 && !lone) vptr_gemm_p16_kernel<4, 2><<<tiles, GNT, 2 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
   else if (lean3 && lone4) vptr_gemm_p16_kernel<3, 4><<<tiles, GNT, 4 * P16_STAGE, st>>>(d, 1 | p16_prio_flag());
@@ -974,7 +1224,29 @@ int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* des
                        hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<2, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess))
       waves = 8;
   }
+  // register-staged operand path (round 6): VPTR_WGRAD_RS bit 0 = the 256-row launches, bit 1 = the 128-row launches (on the four-wave geometry)
+  static int rs = -1;
+  if (rs < 0) {
+    const char* e = getenv("VPTR_WGRAD_RS");
+    rs = e ? atoi(e) : 0;
+    constexpr int S256 = 256 * 128 + 24 * 1024;
+    if (rs && (hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_sync_kernel<16, 8, 4, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * S256) != hipSuccess ||
+               hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<2, 0, 8, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * S256) != hipSuccess ||
+               hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_sync_kernel<16, 4, 4, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
+               hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<2, 0, 4, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess ||
+               hipFuncSetAttribute(reinterpret_cast<const void*>(&vptr_wgrad_p16_kernel<2, 1, 4, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P16_STAGE) != hipSuccess))
+      rs = 0;
+  }
   // 256-row tiles (split_k -2: panel-synchronous, -3: plain; the host counted this launch's tiles with 256 rows): one workgroup per CU
+  if ((proto->split_k == -2 || proto->split_k == -3) && (rs & 1)) {
+    constexpr int STG256 = 256 * 128 + 24 * 1024;
+    VPTR_CHECK(proto->atomic, "vptr_gemm_grouped(p16): 256-row tiles accumulate with atomics only");
+    if (proto->split_k == -2 && sync_s && total_tiles >= 512 && vptr_cu_count() > 0 && vptr_cu_count() % 8 == 0)
+      vptr_wgrad_p16_sync_kernel<16, 8, 4, 2, 1><<<vptr_cu_count(), GNT, 2 * STG256, st>>>(descs_dev, tile_start_dev, count, total_tiles);
+    else
+      vptr_wgrad_p16_kernel<2, 0, 8, 4, 1><<<total_tiles, GNT, 2 * STG256, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), 0);
+    return 0;
+  }
   if (proto->split_k == -2 || proto->split_k == -3) {
     constexpr int STG256 = 256 * 128 + 24 * 1024;
     static bool attr256 = false;
@@ -1011,6 +1283,13 @@ int vptr_wgrad_p16_launch(const vptr_gemm_desc* proto, const vptr_gemm_desc* des
       vptr_wgrad_p16_sync_kernel<16, 8, 3, 3><<<vptr_cu_count(), GNT, 3 * STG192, st>>>(descs_dev, tile_start_dev, count, total_tiles);
     else
       vptr_wgrad_p16_kernel<3, 0, 8, 3><<<total_tiles, GNT, 3 * STG192, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), 0);
+    return 0;
+  }
+  if ((rs & 2) && proto->split_k >= -1) {   // 128-row launches, register-staged, four waves of 64 x 96
+    if (sync_s && proto->split_k == -1 && proto->atomic && total_tiles >= 1024 && vptr_cu_count() > 0 && vptr_cu_count() % 4 == 0)
+      vptr_wgrad_p16_sync_kernel<16, 4, 4, 2, 1><<<2 * vptr_cu_count(), 256, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, total_tiles);
+    else if (!proto->atomic) vptr_wgrad_p16_kernel<2, 1, 4, 4, 1><<<total_tiles, 256, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), 0);
+    else vptr_wgrad_p16_kernel<2, 0, 4, 4, 1><<<total_tiles, 256, 2 * P16_STAGE, st>>>(descs_dev, tile_start_dev, count, xmode | p16_prio_flag(), 0);
     return 0;
   }
   if (sync_s && proto->split_k == -1 && proto->atomic && total_tiles >= 1024 && vptr_cu_count() > 0 && vptr_cu_count() % 4 == 0) {

@@ -1116,23 +1116,35 @@ def _engine_accumulates_into(leaf):
     will = getattr(torch._C, "_will_engine_execute_node", None)
     if will is None:      # a torch build without the query: take the conservative autograd hand-off
         return False
-    ent = _acc_nodes.get(id(leaf))
-    acc = ent[1] if ent is not None and ent[0]() is leaf else None
-    if acc is None:       # the AccumulateGrad node of a leaf is unique and lives as long as the leaf: look it up once per parameter
-        import weakref
+    # the AccumulateGrad node of a leaf is unique, but it OWNS its variable: a process-wide cache of nodes would pin every parameter
+    # (with its .grad and the arena range it views) for the life of the process.  The cache therefore lives for ONE
+    # backward pass: keyed by the engine's graph-task id, emptied by an end-of-backward callback (and by the next pass, should the
+    # callback of a failed pass never have run).
+    task = torch._C._current_graph_task_id()
+    if _acc_nodes["task"] != task:
+        _acc_nodes["nodes"].clear()
+        _acc_nodes["task"] = task
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_drop_acc_nodes)
+        except RuntimeError:   # not inside a backward pass
+            pass
+    acc = _acc_nodes["nodes"].get(id(leaf))
+    if acc is None:
         with torch.enable_grad():
             acc = leaf.view_as(leaf).grad_fn.next_functions[0][0]
-        if len(_acc_nodes) > 8192:
-            for k in [k for k, e in _acc_nodes.items() if e[0]() is None]:
-                del _acc_nodes[k]
-        _acc_nodes[id(leaf)] = (weakref.ref(leaf), acc)
+        _acc_nodes["nodes"][id(leaf)] = acc
     try:
         return bool(will(acc))
     except (RuntimeError, TypeError):
         return False
 
 
-_acc_nodes = {}    # id(leaf) -> (weakref(leaf), its AccumulateGrad node)
+_acc_nodes = {"task": None, "nodes": {}}    # graph-task id -> {id(leaf): its AccumulateGrad node}, for the running backward pass only
+
+
+def _drop_acc_nodes():
+    _acc_nodes["nodes"].clear()
+    _acc_nodes["task"] = None
 
 
 def _loose_grad_for(t):
