@@ -211,15 +211,15 @@ def gemm_roofline(trainer, past, fut, precision):
     import vptr_amd.ops as ops
     NPASS = 3   # instrumented steps: the grouped tn kernel is launched once per step, one sample of it is too noisy (8.8 vs 9.7 ms seen)
     recs, opt_recs = [], []
-    ops._gemm_prof = recs
-    ops._opt_prof = opt_recs
+    ops.profiling.gemm = recs
+    ops.profiling.opt = opt_recs
     try:
         for _ in range(NPASS):
             trainer.step(past, fut)
         torch.cuda.synchronize()
     finally:
-        ops._gemm_prof = None
-        ops._opt_prof = None
+        ops.profiling.gemm = None
+        ops.profiling.opt = None
     by = {}
     for key, flops, e0, e1 in recs:
         ms = e0.elapsed_time(e1)

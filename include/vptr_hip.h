@@ -27,7 +27,7 @@ extern "C" {
 
 typedef void* vptr_stream_t; /* hipStream_t */
 
-int vptr_abi_version(void); /* 8 */
+int vptr_abi_version(void); /* 9 */
 const char* vptr_last_error(void);
 
 /* Run-to-run reproducibility (ABI 8).  The reference (cuDNN / cuBLAS defaults, train_NAR.py) is not bit-deterministic and neither is the
@@ -365,6 +365,19 @@ int vptr_dwconv3x3_fwd(const float* x, const float* w9, const float* b, float* y
                        float* frame_stats, vptr_stream_t stream);
 int vptr_dwconv3x3_bwd(const float* dy, const float* x, const float* w9, float* dx, float* dw9, float* db, int frames,
                        int H, int W, int F, vptr_stream_t stream);
+/* ABI 9.  The first normalisation of the conv-FFN folded into the depthwise kernel's load path (VidHRFormer_modules.py:430-434: fc1 ->
+ * norm1 = LayerNorm((F,H,W)) -> act1 -> dw3x3): x is the RAW output of fc1, raw_stats its per-frame sum / sum of squares as left by the GEMM
+ * epilogue (vptr_gemm_desc::frame_stats), aff_w / aff_b the channel-last [H*W, F] affine of the normalisation.  y = dw3x3(act(norm(x))) (+ its
+ * own frame_stats, as vptr_dwconv3x3_fwd); mean_out / rstd_out [frames] are written for the normalisation's backward pass
+ * (vptr_norm_act_bwd*); a_half (may be NULL) receives act(norm(x)) as fp16 [frames*H*W, F] -- the only thing the backward pass needs of the
+ * activated tensor is the x operand of the depthwise weight gradient, vptr_dwconv3x3_bwd_xh.  Needs W even, W / 2 dividing 16 and
+ * (W/2)*(F/4) % 64 == 0; no fallback. */
+int vptr_dwconv3x3_norm_fwd(const float* x, const float* raw_stats, const float* aff_w, const float* aff_b, float eps, int act,
+                            const float* w9, const float* b, float* y, void* a_half, float* mean_out, float* rstd_out,
+                            int frames, int H, int W, int F, float* frame_stats, vptr_stream_t stream);
+/* vptr_dwconv3x3_bwd with the forward input given as the fp16 copy vptr_dwconv3x3_norm_fwd wrote (W even) */
+int vptr_dwconv3x3_bwd_xh(const float* dy, const void* x_half, const float* w9, float* dx, float* dw9, float* db, int frames,
+                          int H, int W, int F, vptr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise / layout helpers

@@ -250,3 +250,66 @@ def test_frame_stats_large_mean_guard(ops, dev):
     z = xh.reshape(rows, F_) * nw.double().repeat(frames, 1) + nb.double().repeat(frames, 1)
     ref = 0.5 * z * (1.0 + torch.erf(z / 2 ** 0.5))
     assert float((a.double() - ref).norm() / ref.norm()) < 1e-4
+
+
+def test_norm_dwconv_fused_matches_chain_and_fp64(ops, dev):
+    """round 6: LayerNorm((F,H,W)) + GELU folded into the depthwise kernel's load path (ops.norm_dwconv3x3: VidHRFormer_modules.py:430-434)
+    == norm_act followed by dwconv3x3 (forward, frame statistics of the output, every gradient) and == fp64 torch.  The depthwise WEIGHT
+    gradient reads the activated tensor from an fp16 side copy: its bound is the one the model-level parity tests leave (2e-4)."""
+    frames, H, W, C, F_ = 6, 8, 8, 48, 192
+    HW, rows = H * W, frames * H * W
+    assert ops.norm_dwconv_ok(rows, HW, F_, H, W)
+    x0, W1, b1 = rn((rows, C), 1).to(dev), rn((F_, C), 2, C ** -0.5).to(dev), rn((F_,), 3).to(dev)
+    aw, ab = (rn((HW, F_), 5).abs() + 0.5).to(dev), rn((HW, F_), 6, 0.3).to(dev)
+    dwt, dbias = rn((F_, 1, 3, 3), 7, 0.3).to(dev), rn((F_,), 8, 0.1).to(dev)
+    cot = rn((rows, F_), 9).to(dev)
+    res = []
+    for fused in (True, False):
+        st, st2 = ops.frame_stats_buffer(frames, dev), ops.frame_stats_buffer(frames, dev)
+        with torch.no_grad():
+            y = ops.linear(x0, W1, b1, frame_stats=st, frame_rows=HW)
+        xin = y.clone().requires_grad_(True)
+        pw, pb, pd, pdb = (t.clone().requires_grad_(True) for t in (aw, ab, dwt, dbias))
+        if fused:
+            o = ops.norm_dwconv3x3(xin, pw, pb, pd, pdb, frames, H, W, st, frame_stats=st2)
+        else:
+            a = ops.norm_act(xin, pw, pb, "ln", HW, True, raw_stats=st)
+            o = ops.dwconv3x3(a, pd, pdb, frames, H, W, frame_stats=st2)
+        (o * cot).sum().backward()
+        res.append((o.detach(), st2.clone(), xin.grad.clone(), pw.grad.clone(), pb.grad.clone(), pd.grad.clone(), pdb.grad.clone(), y))
+    names = ("y", "stats", "dx", "daff_w", "daff_b", "ddw", "ddb")
+    for n, a, r in zip(names, res[0], res[1]):
+        assert rel(a, r) < (2e-4 if n == "ddw" else 2e-5), (n, rel(a, r))
+    # fp64 reference on the CPU
+    y = res[0][7].double().cpu().requires_grad_(True)
+    pw, pb, pd, pdb = (t.double().cpu().requires_grad_(True) for t in (aw, ab, dwt, dbias))
+    yf = y.view(frames, HW * F_)
+    xh = ((yf - yf.mean(1, keepdim=True)) / torch.sqrt(yf.var(1, unbiased=False, keepdim=True) + 1e-5)).view(frames, HW, F_)
+    a = F.gelu(xh * pw + pb)
+    o = F.conv2d(a.view(frames, H, W, F_).permute(0, 3, 1, 2), pd, pdb, padding=1, groups=F_).permute(0, 2, 3, 1).reshape(rows, F_)
+    (o * cot.double().cpu()).sum().backward()
+    for n, a_, r in zip(names, res[0], (o.detach(), None, y.grad, pw.grad, pb.grad, pd.grad, pdb.grad)):
+        if r is not None:
+            assert rel(a_.double().cpu(), r) < (2e-4 if n == "ddw" else 3e-5), (n, rel(a_.double().cpu(), r))
+
+
+def test_norm_dwconv_large_mean_guard(ops, dev):
+    """the fused kernel's per-wave form of the large-mean guard (test_frame_stats_large_mean_guard): fc1 output 40 +- 0.02"""
+    frames, H, W, C, F_ = 4, 8, 8, 64, 512
+    HW, rows = H * W, frames * H * W
+    assert ops.norm_dwconv_ok(rows, HW, F_, H, W)
+    x, W1 = rn((rows, C), 30), rn((F_, C), 31, 0.002)
+    b = torch.full((F_,), 40.0)
+    nw, nb = rn((HW, F_), 36).abs() + 0.5, rn((HW, F_), 37, 0.1)
+    dwt = rn((F_, 1, 3, 3), 38, 0.3)
+    x, W1, b, nw, nb, dwt = (t.to(dev) for t in (x, W1, b, nw, nb, dwt))
+    st = ops.frame_stats_buffer(frames, dev)
+    y = ops.linear(x, W1, b, frame_stats=st, frame_rows=HW)
+    with torch.no_grad():
+        o = ops.norm_dwconv3x3(y, nw, nb, dwt, None, frames, H, W, st)
+    yd = y.double().reshape(frames, HW * F_)
+    xh = (yd - yd.mean(1, keepdim=True)) / torch.sqrt(yd.var(1, unbiased=False, keepdim=True) + 1e-5)
+    z = xh.reshape(frames, HW, F_) * nw.double() + nb.double()
+    a = 0.5 * z * (1.0 + torch.erf(z / 2 ** 0.5))
+    ref = F.conv2d(a.view(frames, H, W, F_).permute(0, 3, 1, 2), dwt.double(), None, padding=1, groups=F_).permute(0, 2, 3, 1).reshape(rows, F_)
+    assert float((o.double() - ref).norm() / ref.norm()) < 1e-4

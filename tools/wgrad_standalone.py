@@ -53,7 +53,7 @@ def main():
     print("problems %d  shapes %s  GF %.1f" % (len(items), shapes, flops / 1e9))
     # build the descriptor tables ONCE (host work + uploads), then time bare launches of the kernel
     keep, calls = [], []
-    orig_upload, orig_launch = ops._to_device_async, ops.lib.vptr_gemm_grouped
+    orig_upload, orig_launch = ops.wgrad._to_device_async, ops.lib.vptr_gemm_grouped
 
     def upload(b, d):
         t = orig_upload(b, d)
@@ -66,9 +66,9 @@ def main():
         ctypes.memmove(ctypes.byref(pc), proto, ctypes.sizeof(pc))
         calls.append((pc, raw, st, n, total))
         return orig_launch(proto, raw, st, n, total, stream)
-    ops._to_device_async, ops.lib.vptr_gemm_grouped = upload, launch
+    ops.wgrad._to_device_async, ops.lib.vptr_gemm_grouped = upload, launch
     ops._launch_wgrad_group(items)
-    ops._to_device_async, ops.lib.vptr_gemm_grouped = orig_upload, orig_launch
+    ops.wgrad._to_device_async, ops.lib.vptr_gemm_grouped = orig_upload, orig_launch
     torch.cuda.synchronize()
     import ctypes
     from vptr_amd._lib import stream

@@ -19,11 +19,11 @@ enc, dec, T = bench.build_models(dev, 0.1)
 tr = NARTrainer(enc, dec, T, batch_size=16, lr=1e-4, max_grad_norm=1.0, lam_pc=0.1)
 past, fut = bench.synth_batch(16, 0, dev)
 recs = []
-ops._gemm_prof = recs
+ops.profiling.gemm = recs
 for _ in range(steps):
     tr.step(past, fut)
 torch.cuda.synchronize()
-ops._gemm_prof = None
+ops.profiling.gemm = None
 ms = [e0.elapsed_time(e1) for key, fl, e0, e1 in recs if len(key) > 4 and str(key[4]).startswith("grouped") and key[4] != "grouped_split"]
 print("grouped weight-gradient launches: %d, ms: %s" % (len(ms), " ".join("%.2f" % m for m in ms)))
 out = torch.zeros(8, dtype=torch.int32, device=dev)

@@ -91,6 +91,8 @@ SIGNATURES = {
     "vptr_norm_act_bwd_partials": [I, I, I, I],
     "vptr_dwconv3x3_fwd": [P, P, P, P, I, I, I, I, P, P],
     "vptr_dwconv3x3_bwd": [P, P, P, P, P, P, I, I, I, I, P],
+    "vptr_dwconv3x3_norm_fwd": [P, P, P, P, F, I, P, P, P, P, P, P, I, I, I, I, P, P],
+    "vptr_dwconv3x3_bwd_xh": [P, P, P, P, P, P, I, I, I, I, P],
     "vptr_nchw_to_tokens": [P, P, I, I, I, P],
     "vptr_tokens_to_nchw": [P, P, I, I, I, I, P],
     "vptr_nchw_to_tokens_masked": [P, P, P, I, I, I, P],
@@ -138,7 +140,7 @@ def _load():
         fn.restype = c_int
     lib.vptr_abi_version.restype = c_int
     lib.vptr_last_error.restype = ctypes.c_char_p
-    if lib.vptr_abi_version() != 8:
+    if lib.vptr_abi_version() != 9:
         raise ImportError("vptr_amd: ABI version mismatch in %s" % LIB_PATH)
     return lib
 

@@ -305,7 +305,7 @@ extern "C" int vptr_winattn_fwd(const float* q, const float* k, const float* v, 
   if (bias_table) VPTR_CHECK(rel_index != nullptr, "winattn_fwd: bias table needs rel_index");
   if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "winattn_fwd: dropout needs seed_dev");
   const int L = ws * ws, hd = C / nh;
-  if (vptr_attn_mfma_ok(L, L, C, nh, 0)) {
+  if (vptr_attn_mfma_ok(L, L, C, nh, 0, (int64_t)B * (H / ws) * (W / ws))) {
     AmGeom gm = {0, H, W, ws, 0, 0, 0, L, L, C, nh, hd, B * (H / ws) * (W / ws)};
     const int rc = vptr_attn_mfma_fwd(q, k, v, bias_table, rel_index, o, gm, 0, dropout_p, seed_dev, site, p16, (hipStream_t)stream);
     if (rc) return rc;
@@ -458,7 +458,7 @@ extern "C" int vptr_winattn_bwd_ws(const float* q, const float* k, const float* 
   if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "winattn_bwd: dropout needs seed_dev");
   const int L = ws * ws, hd = C / nh, ntab = (2 * ws - 1) * (2 * ws - 1);
   const int nwin = B * (H / ws) * (W / ws);
-  if (vptr_attn_mfma_ok(L, L, C, nh, 0)) {
+  if (vptr_attn_mfma_ok(L, L, C, nh, 0, (int64_t)B * (H / ws) * (W / ws))) {
     AmGeom gm = {0, H, W, ws, 0, 0, 0, L, L, C, nh, hd, nwin};
     const int rc = vptr_attn_mfma_bwd(q, k, v, bias_table, rel_index, dout, dq, dk, dv, dbias_table, gm, 0, dropout_p, seed_dev, site, dq_scale, p16,
                                       (hipStream_t)stream);
@@ -765,7 +765,7 @@ extern "C" int vptr_tattn_fwd(const float* q, const float* k, const float* v, fl
   if (causal) VPTR_CHECK(Tq == Tk, "tattn_fwd: causal mask needs Tq == Tk");
   if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "tattn_fwd: dropout needs seed_dev");
   const int hd = C / nh;
-  if (vptr_attn_mfma_ok(Tq, Tk, C, nh, causal)) {
+  if (vptr_attn_mfma_ok(Tq, Tk, C, nh, causal, (int64_t)Nb * HW)) {
     AmGeom gm = {1, 0, 0, 0, Tq, Tk, HW, Tq, Tk, C, nh, hd, Nb * HW};
     const int rc = vptr_attn_mfma_fwd(q, k, v, nullptr, nullptr, o, gm, causal, dropout_p, seed_dev, site, p16, (hipStream_t)stream);
     if (rc) return rc;
@@ -894,7 +894,7 @@ extern "C" int vptr_tattn_bwd(const float* q, const float* k, const float* v, co
   if (causal) VPTR_CHECK(Tq == Tk, "tattn_bwd: causal mask needs Tq == Tk");
   if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "tattn_bwd: dropout needs seed_dev");
   const int hd = C / nh;
-  if (vptr_attn_mfma_ok(Tq, Tk, C, nh, causal)) {
+  if (vptr_attn_mfma_ok(Tq, Tk, C, nh, causal, (int64_t)Nb * HW)) {
     AmGeom gm = {1, 0, 0, 0, Tq, Tk, HW, Tq, Tk, C, nh, hd, Nb * HW};
     const int rc = vptr_attn_mfma_bwd(q, k, v, nullptr, nullptr, dout, dq, dk, dv, nullptr, gm, causal, dropout_p, seed_dev, site, dq_scale, p16,
                                       (hipStream_t)stream);

@@ -14,8 +14,9 @@ struct AmGeom {
   int idx32;           // 1: groups * nh * Lq * Lk < 2^32 -- dropout element indices fit 32 bits (same hash, cheaper index arithmetic)
 };
 
-// true when the MFMA kernels cover the geometry (otherwise the fp32 vector kernels of attn.hip run); VPTR_ATTN_MFMA=0 disables them
-bool vptr_attn_mfma_ok(int Lq, int Lk, int C, int nh, int causal);
+// true when the MFMA kernels cover the geometry AND the tensor size (32-bit row offsets: < 2^31 elements) -- otherwise the fp32 vector
+// kernels of attn.hip run; VPTR_ATTN_MFMA=0 disables them
+bool vptr_attn_mfma_ok(int Lq, int Lk, int C, int nh, int causal, int64_t groups /* problems: windows, or N * HW pixels */);
 int vptr_attn_mfma_fwd(const float* q, const float* k, const float* v, const float* table, const int64_t* rel_index, float* o, const AmGeom& gm, int causal,
                        float p, const uint64_t* seed_dev, uint32_t site, int p16, hipStream_t st);
 int vptr_attn_mfma_bwd(const float* q, const float* k, const float* v, const float* table, const int64_t* rel_index, const float* dout, float* dq, float* dk,

@@ -768,12 +768,14 @@ static int am_enabled() {   // read per call: tests switch the mode inside one p
 }
 
 // true when the MFMA kernels cover the geometry (otherwise the fp32 vector kernels of attn.hip run)
-bool vptr_attn_mfma_ok(int Lq, int Lk, int C, int nh, int causal) {
+bool vptr_attn_mfma_ok(int Lq, int Lk, int C, int nh, int causal, int64_t groups) {
   const int hd = C / nh;
   // VPTR_ATTN_MFMA: 0 = never, 1 (default) = problems with more than 16 rows (the 16-token fp32 vector kernels of attn.hip are
   // faster on 16 x 16 problems: K64 step 56.9 vs 61.0 ms), 2 = every covered geometry
   const int mode = am_enabled();
   if (mode == 0 || (mode == 1 && Lq <= 16 && Lk <= 16)) return false;
+  // row offsets are 32-bit inside these kernels (am_derive): tensors of 2^31 or more elements take the fp32 vector kernels of attn.hip
+  if (groups * (int64_t)(Lq > Lk ? Lq : Lk) * C >= ((int64_t)1 << 31)) return false;
   return Lq >= 1 && Lk >= 1 && Lq <= AM_MAXL && Lk <= AM_MAXL && hd % 2 == 0 && C % 2 == 0 && hd <= 96 && (!causal || Lq == Lk);
 }
 

@@ -2,6 +2,7 @@
 // All kernels here are HBM-bound: float4 accesses, one wave per row for row-wise ops, thread-per-column sweeps with
 // coalesced row reads for column reductions (partials combined with fp32 atomics).
 #include "common.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim: one wave per row, 4 rows per 256-thread block.
@@ -1319,15 +1320,22 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
 // Two adjacent x columns per thread (W even): 4 column loads per row for 2 outputs instead of 6 -- the single-column version
 // is bound by the CU's vector-memory issue rate (48 us against a 35 us HBM time at the step's shape).
 struct DwRow2 { float4 c0, c1, c2, c3; };   // columns xw0-1, xw0, xw0+1, xw0+2 (out-of-range ones zeroed)
-__device__ __forceinline__ DwRow2 dw_load_row2(const float4* __restrict__ x, int64_t frame_row0, int row, int H, int xw0, int W, int F4,
+typedef __attribute__((ext_vector_type(4))) _Float16 half4_t;   // 4 channels of an fp16 side copy (dwconv_norm_fwd3_kernel)
+__device__ __forceinline__ float4 dw_ld4(const float4* __restrict__ x, const int64_t i) { return x[i]; }
+__device__ __forceinline__ float4 dw_ld4(const half4_t* __restrict__ x, const int64_t i) {
+  const half4_t h = x[i];
+  return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+}
+template <typename XT>
+__device__ __forceinline__ DwRow2 dw_load_row2(const XT* __restrict__ x, int64_t frame_row0, int row, int H, int xw0, int W, int F4,
                                                int c4) {
   const float rok = (row >= 0 && row < H) ? 1.f : 0.f;
   const int64_t base = (frame_row0 + min(max(row, 0), H - 1)) * W;
   DwRow2 o;
-  o.c0 = scale4(x[(base + max(xw0 - 1, 0)) * F4 + c4], xw0 > 0 ? rok : 0.f);
-  o.c1 = scale4(x[(base + xw0) * F4 + c4], rok);
-  o.c2 = scale4(x[(base + xw0 + 1) * F4 + c4], rok);
-  o.c3 = scale4(x[(base + min(xw0 + 2, W - 1)) * F4 + c4], xw0 + 2 < W ? rok : 0.f);
+  o.c0 = scale4(dw_ld4(x, (base + max(xw0 - 1, 0)) * F4 + c4), xw0 > 0 ? rok : 0.f);
+  o.c1 = scale4(dw_ld4(x, (base + xw0) * F4 + c4), rok);
+  o.c2 = scale4(dw_ld4(x, (base + xw0 + 1) * F4 + c4), rok);
+  o.c3 = scale4(dw_ld4(x, (base + min(xw0 + 2, W - 1)) * F4 + c4), xw0 + 2 < W ? rok : 0.f);
   return o;
 }
 __global__ __launch_bounds__(256) void dwconv_fwd2_kernel(const float* __restrict__ x_, const float* __restrict__ w9,
@@ -1438,21 +1446,169 @@ __global__ __launch_bounds__(256) void dwconv_fwd3_kernel(const float* __restric
     }
   }
 }
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6: LayerNorm((F,H,W)) + activation of the conv-FFN's first normalisation applied in the LOAD path of the depthwise kernel
+// (VidHRFormer_modules.py:430-434: fc1 -> norm1 -> act1 -> dw3x3).  x is the RAW output of fc1, whose epilogue left the per-frame sum / sum of
+// squares in raw_stats; every element is normalised, activated once by the thread that owns its column (the neighbours get it through the
+// DPP shifts of dwconv_fwd3_kernel) and the activated tensor never exists in fp32: what the backward pass needs of it -- the x operand
+// of the depthwise WEIGHT gradient -- is kept as fp16 (ah; half the bytes; |GELU| < 65504, relative rounding 2^-12 on one factor of a
+// 10 240-term sum).  Per conv-FFN forward: 86.5 MB read + 86.5 MB written + 43 MB written instead of 2 x (86.5 + 86.5) MB in two launches.
+// mean_out / rstd_out: the statistics the backward pass of the normalisation reads (same values in every wave of a frame: same code,
+// same data; the rare large-mean guard of norm_act_fwd_kernel runs per wave here).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 dwn_act4(const float4 v, const float m, const float r, const float4 w, const float4 b, const int act, const float ok) {
+  float4 o;
+  o.x = vptr_act((v.x - m) * r * w.x + b.x, act) * ok;
+  o.y = vptr_act((v.y - m) * r * w.y + b.y, act) * ok;
+  o.z = vptr_act((v.z - m) * r * w.z + b.z, act) * ok;
+  o.w = vptr_act((v.w - m) * r * w.w + b.w, act) * ok;
+  return o;
+}
+__device__ __forceinline__ void dwn_store_half4(_Float16* __restrict__ ah, const int64_t e, const float4 v) {
+  const half4_t h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+  *reinterpret_cast<half4_t*>(ah + e) = h;
+}
+__global__ __launch_bounds__(256) void dwconv_norm_fwd3_kernel(const float* __restrict__ x_, const float* __restrict__ raw_stats,
+                                                               const float* __restrict__ aw_, const float* __restrict__ ab_, float eps, int act,
+                                                               const float* __restrict__ w9, const float* __restrict__ b, float* __restrict__ y_,
+                                                               _Float16* __restrict__ ah, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                               int frames, int H, int W, int F4, float* __restrict__ stats) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int W2 = W >> 1;
+  if (idx >= (int64_t)frames * W2 * F4) return;   // whole waves leave together (W2 * F4 % 64 == 0: a wave lies inside one frame)
+  const int xp = (int)(idx % W2), xw0 = xp * 2;
+  const int c4 = (int)((idx / W2) % F4);
+  const int64_t f = idx / ((int64_t)F4 * W2);
+  const float lok = xp > 0 ? 1.f : 0.f, rok_ = xp + 1 < W2 ? 1.f : 0.f;
+  const float4* __restrict__ x = reinterpret_cast<const float4*>(x_);
+  const float4* __restrict__ aw = reinterpret_cast<const float4*>(aw_);
+  const float4* __restrict__ ab = reinterpret_cast<const float4*>(ab_);
+  float4* __restrict__ y = reinterpret_cast<float4*>(y_);
+  // the frame's statistics from its producer's sums (see norm_act_fwd_kernel)
+  const int P = H * W * F4;
+  const float inv_n = 1.f / ((float)P * 4.f);
+  float m = raw_stats[2 * f] * inv_n;
+  const float e2 = raw_stats[2 * f + 1] * inv_n;
+  float var = fmaxf(e2 - m * m, 0.f);
+  if (var < 1e-3f * e2) {   // wave-uniform (f is): |mean| > ~30 std -- exact second pass of this wave over its frame, around the approximate mean
+    const float4* xf = x + f * P;
+    float sq = 0.f, s1 = 0.f;
+    for (int j = threadIdx.x & 63; j < P; j += 64) {
+      const float4 t = xf[j];
+      const float a = t.x - m, b2 = t.y - m, c = t.z - m, d = t.w - m;
+      s1 += (a + b2) + (c + d);
+      sq += (a * a + b2 * b2) + (c * c + d * d);
+    }
+    const float dm = wave_sum(s1) * inv_n;
+    var = fmaxf(wave_sum(sq) * inv_n - dm * dm, 0.f);
+    m += dm;
+  }
+  const float r = rsqrtf(var + eps);
+  if (xp == 0 && c4 == 0) { mean_out[f] = m; rstd_out[f] = r; }
+  float4 w[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) w[t] = reinterpret_cast<const float4*>(w9)[(int64_t)t * F4 + c4];
+  const float4 bias = b ? reinterpret_cast<const float4*>(b)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  // raw operands of one input row (this thread's two columns): x and the two affine tables -- requested one row AHEAD of the row being
+  // activated, so that the six loads of row y + 2 are in flight under the 8 GELUs and 72 FMAs of rows y + 1 / y
+  struct Raw { float4 x1, x2, w1, w2, b1, b2; };
+  auto fetch = [&](const int row) -> Raw {
+    const int rc = min(max(row, 0), H - 1);
+    const int64_t base = ((f * H + rc) * W + xw0) * F4 + c4;
+    const int hw = (rc * W + xw0) * F4 + c4;
+    Raw q;
+    q.x1 = x[base]; q.x2 = x[base + F4];
+#ifdef VPTR_DWN_NOAFF   // elimination build (WRONG results): no affine loads
+    q.w1 = q.w2 = make_float4(1.f, 1.f, 1.f, 1.f); q.b1 = q.b2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#else
+    q.w1 = aw[hw]; q.w2 = aw[hw + F4]; q.b1 = ab[hw]; q.b2 = ab[hw + F4];
+#endif
+    return q;
+  };
+  auto activate = [&](const Raw& q, const int row) -> DwRow2 {
+    const bool in = row >= 0 && row < H;
+    const float rok = in ? 1.f : 0.f;
+    DwRow2 o;
+    o.c1 = dwn_act4(q.x1, m, r, q.w1, q.b1, act, rok);
+    o.c2 = dwn_act4(q.x2, m, r, q.w2, q.b2, act, rok);
+#ifndef VPTR_DWN_NOHALF   // elimination build: no fp16 side copy
+    if (ah && in) {   // every element is the OWN column of exactly one thread
+      const int64_t base = ((f * H + row) * W + xw0) * F4 + c4;
+      dwn_store_half4(ah, base * 4, o.c1);
+      dwn_store_half4(ah, (base + F4) * 4, o.c2);
+    }
+#endif
+    o.c0 = make_float4(dpp_from_prev(o.c2.x) * lok, dpp_from_prev(o.c2.y) * lok, dpp_from_prev(o.c2.z) * lok, dpp_from_prev(o.c2.w) * lok);
+    o.c3 = make_float4(dpp_from_next(o.c1.x) * rok_, dpp_from_next(o.c1.y) * rok_, dpp_from_next(o.c1.z) * rok_, dpp_from_next(o.c1.w) * rok_);
+    return o;
+  };
+  Raw q1 = fetch(0), q2 = fetch(1);
+  DwRow2 r0, r1 = activate(q1, 0);
+  r0.c0 = r0.c1 = r0.c2 = r0.c3 = make_float4(0.f, 0.f, 0.f, 0.f);   // row -1: padding of the ACTIVATED tensor
+  float ssum = 0.f, ssq = 0.f;
+  for (int yh = 0; yh < H; ++yh) {
+    const Raw q3 = fetch(yh + 2);              // (clamped address; its values are only used while yh + 2 < H)
+    const DwRow2 r2 = activate(q2, yh + 1);    // row H: all zeros (rok)
+    float4 a = bias, a2 = bias;
+    fma4(a, w[0], r0.c0); fma4(a, w[1], r0.c1); fma4(a, w[2], r0.c2);
+    fma4(a, w[3], r1.c0); fma4(a, w[4], r1.c1); fma4(a, w[5], r1.c2);
+    fma4(a, w[6], r2.c0); fma4(a, w[7], r2.c1); fma4(a, w[8], r2.c2);
+    fma4(a2, w[0], r0.c1); fma4(a2, w[1], r0.c2); fma4(a2, w[2], r0.c3);
+    fma4(a2, w[3], r1.c1); fma4(a2, w[4], r1.c2); fma4(a2, w[5], r1.c3);
+    fma4(a2, w[6], r2.c1); fma4(a2, w[7], r2.c2); fma4(a2, w[8], r2.c3);
+    y[((f * H + yh) * W + xw0) * F4 + c4] = a;
+    y[((f * H + yh) * W + xw0 + 1) * F4 + c4] = a2;
+    if (stats) {
+      ssum += ((a.x + a.y) + (a.z + a.w)) + ((a2.x + a2.y) + (a2.z + a2.w));
+      ssq += ((a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w)) + ((a2.x * a2.x + a2.y * a2.y) + (a2.z * a2.z + a2.w * a2.w));
+    }
+    r0 = r1;
+    r1 = r2;
+    q2 = q3;
+  }
+  if (stats) {
+    const float S = wave_sum(ssum), Q = wave_sum(ssq);
+    if ((threadIdx.x & 63) == 0) {
+      unsafeAtomicAdd(stats + 2 * f, S);
+      unsafeAtomicAdd(stats + 2 * f + 1, Q);
+    }
+  }
+}
+extern "C" int vptr_dwconv3x3_norm_fwd(const float* x, const float* raw_stats, const float* aff_w, const float* aff_b, float eps, int act,
+                                       const float* w9, const float* b, float* y, void* a_half, float* mean_out, float* rstd_out,
+                                       int frames, int H, int W, int F, float* frame_stats, vptr_stream_t stream) {
+  VPTR_CHECK(x && raw_stats && aff_w && aff_b && w9 && y && mean_out && rstd_out && frames > 0 && H > 0 && W > 0 && F > 0 && F % 4 == 0,
+             "dwconv3x3_norm_fwd: bad arguments");
+  const int W2 = W / 2;
+  VPTR_CHECK(W % 2 == 0 && W2 >= 1 && 16 % W2 == 0 && (W2 * (F / 4)) % 64 == 0,
+             "dwconv3x3_norm_fwd: needs W even, W / 2 dividing 16 and (W/2)*(F/4) %% 64 == 0 (got W %d, F %d)", W, F);
+  VPTR_CHECK(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(aff_w) | reinterpret_cast<uintptr_t>(aff_b) |
+               reinterpret_cast<uintptr_t>(w9) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 && (reinterpret_cast<uintptr_t>(a_half) & 7) == 0,
+             "dwconv3x3_norm_fwd: operands must be 16-byte aligned");
+  const int64_t total = (int64_t)frames * W2 * (F / 4);
+  dwconv_norm_fwd3_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      x, raw_stats, aff_w, aff_b, eps, act, w9, b, y, reinterpret_cast<_Float16*>(a_half), mean_out, rstd_out, frames, H, W, F / 4, frame_stats);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
+
 // dw9[tap, c] += sum_{f,y,x} dy[f,y,x,c] * x[f,y+ky-1,x+kx-1,c];  db[c] += sum dy.
 // Block = 32 channel quads x 8 x-lanes over a chunk of frames; every thread walks its columns with the same rolling window
 // (1 + 3 float4 loads per pixel), the 8 x-lanes are summed through LDS and each block issues 40 atomics per channel quad.
 #define DWB_C4 32
 #define DWB_XL 8
-template <bool PAIR>  // PAIR (W even): lane = (x pair, frame parity), 4 x + 2 dy loads per two pixels instead of 6 + 2
-__global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restrict__ dy_, const float* __restrict__ x_,
+template <bool PAIR, bool XH = false>  // PAIR (W even): lane = (x pair, frame parity), 4 x + 2 dy loads per two pixels instead of 6 + 2; XH: x is the fp16 side copy of dwconv_norm_fwd3_kernel
+__global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restrict__ dy_, const void* __restrict__ x_,
                                                            float* __restrict__ dw9, float* __restrict__ db, int frames, int H,
                                                            int W, int F4, int fpb) {
+  typedef typename std::conditional<XH, half4_t, float4>::type XT;
+  static_assert(PAIR || !XH, "the fp16 operand comes with the paired form");
   __shared__ float red[DWB_XL * DWB_C4 * 41];
   const int cl = threadIdx.x % DWB_C4, xl = threadIdx.x / DWB_C4;
   const int c4 = blockIdx.x * DWB_C4 + cl;
   const bool cok = c4 < F4;
   const int c4c = cok ? c4 : F4 - 1;
-  const float4* __restrict__ x = reinterpret_cast<const float4*>(x_);
+  const XT* __restrict__ x = reinterpret_cast<const XT*>(x_);
   const float4* __restrict__ dy = reinterpret_cast<const float4*>(dy_);
   const int f0 = blockIdx.y * fpb, f1 = min(frames, f0 + fpb);
   float4 acc[9], ab = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1476,7 +1632,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restri
           r1 = r2;
         }
       }
-  } else
+  } else if constexpr (!XH)
   for (int64_t f = f0; f < f1; ++f)
     for (int xw = xl; xw < W; xw += DWB_XL) {
       DwRow r0 = dw_load_row(x, f * H, -1, H, xw, W, F4, c4c), r1 = dw_load_row(x, f * H, 0, H, xw, W, F4, c4c);
@@ -1537,8 +1693,20 @@ extern "C" int vptr_dwconv3x3_fwd(const float* x, const float* w9, const float* 
   return 0;
 }
 
+static int dwconv3x3_bwd_impl(const float* dy, const void* x, int x_half, const float* w9, float* dx, float* dw9, float* db,
+                              int frames, int H, int W, int F, vptr_stream_t stream);
 extern "C" int vptr_dwconv3x3_bwd(const float* dy, const float* x, const float* w9, float* dx, float* dw9, float* db,
                                   int frames, int H, int W, int F, vptr_stream_t stream) {
+  return dwconv3x3_bwd_impl(dy, x, 0, w9, dx, dw9, db, frames, H, W, F, stream);
+}
+// the same with the forward input given as the fp16 side copy vptr_dwconv3x3_norm_fwd wrote (W even)
+extern "C" int vptr_dwconv3x3_bwd_xh(const float* dy, const void* x_half, const float* w9, float* dx, float* dw9, float* db,
+                                     int frames, int H, int W, int F, vptr_stream_t stream) {
+  VPTR_CHECK(W % 2 == 0 && (reinterpret_cast<uintptr_t>(x_half) & 7) == 0, "dwconv3x3_bwd_xh: needs W even and an 8-byte aligned fp16 operand");
+  return dwconv3x3_bwd_impl(dy, x_half, 1, w9, dx, dw9, db, frames, H, W, F, stream);
+}
+static int dwconv3x3_bwd_impl(const float* dy, const void* x, int x_half, const float* w9, float* dx, float* dw9, float* db,
+                              int frames, int H, int W, int F, vptr_stream_t stream) {
   VPTR_CHECK(frames > 0 && H > 0 && W > 0 && F > 0 && F % 4 == 0, "dwconv3x3_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)frames * W * (F / 4);
@@ -1552,7 +1720,9 @@ extern "C" int vptr_dwconv3x3_bwd(const float* dy, const float* x, const float* 
   }
   if (dw9 && db) {
     const int fpb = g_vptr_deterministic ? frames : (frames >= 64 ? 8 : 1);   // deterministic: one adder per tap and channel
-    if (W % 2 == 0)
+    if (x_half)
+      dwconv_bwd_w_kernel<true, true><<<dim3(cdiv(F / 4, DWB_C4), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
+    else if (W % 2 == 0)
       dwconv_bwd_w_kernel<true><<<dim3(cdiv(F / 4, DWB_C4), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
     else
       dwconv_bwd_w_kernel<false><<<dim3(cdiv(F / 4, DWB_C4), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);

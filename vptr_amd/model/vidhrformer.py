@@ -261,8 +261,15 @@ class MlpDWBN(nn.Module):
         buf = ops.frame_stats_buffer(3 * frames, u.device).view(3, frames, 2) if S else None   # one fill for the three normalisations
         st = [buf[i] if k else None for i, k in enumerate((S, Sd, S))]
         h = ops.linear(u, self.fc1.weight.view(F, C), self.fc1.bias, x_p16=x_p16, dy_p16=P, frame_stats=st[0], frame_rows=HW)
-        h = self._norm_act(h, self.norm1, g, dx_p16=P, raw_stats=st[0])
-        h = ops.dwconv3x3(h, self.dw3x3.weight, self.dw3x3.bias, frames, g.H, g.W, frame_stats=st[1])
+        if st[0] is not None and ops.norm_dwconv_ok(rows, HW, F, g.H, g.W) and tuple(self.norm1.normalized_shape[1:]) == (g.H, g.W):
+            # norm1 + act1 in the depthwise kernel's load path: the activated hidden tensor never exists in fp32 (ops.norm_dwconv3x3)
+            w1 = self.norm1.weight.reshape(F, HW).t().contiguous()
+            b1 = self.norm1.bias.reshape(F, HW).t().contiguous()
+            h = ops.norm_dwconv3x3(h, w1, b1, self.dw3x3.weight, self.dw3x3.bias, frames, g.H, g.W, st[0], frame_stats=st[1],
+                                   eps=self.norm1.eps, dx_p16=P)
+        else:
+            h = self._norm_act(h, self.norm1, g, dx_p16=P, raw_stats=st[0])
+            h = ops.dwconv3x3(h, self.dw3x3.weight, self.dw3x3.bias, frames, g.H, g.W, frame_stats=st[1])
         h = self._norm_act(h, self.norm2, g, dropout_p=p, site=site, out_p16=P, raw_stats=st[1])
         h = ops.linear(h, self.fc2.weight.view(self.out_features, F), self.fc2.bias, x_p16=P, dy_p16=P, frame_stats=st[2], frame_rows=HW)
         return self._norm_act(h, self.norm3, g, dropout_p=p, site=site + 1, rowscale=rowscale, rs_div=rs_div, rs_mod=rs_mod,

@@ -192,7 +192,7 @@ class FlatAdamW:
             self.sumsq.zero_()
             check(lib.vptr_sumsq(ptr(self.grad), n, ptr(self.sumsq), stream()), "vptr_sumsq")
         self.step_dev.add_(1.0)
-        prof = ops._opt_prof
+        prof = ops.profiling.opt
         if prof is not None:   # bench.py's HBM roofline pass: HIP events on the launch stream around the optimizer's streaming kernels
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             ev[0].record()
@@ -444,6 +444,22 @@ class NARTrainer:
             return self._static_out
         return self._step_impl(past, future)
 
+    @staticmethod
+    def _warm_up_for_capture(warmup, step):
+        """eager steps in front of a capture: `warmup` - 1 of them, then as many more as the tile-row tuning of the grouped weight-gradient
+        launches still wants (ops.wgrad_tune_open: each setting is timed ops._TUNE_SAMPLES times, the first, cold sample not counted), then
+        the geometry is FIXED (ops.wgrad_tune_settle) and one last step issues exactly the launches -- and table uploads, counted in
+        ops._upload_stats -- the capture will issue."""
+        for _ in range(max(warmup, 1) - 1):
+            step()
+        extra = 0
+        while ops.wgrad_tune_open() and extra < 2 * ops._TUNE_SAMPLES:
+            step()
+            extra += 1
+        ops.wgrad_tune_settle()
+        ops._upload_stats.update(count=0, max_bytes=0)
+        step()
+
     def capture(self, past, future, warmup=3):
         """Capture the whole step (forward, losses, backward, clip, AdamW) into one hipGraph.  `past`/`future` give the
         static shapes; real data is copied into the captured input buffers by `step`.
@@ -459,15 +475,12 @@ class NARTrainer:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for i in range(max(warmup, 1)):
-                if i == max(warmup, 1) - 1:
-                    ops._upload_stats.update(count=0, max_bytes=0)
-                self._step_impl(self._static_past, self._static_future)
+            self._warm_up_for_capture(warmup, lambda: self._step_impl(self._static_past, self._static_future))
         torch.cuda.current_stream().wait_stream(s)
         # the captured step uploads as many host-built tables as the last warm-up step did (grouped launches: 2 per group, more with
         # the GAN branch or non-P16 groups); each gets a pinned buffer of its own that lives as long as the graph
         ops.reserve_graph_staging(count=ops._upload_stats["count"] + 4, nbytes=max(1 << 16, 2 * ops._upload_stats["max_bytes"]))
-        ops.wgrad_tune_settle()   # the tile geometry of the grouped weight-gradient launch is chosen from the warm-up steps' timings
+        ops.wgrad_tune_settle()
         g = torch.cuda.CUDAGraph(keep_graph=True)
         with torch.cuda.graph(g):
             self._static_out = self._step_impl(self._static_past, self._static_future)
@@ -495,10 +508,7 @@ class NARTrainer:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for i in range(max(warmup, 1)):
-                if i == max(warmup, 1) - 1:
-                    ops._upload_stats.update(count=0, max_bytes=0)
-                self._step_impl(self._static_past, self._static_future)
+            self._warm_up_for_capture(warmup, lambda: self._step_impl(self._static_past, self._static_future))
         torch.cuda.current_stream().wait_stream(s)
         ops.reserve_graph_staging(count=ops._upload_stats["count"] + 4, nbytes=max(1 << 16, 2 * ops._upload_stats["max_bytes"]))
         ops.wgrad_tune_settle()
