@@ -27,7 +27,7 @@ extern "C" {
 
 typedef void* vptr_stream_t; /* hipStream_t */
 
-int vptr_abi_version(void); /* 9 */
+int vptr_abi_version(void); /* 10 */
 const char* vptr_last_error(void);
 
 /* Run-to-run reproducibility (ABI 8).  The reference (cuDNN / cuBLAS defaults, train_NAR.py) is not bit-deterministic and neither is the
@@ -163,9 +163,31 @@ typedef struct vptr_gemm_desc {
      output is its residual).  The input gradients of the encoder memory arrive from the encoder-decoder attention of every decoder
      block (VidHRFormer_modules.py:199-206): with this flag they are summed by the GEMMs instead of one autograd `add` per block. */
   int batch_accum;
+  /* ABI 10.  a_mode = VPTR_A_P16, plain launches (alpha / shared bias, fp32 or P16 output): batch = b (ANY b >= 1) members at constant
+     strides -- member i reads A + i * batch_stride_a, B + i * batch_stride_b and writes D + i * batch_stride_d (strides in fp32
+     elements, i.e. 4-byte units of the P16 image; multiples of 16).  Set batch_stride_d != 0 to select this form; A_x*, B_x*, D_x*,
+     bias_x*, alpha_x* are then ignored, every member shares bias / alpha.  First user: the 36 Winograd-domain products of a frozen
+     3 x 3 convolution (vptr_wino_in / vptr_wino_out below). */
+  int64_t batch_stride_a, batch_stride_b, batch_stride_d;
 } vptr_gemm_desc;
 
 int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ABI 10.  Winograd F(4x4, 3x3) for FROZEN stride-1 3x3 convolutions (the 18 ResnetBlock convolutions of VPTREnc under
+ * train_NAR.py:54-56 / ResNetAutoEncoder.py:127-151: 92 % of the encoder's FLOPs; weights never change in stage 2 / inference).
+ *   y = A^T [ U . (B^T d B) ] A per 4 x 4 output tile, U = G g G^T made once per weight version by the host (P16, [36][Cout][Cin]):
+ *   vptr_wino_in   x  [frames, H, W, C] fp32 NHWC  ->  V [36][Mpad][C] P16, row = (frame, tile_y, tile_x), the convolution's padding
+ *                  (pad_mode 0 zero / 1 reflect / 2 replicate, one pixel) folded into the 6 x 6 patch of every tile
+ *   vptr_gemm      a_mode = VPTR_A_P16, b_mode = VPTR_B_P16, batch = 36, batch_stride_a = batch_stride_d = Mpad * C, batch_stride_b = C * C
+ *   vptr_wino_out  M36 [36][Mpad][C] fp32 -> y [frames, H, W, C]: v = (A^T m A) * scale[c] + shift[c]; relu; + residual; act_after
+ *                  (the folded eval-mode BatchNorm, ReLU and skip connection of ResnetBlock, ResNetAutoEncoder.py:153-157); y may be the
+ *                  residual buffer itself.
+ * H, W multiples of 4; C a multiple of 16; Mpad >= frames * (H/4) * (W/4) (rows beyond that are never touched: keep V zeroed).
+ * 4x fewer MFMA passes than the implicit GEMM; fp32 transforms, relative error 6e-5 after nine blocks (tools/winograd_numerics.py). */
+int vptr_wino_in(const float* x, void* V, int frames, int H, int W, int C, int64_t Mpad, int pad_mode, vptr_stream_t stream);
+int vptr_wino_out(const float* M36, const float* scale, const float* shift, const float* residual, float* y, int frames, int H, int W, int C,
+                  int64_t Mpad, int relu, int act_after, vptr_stream_t stream);
 
 /* "Convert once" operand format of the a_mode = VPTR_A_CONV_PLANES path (first user: the frozen VPTREnc of the NAR / FAR
  * steps, ResNetAutoEncoder.py:127-151 under train_NAR.py:54-56): x [rows, C] fp32 -> planes [(rows + 1), ceil(C/32), 64] bf16,

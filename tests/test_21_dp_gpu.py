@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, G=4, full=True):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -46,7 +46,7 @@ def _worker(rank, world, port, q):
         dev = torch.device("cuda:0")
         z = load("step_far_tiny")
         cfg, meta = jload(z, "cfg"), jload(z, "meta")
-        G = 4                                    # global batch, 2 per rank
+        # G = global batch (4: 2 per rank at world 2; 8: 1 per rank at world 8)
 
         def make(seed_shift):
             enc = pkg.VPTREnc(1, meta["feat"], 3, "reflect")
@@ -83,9 +83,15 @@ def _worker(rank, world, port, q):
             return grads, tr.opt.flat.detach().clone(), float(out["grad_norm"])
 
         g_ov, p_ov, n_ov = run(True, True)
-        g_pl, p_pl, n_pl = run(True, False)
         g_1, p_1, n_1 = run(False, False)
-        g_fr, p_fr, n_fr = run(True, True, front=True)
+        if full:
+            g_pl, p_pl, n_pl = run(True, False)
+            g_fr, p_fr, n_fr = run(True, True, front=True)
+        else:   # the 8-rank test: chunked overlapped exchange and the front-graph step against ONE replica on the global batch
+            g_fr, p_fr, n_fr = run(True, True, front=True)
+            g_pl, p_pl, n_pl = g_ov, p_ov, n_ov
+        offs = [shard_batch(G, r, world) for r in range(world)]
+        assert offs[0][0] == 0 and all(offs[i][0] + offs[i][1] == offs[i + 1][0] for i in range(world - 1)) and offs[-1][0] + offs[-1][1] == G
 
         def rel(a, b):
             return float((a.double() - b.double()).norm() / b.double().norm())
@@ -129,3 +135,29 @@ def test_dp_two_ranks_on_one_gpu():
         assert r["grad_front_vs_plain"] < 1e-5 and r["param_front_vs_plain"] < 1e-5, r     # front-graph step == eager step
         assert abs(r["norms"][0] - r["norms"][2]) < 1e-3 * r["norms"][2], r
     assert res[0]["param_digest"] == res[1]["param_digest"], "replicas diverged"
+
+
+def test_dp_eight_ranks_on_one_gpu():
+    """world 8 (the node the scaling bench runs on), one clip per rank, all ranks on cuda:0 over gloo: rank logic, shard_batch, the
+    DP_CHUNKS boundaries, the rank-0 broadcast and the front-graph step at the real world size -- chunked overlapped exchange == one
+    replica on the 8-clip batch"""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, 8, False)) for r in range(world)]
+    for p in procs:
+        p.start()
+    from helpers import collect, margin
+    res = sorted(collect(q, procs, world, 1200), key=lambda r: r["rank"])
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert [r["rank"] for r in res] == list(range(world))
+    for r in res:
+        for k, b in (("grad_dp_vs_single", 2e-4), ("param_dp_vs_single", 1e-5), ("grad_front_vs_plain", 1e-5), ("param_front_vs_plain", 1e-5)):
+            margin("dp8:%s:rank%d" % (k, r["rank"]), r[k], b)
+        assert r["grad_dp_vs_single"] < 2e-4, r          # fp32 atomics + an 8-way reduction order over the batch
+        assert r["param_dp_vs_single"] < 1e-5, r
+        assert r["grad_front_vs_plain"] < 1e-5 and r["param_front_vs_plain"] < 1e-5, r
+        assert abs(r["norms"][0] - r["norms"][2]) < 1e-3 * r["norms"][2], r
+    assert len({r["param_digest"] for r in res}) == 1, "replicas diverged"

@@ -136,7 +136,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.lib.vptr_abi_version() == 9
+    assert _lib.lib.vptr_abi_version() == 10
     assert ctypes.sizeof(_lib.GemmDesc) % 8 == 0
 
 

@@ -43,6 +43,7 @@ class GemmDesc(ctypes.Structure):
         ("d_transposed", c_int),
         ("d_row_w", c_int), ("d_row_off", c_int),
         ("batch_accum", c_int),
+        ("batch_stride_a", c_int64), ("batch_stride_b", c_int64), ("batch_stride_d", c_int64),
     ]
 
 
@@ -62,6 +63,8 @@ SIGNATURES = {
     "vptr_gemm": [ctypes.POINTER(GemmDesc), P],
     "vptr_gemm_tile_cols": [I],
     "vptr_split_planes": [P, P, L, I, P],
+    "vptr_wino_in": [P, P, I, I, I, I, L, I, P],
+    "vptr_wino_out": [P, P, P, P, P, I, I, I, I, L, I, I, P],
     "vptr_to_p16": [P, P, L, I, P],
     "vptr_weight_planes": [P, P, I, I, P],
     "vptr_gemm_grouped": [ctypes.POINTER(GemmDesc), P, P, I, I, P],
@@ -140,7 +143,7 @@ def _load():
         fn.restype = c_int
     lib.vptr_abi_version.restype = c_int
     lib.vptr_last_error.restype = ctypes.c_char_p
-    if lib.vptr_abi_version() != 9:
+    if lib.vptr_abi_version() != 10:
         raise ImportError("vptr_amd: ABI version mismatch in %s" % LIB_PATH)
     return lib
 

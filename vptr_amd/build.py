@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libvptr_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_p16.hip", "norm.hip", "attn.hip", "attn_mfma.hip", "attn16.hip", "elementwise.hip", "conv7.hip", "losses.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_p16.hip", "norm.hip", "attn.hip", "attn_mfma.hip", "attn16.hip", "elementwise.hip", "conv7.hip", "losses.hip", "winograd.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=fast", "-fno-slp-vectorize",
          "-Wno-unused-result"]
 

@@ -13,7 +13,7 @@ void vptr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* vptr_last_error(void) { return g_err; }
-extern "C" int vptr_abi_version(void) { return 9; }
+extern "C" int vptr_abi_version(void) { return 10; }
 
 int g_vptr_deterministic = 0;
 // process-wide switch (host-side launch decisions only; set it before the launches it should affect are enqueued): returns the previous value

@@ -858,7 +858,7 @@ extern "C" int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream) {
   VPTR_CHECK(d.A && d.B && (d.D || d.D_planes), "vptr_gemm: null operand");
   if (d.D_planes) VPTR_CHECK(d.a_mode == VPTR_A_CONV_PLANES, "vptr_gemm: D_planes is an output of the conv plane kernel only");
   VPTR_CHECK(d.precision == 1 || d.precision == 3, "vptr_gemm: precision must be 1 or 3 (got %d)", d.precision);
-  if (d.a_mode != VPTR_A_P16) VPTR_CHECK(d.batch_accum == 0, "vptr_gemm: batch_accum is an option of the P16 kernels only");
+  if (d.a_mode != VPTR_A_P16) VPTR_CHECK(d.batch_accum == 0 && d.batch_stride_d == 0, "vptr_gemm: batch_accum / strided batches are options of the P16 kernels only");
   if (d.a_mode == VPTR_A_P16 || d.b_mode == VPTR_B_P16) {
     VPTR_CHECK(d.d_row_w == 0, "vptr_gemm(p16): no output row map");
     const int rc = vptr_gemm_p16_launch(d, reinterpret_cast<hipStream_t>(stream));

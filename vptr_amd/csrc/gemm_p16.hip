@@ -1019,9 +1019,15 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
   if (d.alpha == 0.f) d.alpha = 1.f;
   if (d.batch < 1) d.batch = 1;
   if (d.ksegs < 1) d.ksegs = 1;
-  VPTR_CHECK(d.batch <= 3 && d.ksegs <= 3 && (d.batch == 1 || d.ksegs == 1), "vptr_gemm(p16): at most 3 batch members or 3 K segments");
+  const bool strided = d.batch_stride_d != 0;
+  if (strided)   // ABI 10: any number of members at constant strides, plain epilogue (shared bias / alpha)
+    VPTR_CHECK(d.ksegs == 1 && d.batch <= 4096 && !d.Dpre && !d.residual && !d.atomic && !d.batch_accum && !d.frame_stats && !d.act_grad_src && !d.rowscale &&
+                   !d.colscale && d.dropout_p == 0.f && d.act == VPTR_ACT_NONE && !d.act_after &&
+                   ((d.batch_stride_a | d.batch_stride_b | d.batch_stride_d) & 15) == 0 && d.batch_stride_a >= 0 && d.batch_stride_b >= 0 && d.batch_stride_d > 0,
+               "vptr_gemm(p16): a strided batch takes bias / alpha only and strides that are non-negative multiples of 16");
+  VPTR_CHECK((strided || d.batch <= 3) && d.ksegs <= 3 && (d.batch == 1 || d.ksegs == 1), "vptr_gemm(p16): at most 3 batch members or 3 K segments");
   uintptr_t bits = reinterpret_cast<uintptr_t>(d.A) | reinterpret_cast<uintptr_t>(d.B);
-  const int extra = (d.batch > 1 ? d.batch : d.ksegs) - 1;
+  const int extra = strided ? 0 : (d.batch > 1 ? d.batch : d.ksegs) - 1;
   if (extra >= 1) {
     VPTR_CHECK(d.A_x1 && d.B_x1, "vptr_gemm(p16): member / segment 1 needs A_x1, B_x1");
     bits |= reinterpret_cast<uintptr_t>(d.A_x1) | reinterpret_cast<uintptr_t>(d.B_x1);
@@ -1031,7 +1037,7 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
     bits |= reinterpret_cast<uintptr_t>(d.A_x2) | reinterpret_cast<uintptr_t>(d.B_x2);
   }
   VPTR_CHECK((bits & 63) == 0, "vptr_gemm(p16): operands must be 64-byte aligned (whole granules)");
-  if (d.batch > 1) {
+  if (d.batch > 1 && !strided) {
     VPTR_CHECK(d.D_x1 && (d.batch < 3 || d.D_x2) && !d.Dpre && !d.residual && !d.atomic, "vptr_gemm(p16): bad batch members");
     if (d.alpha_x1 == 0.f) d.alpha_x1 = 1.f;
     if (d.alpha_x2 == 0.f) d.alpha_x2 = 1.f;
@@ -1068,7 +1074,7 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
   const int tiles = ((d.M + GBM - 1) / GBM) * ((d.N + 175) / 176) * d.batch;
   // the plain launches (bias / alpha / residual, fp32 or P16 output, vector-aligned) take the lean instantiation
   uintptr_t ebits = reinterpret_cast<uintptr_t>(d.D) | reinterpret_cast<uintptr_t>(d.residual) | reinterpret_cast<uintptr_t>(d.bias);
-  if (d.batch > 1) ebits |= reinterpret_cast<uintptr_t>(d.D_x1) | reinterpret_cast<uintptr_t>(d.D_x2) | reinterpret_cast<uintptr_t>(d.bias_x1) | reinterpret_cast<uintptr_t>(d.bias_x2);
+  if (d.batch > 1 && !strided) ebits |= reinterpret_cast<uintptr_t>(d.D_x1) | reinterpret_cast<uintptr_t>(d.D_x2) | reinterpret_cast<uintptr_t>(d.bias_x1) | reinterpret_cast<uintptr_t>(d.bias_x2);
   #ifdef VPTR_P16_TIMING
   const bool dpre_ok = true;
 #else
@@ -1121,6 +1127,10 @@ int vptr_gemm_p16_launch(vptr_gemm_desc& d, hipStream_t st) {
       const double e128 = tiles / (double)(((tiles + 2 * cus - 1) / (2 * cus)) * 2 * cus);
       use256 = rows_mode == 2 || e256 > 1.03 * e128;
     }
+    // strided batches (the 36 Winograd-domain products of a frozen 3 x 3 convolution): VPTR_WINO_ROWS=256 puts them on the 256-row tiles
+    static int wino_rows = -1;
+    if (wino_rows < 0) { const char* e = getenv("VPTR_WINO_ROWS"); wino_rows = (e && atoi(e) == 256 && rows_mode >= 0) ? 256 : 128; }
+    if (strided && wino_rows == 256 && lean && d.M >= 256) use256 = true;
   }
   if (d.act_grad_src) {   // activation-gradient epilogue: its own instantiation, no fallback
     VPTR_CHECK(!d.colscale && !d.Dpre && !d.rowscale && !d.residual && !d.bias && !d.act_after && !d.atomic && d.batch == 1 && d.ksegs == 1 &&

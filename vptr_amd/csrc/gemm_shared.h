@@ -48,6 +48,12 @@ struct Member {
 };
 __device__ __forceinline__ Member member_of(const vptr_gemm_desc& p, const int member) {
   Member m = {p.A, p.B, p.D, p.bias, p.alpha, p.residual, p.ldr};
+  if (p.batch_stride_d != 0) {   // strided members (ABI 10): shared bias / alpha, no residual
+    m.A = p.A + (int64_t)member * p.batch_stride_a;
+    m.B = p.B + (int64_t)member * p.batch_stride_b;
+    m.D = p.D + (int64_t)member * p.batch_stride_d;
+    return m;
+  }
   if (member > 0) {  // workgroup-uniform
     const bool one = member == 1;
     m.A = one ? p.A_x1 : p.A_x2;
@@ -169,7 +175,7 @@ constexpr int epi_lds_bytes() { return GBM * (16 * NFN + 4) * (int)sizeof(float)
 __device__ __forceinline__ bool epi_vec_ok(const vptr_gemm_desc& p) {
   uintptr_t bits = reinterpret_cast<uintptr_t>(p.D) | reinterpret_cast<uintptr_t>(p.Dpre) | reinterpret_cast<uintptr_t>(p.residual) |
                    reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.colscale);
-  if (p.batch > 1) bits |= reinterpret_cast<uintptr_t>(p.D_x1) | reinterpret_cast<uintptr_t>(p.D_x2) | reinterpret_cast<uintptr_t>(p.bias_x1) |
+  if (p.batch > 1 && p.batch_stride_d == 0) bits |= reinterpret_cast<uintptr_t>(p.D_x1) | reinterpret_cast<uintptr_t>(p.D_x2) | reinterpret_cast<uintptr_t>(p.bias_x1) |
                            reinterpret_cast<uintptr_t>(p.bias_x2);
   return ((bits & 15) == 0) && ((p.N & 3) == 0) && ((p.ldd & 3) == 0) && ((p.ldr & 3) == 0);
 }

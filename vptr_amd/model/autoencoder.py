@@ -217,11 +217,22 @@ class ResnetEncoder(nn.Module):
         # frozen encoder (stage 2): activations and weights of the 18 ResnetBlock convolutions as bf16 hi / lo planes, staged
         # by global_load_lds ("convert once"); anywhere else the register-staged fp32 path
         planes = ops.config.weights_frozen and cin % 4 == 0 and os.environ.get("VPTR_ENC_PLANES", "1") != "0"
+        # frozen encoder, maps of whole 4 x 4 tiles: the 18 ResnetBlock convolutions as Winograd F(4x4, 3x3) -- 36 multiplies per tile instead
+        # of 144 (ops.wino_conv3x3: input transform, one 36-member strided-batch P16 GEMM, output transform with BN / ReLU / skip fused)
+        wino = planes and ops.wino_ok(h, w, cin, cin) and all(c.bias is None for c in m[idx]._layers()[0])
+        wbufs = ops.wino_buffers(B, h, w, cin, x.device, self) if wino else None
         for bi in range(9):
             blk = m[idx + bi]
             convs, bns = blk._layers()
             s1, b1 = _bn_eval(bns[0])
             s2, b2 = _bn_eval(bns[1])
+            if wino:
+                if bi == 0:
+                    tbuf = torch.empty_like(y)
+                t = ops.wino_conv3x3(y, ops.wino_filter(convs[0].weight), B, h, w, wbufs, pad_mode, colscale=s1, bias=b1, relu=True, out=tbuf)
+                y = ops.wino_conv3x3(t, ops.wino_filter(convs[1].weight), B, h, w, wbufs, pad_mode, colscale=s2, bias=b2, residual=y,
+                                     act_after=(bi == 8), out=y)
+                continue
             if planes:
                 # two persistent, zero-initialised plane buffers: the convs write their result in plane form themselves
                 # (pad channels and the all-zero row are never touched), only the very first input needs a split pass

@@ -168,6 +168,72 @@ def conv_nhwc_planes(x_planes, Bplanes, frames, IH, IW, Cin, OH, OW, KH, KW, str
     return y
 
 
+# ---- Winograd F(4x4, 3x3) for frozen stride-1 3x3 convolutions (csrc/winograd.hip; ResNetAutoEncoder.py:127-151 under train_NAR.py:54-56) ------
+_WINO_G = ((0.25, 0.0, 0.0), (-1.0 / 6, -1.0 / 6, -1.0 / 6), (-1.0 / 6, 1.0 / 6, -1.0 / 6), (1.0 / 24, 1.0 / 12, 1.0 / 6),
+           (1.0 / 24, -1.0 / 12, 1.0 / 6), (0.0, 0.0, 1.0))
+
+
+def wino_ok(H, W, Cin, Cout):
+    """can a frozen stride-1, pad-1 3x3 convolution on H x W maps run as Winograd F(4x4, 3x3)?  (whole 4 x 4 output tiles, P16 operands)"""
+    return (config.winograd and config.weights_frozen and config.use_p16 and config.gemm_precision == 3 and H % 4 == 0 and W % 4 == 0
+            and H >= 4 and W >= 4 and Cin % 16 == 0 and Cout % 16 == 0)
+
+
+def wino_filter(weight):
+    """Conv2d weight [Cout, Cin, 3, 3] -> U [36, Cout, Cin] in the P16 operand format, U[xi nu] = (G g G^T)[xi][nu] (fp64 transform, rounded
+    once).  Only inside a frozen_weights scope: the transformed filter is cached on the parameter, keyed by version and address."""
+    if not config.weights_frozen:
+        raise RuntimeError("wino_filter: transformed filters are only kept for frozen modules")
+    key = (weight._version, weight.data_ptr())
+    hit = getattr(weight, "_vptr_wino", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.no_grad():
+        Cout, Cin, KH, KW = weight.shape
+        if (KH, KW) != (3, 3):
+            raise RuntimeError("wino_filter: 3x3 kernels only")
+        G = torch.tensor(_WINO_G, dtype=torch.float64, device=weight.device)
+        U = torch.einsum("ia,kcab,jb->ijkc", G, weight.double(), G).reshape(36 * Cout, Cin).float().contiguous()
+        Up = torch.empty_like(U)
+        check(lib.vptr_to_p16(ptr(U), ptr(Up), U.shape[0], Cin, stream()), "vptr_to_p16")
+        Up = Up.view(36, Cout, Cin)
+    setattr(weight, "_vptr_wino", (key, Up))
+    return Up
+
+
+def wino_buffers(frames, H, W, C, device, holder):
+    """(V, M36, Mpad): the persistent Winograd-domain operand (P16, zero-initialised: rows beyond the tile count are never written) and
+    product buffers of one module, keyed on shape -- one forward at a time per module, like the plane buffers"""
+    rows = frames * (H // 4) * (W // 4)
+    Mpad = (rows + 127) // 128 * 128
+    key = ("wino", Mpad, C, device)
+    hit = getattr(holder, "_wino_bufs", None)
+    if hit is None or hit[0] != key:
+        hit = (key, torch.zeros((36, Mpad, C), device=device, dtype=torch.float32), torch.empty((36, Mpad, C), device=device, dtype=torch.float32))
+        holder._wino_bufs = hit
+    return hit[1], hit[2], Mpad
+
+
+def wino_conv3x3(x, U, frames, H, W, bufs, pad_mode="zero", colscale=None, bias=None, relu=False, residual=None, act_after=False, out=None):
+    """y = [relu](conv3x3(x) * colscale + bias) [+ residual] [relu] on NHWC tokens x [frames * H * W, C] (stride 1, one pixel of `pad_mode`
+    padding) as Winograd F(4x4, 3x3): input transform -> ONE strided-batch P16 GEMM of 36 members -> output transform with the epilogue.
+    U from wino_filter, bufs from wino_buffers.  out may be `residual` itself."""
+    V, M36, Mpad = bufs
+    C = x.shape[1]
+    Cout = U.shape[1]
+    if Cout != C:
+        raise RuntimeError("wino_conv3x3: square convolutions only (Cin %d, Cout %d)" % (C, Cout))
+    rows = frames * (H // 4) * (W // 4)
+    x = _c(x)
+    check(lib.vptr_wino_in(ptr(x), ptr(V), frames, H, W, C, Mpad, PAD_MODES[pad_mode], stream()), "vptr_wino_in")
+    gemm_raw(V, U, M36, rows, Cout, C, 5, 3, lda=C, ldb=C, ldd=Cout, precision=3, batch_strided=(36, Mpad * C, Cout * C, Mpad * Cout))
+    if out is None:
+        out = torch.empty((frames * H * W, Cout), device=x.device, dtype=torch.float32)
+    check(lib.vptr_wino_out(ptr(M36), ptr(colscale), ptr(bias), ptr(residual), ptr(out), frames, H, W, Cout, Mpad, int(bool(relu)),
+                            int(bool(act_after)), stream()), "vptr_wino_out")
+    return out
+
+
 # ---- trainable convolutions (stage-1 auto-encoder / PatchGAN training, train_AutoEncoder.py:44-86) -------------------------
 class _Conv2dNHWCFn(torch.autograd.Function):
     """nn.Conv2d / nn.ConvTranspose2d on NHWC token grids with full autograd, every piece an MFMA GEMM:

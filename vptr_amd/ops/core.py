@@ -48,6 +48,7 @@ class _Config:
     fused_mlp = os.environ.get("VPTR_FUSED_MLP", "1") != "0"
     # LayerNorm((F,H,W)) statistics accumulated by the epilogue of the producing GEMM / depthwise convolution; 0 = separate pass (A/B)
     fused_frame_stats = os.environ.get("VPTR_FUSED_STATS", "1") != "0"
+    winograd = os.environ.get("VPTR_ENC_WINOGRAD", "1") != "0"   # frozen 3x3 stride-1 convolutions of VPTREnc as Winograd F(4x4, 3x3) (round 6)
     fused_norm_dwconv = os.environ.get("VPTR_FUSED_NORM_DW", "1") != "0"   # conv-FFN norm1 + act1 inside the depthwise kernel's load path (round 6)
     loose_grad_arena = os.environ.get("VPTR_GRAD_ARENA", "1") != "0"   # models without a trainer: `.grad` tensors are views of one buffer per model
     deterministic = False   # ops.set_deterministic / VPTR_DETERMINISTIC=1
@@ -157,7 +158,8 @@ def _c(t):
 def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None, colscale=None, alpha=1.0, act=ACT_NONE,
              Dpre=None, rowscale=None, rs_div=1, rs_mod=1, dropout_p=0.0, site=0, residual=None, act_after=False,
              atomic=False, split_k=1, conv=None, precision=None, seed=None, a_rowsum=None, batch_extra=None, kseg_extra=None,
-             planes_out=None, d_p16=False, act_grad_src=None, frame_stats=None, frame_rows=0, row_map=None, ldd=None, batch_accum=0):
+             planes_out=None, d_p16=False, act_grad_src=None, frame_stats=None, frame_rows=0, row_map=None, ldd=None, batch_accum=0,
+             batch_strided=None):
     """One vptr_gemm launch.  batch_extra = [(A, B, D, bias, alpha), ...] adds up to two same-shaped independent problems to
     the grid; kseg_extra = [(A, B), ...] adds up to two K-segments accumulated into the same D (include/vptr_hip.h)."""
     d = GemmDesc()
@@ -167,6 +169,8 @@ def gemm_raw(A, B, D, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, bias=None
             setattr(d, "A_x%d" % i, A2.data_ptr()), setattr(d, "B_x%d" % i, B2.data_ptr()), setattr(d, "D_x%d" % i, D2.data_ptr())
             setattr(d, "bias_x%d" % i, bias2.data_ptr() if bias2 is not None else None)
             setattr(d, "alpha_x%d" % i, alpha2)
+    if batch_strided:   # (members, stride_a, stride_b, stride_d) in fp32 elements: ABI 10 strided members of a P16 launch
+        d.batch, d.batch_stride_a, d.batch_stride_b, d.batch_stride_d = (int(v) for v in batch_strided)
     if kseg_extra:
         d.ksegs = 1 + len(kseg_extra)
         for i, (A2, B2) in enumerate(kseg_extra, 1):

@@ -353,14 +353,28 @@ class NARTrainer:
         grad = self.opt.grad
         base, n = grad.data_ptr(), grad.numel()
         works, sent = [], [0]
+        # bench.py's tuning table (comm_stats["timeline"] = True): HIP events on the launch stream at the start of the exchange, behind every
+        # weight-gradient chunk (= the moment its all-reduces may start: c10d orders them behind this point of the stream) and behind every
+        # Work.wait() (= the moment that all-reduce had finished, or the stream reached the wait -- whichever is later)
+        tl = None
+        if self.comm_stats is not None and self.comm_stats.get("timeline"):
+            tl = {"t0": torch.cuda.Event(enable_timing=True), "chunk_end": [], "sent_bytes": [], "ar_done": [], "ar_bytes": []}
+            tl["t0"].record()
 
         def send_upto(next_ptr):
             hi = n if next_ptr is None else max(sent[0], min(n, (next_ptr - base) // 4))
             off = sent[0]
+            if tl is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                tl["chunk_end"].append(e)
+                tl["sent_bytes"].append((hi - off) * 4)
             while off < hi:  # sub-ranges of at most bucket_elems, like the non-overlapped path
                 end = min(hi, off + self.bucket_elems)
                 works.append(torch.distributed.all_reduce(grad[off:end], op=torch.distributed.ReduceOp.SUM, group=self.pg,
                                                           async_op=True))
+                if tl is not None:
+                    tl["ar_bytes"].append((end - off) * 4)
                 off = end
             sent[0] = hi
 
@@ -370,6 +384,12 @@ class NARTrainer:
         tok = self._comm_begin()
         for w in works:
             w.wait()
+            if tl is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                tl["ar_done"].append(e)
+        if tl is not None:
+            self.comm_stats["last_timeline"] = tl     # of the most recent step; bench.py resolves the events after its final synchronize
         self._comm_end(tok, n * 4, len(works))
         self._grad_scale = 1.0 / self.world   # the mean over ranks is folded into the optimizer kernel (FlatAdamW.step(grad_scale)): no extra pass over the slab
 
