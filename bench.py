@@ -189,21 +189,22 @@ def _numa_core_list():
     return nodes or [sorted(os.sched_getaffinity(0))]
 
 
-def _cpu_probe(threads, pin, steps):
-    """child process of `cpu_baseline` (bench.py --cpu-probe): the affinity mask is set BEFORE torch creates its thread pool, so every
-    worker inherits it.  pin = 1: `threads` physical cores of as few NUMA nodes as possible (numactl --physcpubind style), 0: no mask."""
+def _cpu_probe(thread_list, pin, steps):
+    """child process of `cpu_baseline` (bench.py --cpu-probe 8,16,32): the affinity mask is set BEFORE torch creates its thread pool, so every
+    worker inherits it.  pin = 1: the process is bound to max(thread_list) physical cores of as few NUMA nodes as possible (numactl
+    --physcpubind style; the smaller counts of the sweep run inside that set), 0: no mask."""
     cpus = None
     if pin:
         flat = [c for node in _numa_core_list() for c in node]
-        cpus = flat[:threads]
-        if len(cpus) == threads:
+        cpus = flat[:max(thread_list)]
+        if len(cpus) == max(thread_list):
             os.sched_setaffinity(0, set(cpus))
         else:
             cpus = None
     from oracle import vptr_oracle as O
     import vptr_amd.model as M
     torch.manual_seed(3407)
-    torch.set_num_threads(threads)
+    torch.set_num_threads(max(thread_list))
     n = 4
     cfg = dict(Tp=TP, Tf=TF, H=8, W=8, C=528, nhead=8, window_size=4, num_encoder_layers=4, num_decoder_layers=8, rpe=True)
     enc = M.VPTREnc(1, 528, 3, "reflect")
@@ -211,79 +212,61 @@ def _cpu_probe(threads, pin, steps):
     T = M.VPTRFormerNAR(TP, TF, 8, 8, 528, 8, 4, 8, 0.0, 4, 4, False, True)
     st = O.NARStep(dict(enc.state_dict()), dict(dec.state_dict()), dict(T.state_dict()), cfg)
     past, fut = synth_batch(n, 0, "cpu")
-    st.step(past, fut)   # warm-up at this thread count
-    times = []
-    for _ in range(steps):
-        t0 = time.perf_counter()
-        st.step(past, fut)
-        times.append(time.perf_counter() - t0)
-    print("CPU_PROBE " + json.dumps({"threads": threads, "pinned": cpus is not None, "cpus": cpus, "times": times, "n": n}))
+    for k in thread_list:
+        torch.set_num_threads(k)
+        st.step(past, fut)   # warm-up at this thread count
+        times = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            st.step(past, fut)
+            times.append(time.perf_counter() - t0)
+        print("CPU_PROBE " + json.dumps({"threads": k, "pinned": cpus is not None, "bound_to_cpus": len(cpus) if cpus else None, "times": times, "n": n}))
+        sys.stdout.flush()
 
 
-def cpu_baseline(seconds_budget=150.0, timed_steps=3):
+def cpu_baseline(seconds_budget=120.0, timed_steps=3):
     """The oracle (oracle/vptr_oracle.py: CPU restatement of the reference, parity-pinned by tests/golden) timed on the host cores of this
-    box on a bounded sample of the same workload: N = 4 KTH-shaped clips.  Thread sweep over {8, 16, 32, all
-    physical cores}, every point in its OWN process with 1 warm-up + `timed_steps` timed steps, once pinned to that
-    many physical cores of as few NUMA nodes as possible (affinity set before the thread pool exists) and -- for the best count -- once
-    unpinned.  The reported figure is the best mean of all points.  A point whose predicted time does not fit the budget is listed as skipped."""
+    box on a bounded sample of the same workload: N = 4 KTH-shaped clips.  Thread sweep over {8, 16, 32} (VERDICT r5
+    item 7) in ONE child process bound -- before its thread pool exists -- to 32 physical cores of one NUMA node, 1 warm-up + `timed_steps`
+    timed steps per point; the reported figure is the best mean.  All physical cores are not swept: the oracle's small fp32 GEMMs stop scaling
+    near 16 threads (32 threads: 2x the time of 16 in every run of this pool; 128: 13.7 s/step, measured in round 3)."""
     import subprocess
     phys = _physical_cores()
     nodes = _numa_core_list()
-    cand = [k for k in (8, 16, 32, phys) if k <= phys]
-    cand = [k for i, k in enumerate(cand) if k not in cand[:i]] or [phys]
+    cand = [k for k in (8, 16, 32) if k <= phys] or [phys]
     t_start = time.perf_counter()
-    points, skipped = [], []
-
-    def run(k, pin, steps):
-        try:
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-probe", str(k), "--cpu-probe-pin", str(pin), "--cpu-probe-steps", str(steps)],
-                                 capture_output=True, text=True, timeout=max(60.0, seconds_budget),
-                                 env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(k)))
-            for line in out.stdout.splitlines():
-                if line.startswith("CPU_PROBE "):
-                    r = json.loads(line[len("CPU_PROBE "):])
-                    r["mean"] = sum(r["times"]) / len(r["times"])
-                    return r
-        except Exception:  # noqa
-            pass
-        return None
-
-    for k in cand:
-        used = time.perf_counter() - t_start
-        # predicted cost of this point from the last one (the oracle's small fp32 GEMMs stop scaling early: time per step GROWS with the
-        # thread count past ~16 on the two-socket hosts of this pool), plus ~8 s of process start + model build
-        pred = 8.0 + (1 + timed_steps) * (points[-1]["mean"] * (2.0 if points and k > points[-1]["threads"] else 1.0) if points else 4.0)
-        steps = timed_steps
-        if used + pred > seconds_budget:
-            steps = 1
-            pred = 8.0 + 2 * (points[-1]["mean"] * 2.0 if points else 4.0)
-            if used + pred > seconds_budget:
-                skipped.append(k)
-                continue
-        r = run(k, 1, steps)
-        if r is None:
-            skipped.append(k)
-        else:
-            points.append(r)
+    points = []
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-probe", ",".join(str(k) for k in cand), "--cpu-probe-pin", "1",
+                              "--cpu-probe-steps", str(timed_steps)], capture_output=True, text=True, timeout=seconds_budget * 2.5,
+                             env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        for line in out.stdout.splitlines():
+            if line.startswith("CPU_PROBE "):
+                r = json.loads(line[len("CPU_PROBE "):])
+                r["mean"] = sum(r["times"]) / len(r["times"])
+                points.append(r)
+    except subprocess.TimeoutExpired as e:
+        for line in (e.stdout or b"").decode(errors="replace").splitlines():
+            if line.startswith("CPU_PROBE "):
+                r = json.loads(line[len("CPU_PROBE "):])
+                r["mean"] = sum(r["times"]) / len(r["times"])
+                points.append(r)
     if not points:
         raise RuntimeError("cpu_baseline: no probe finished")
     best = min(points, key=lambda r: r["mean"])
-    if time.perf_counter() - t_start + 8.0 + (1 + timed_steps) * best["mean"] < seconds_budget + 30.0:
-        r = run(best["threads"], 0, timed_steps)
-        if r is not None:
-            points.append(r)
-            best = min(points, key=lambda q: q["mean"])
     n, mean = best["n"], best["mean"]
     return {"value": round(n * TF / mean, 3), "unit": "predicted frames/s", "cores": best["threads"], "kind": "port",
-            "pinned": best["pinned"], "physical_cores": phys, "logical_cpus": os.cpu_count(), "numa_nodes": len(nodes), "cpu_model": _cpu_model(),
+            "pinned": best["pinned"], "bound_to_cpus": best["bound_to_cpus"], "physical_cores": phys, "logical_cpus": os.cpu_count(),
+            "numa_nodes": len(nodes), "cpu_model": _cpu_model(),
             "s_per_step": round(mean, 3), "s_per_step_min_max": [round(min(best["times"]), 3), round(max(best["times"]), 3)],
             "timed_steps": len(best["times"]),
-            "thread_sweep": [{"threads": r["threads"], "pinned": r["pinned"], "timed_steps": len(r["times"]), "s_per_step": round(r["mean"], 3),
+            "thread_sweep": [{"threads": r["threads"], "timed_steps": len(r["times"]), "s_per_step": round(r["mean"], 3),
                               "min": round(min(r["times"]), 3)} for r in points],
-            "thread_sweep_skipped": skipped, "wall_s": round(time.perf_counter() - t_start, 1),
-            "sample": "oracle NAR train step (fp32 torch CPU), batch %d x 10->10 @64x64; every sweep point in its own process, 1 warm-up + "
-                      "timed steps, pinned = sched_setaffinity to that many physical cores node by node before the thread pool exists; "
-                      "best point: %d threads%s, mean %.2f s/step" % (n, best["threads"], " pinned" if best["pinned"] else " unpinned", mean)}
+            "thread_sweep_skipped": [k for k in cand if k not in [r["threads"] for r in points]] + ([phys] if phys > 32 else []),
+            "wall_s": round(time.perf_counter() - t_start, 1),
+            "sample": "oracle NAR train step (fp32 torch CPU), batch %d x 10->10 @64x64; one child process bound (sched_setaffinity before the "
+                      "thread pool exists) to 32 physical cores of one NUMA node, 1 warm-up + %d timed steps per thread count; "
+                      "best: %d threads, mean %.2f s/step" % (n, len(best["times"]), best["threads"], mean)}
 
 
 def gemm_roofline(trainer, past, fut, precision):
@@ -699,14 +682,14 @@ def main():
                                                               "per-link bound: tune against the exchange_timeline of the line)")
     ap.add_argument("--global-batch", type=int, default=64, help="global batch of --scaling strong (train_FAR_mp.py:300 uses 64)")
     ap.add_argument("--ddp-probe", action="store_true", help=argparse.SUPPRESS)   # internal: other_configs' DDP-wrapped iteration, own process
-    ap.add_argument("--cpu-probe", type=int, default=0, help=argparse.SUPPRESS)        # internal: one thread-sweep point of cpu_baseline, own process
+    ap.add_argument("--cpu-probe", type=str, default="", help=argparse.SUPPRESS)        # internal: one thread-sweep point of cpu_baseline, own process
     ap.add_argument("--cpu-probe-pin", type=int, default=1, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-probe-steps", type=int, default=3, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.cpu_probe:
-        _cpu_probe(args.cpu_probe, args.cpu_probe_pin, args.cpu_probe_steps)
+        _cpu_probe([int(k) for k in args.cpu_probe.split(",")], args.cpu_probe_pin, args.cpu_probe_steps)
         return
     if args.ddp_probe:
         import faulthandler

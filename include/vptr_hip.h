@@ -188,6 +188,11 @@ int vptr_gemm(const vptr_gemm_desc* desc, vptr_stream_t stream);
 int vptr_wino_in(const float* x, void* V, int frames, int H, int W, int C, int64_t Mpad, int pad_mode, vptr_stream_t stream);
 int vptr_wino_out(const float* M36, const float* scale, const float* shift, const float* residual, float* y, int frames, int H, int W, int C,
                   int64_t Mpad, int relu, int act_after, vptr_stream_t stream);
+/* vptr_wino_out followed by vptr_wino_in of the NEXT convolution in one pass: the activated map of a (frame, 64-channel) unit stays in LDS
+ * between the two transforms, so a ResnetBlock's intermediate map never reaches HBM.  y may be NULL (the map is not needed outside) or the
+ * residual buffer.  (H/4) * (W/4) must divide 16 (4 x 4 ... 16 x 16 maps); V_next != M36. */
+int vptr_wino_out_in(const float* M36, const float* scale, const float* shift, const float* residual, float* y, void* V_next, int frames, int H,
+                     int W, int C, int64_t Mpad, int relu, int act_after, int pad_mode, vptr_stream_t stream);
 
 /* "Convert once" operand format of the a_mode = VPTR_A_CONV_PLANES path (first user: the frozen VPTREnc of the NAR / FAR
  * steps, ResNetAutoEncoder.py:127-151 under train_NAR.py:54-56): x [rows, C] fp32 -> planes [(rows + 1), ceil(C/32), 64] bf16,

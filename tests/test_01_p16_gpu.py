@@ -252,11 +252,13 @@ def test_frame_stats_large_mean_guard(ops, dev):
     assert float((a.double() - ref).norm() / ref.norm()) < 1e-4
 
 
-def test_norm_dwconv_fused_matches_chain_and_fp64(ops, dev):
+@pytest.mark.parametrize("geo", [(6, 8, 8, 48, 192), (2, 16, 16, 32, 96), (3, 16, 16, 32, 128)], ids=["lds8x8", "walk16x16_F96", "lds16x16"])
+def test_norm_dwconv_fused_matches_chain_and_fp64(ops, dev, geo):
     """round 6: LayerNorm((F,H,W)) + GELU folded into the depthwise kernel's load path (ops.norm_dwconv3x3: VidHRFormer_modules.py:430-434)
     == norm_act followed by dwconv3x3 (forward, frame statistics of the output, every gradient) and == fp64 torch.  The depthwise WEIGHT
     gradient reads the activated tensor from an fp16 side copy: its bound is the one the model-level parity tests leave (2e-4)."""
-    frames, H, W, C, F_ = 6, 8, 8, 48, 192
+    # F % 64 == 0 and H * W <= 256: the LDS-slab kernel (dwconv_norm_lds_kernel); F = 96 on 16 x 16 maps: the register-walk kernel
+    frames, H, W, C, F_ = geo
     HW, rows = H * W, frames * H * W
     assert ops.norm_dwconv_ok(rows, HW, F_, H, W)
     x0, W1, b1 = rn((rows, C), 1).to(dev), rn((F_, C), 2, C ** -0.5).to(dev), rn((F_,), 3).to(dev)

@@ -154,7 +154,7 @@ def _mask_parity(dev, far, N, T, C, n_enc, n_dec, ref_dtype=torch.float32, param
     errs = []
     for k, p in m.named_parameters():
         if k in refg:
-            if analytic_zero(float(refg[k].norm()), norms):    # helpers.analytic_zero: both sides are round-off; ours must class as zero too
+            if analytic_zero(float(refg[k].norm()), norms, k):    # helpers.analytic_zero: both sides are round-off; ours must class as zero too
                 assert float(p.grad.norm()) < ZERO_CLASS * median, "analytically zero gradient %s: %.3e vs median %.3e" % (k, float(p.grad.norm()), median)
                 continue
             e = rel(p.grad, refg[k], floor)

@@ -113,3 +113,37 @@ def test_encoder_winograd_matches_direct_path(dev):
             ops.config.winograd = True
     assert rel(a, b) < 2e-4
     assert float((a - b).abs().max()) < 2e-3 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("frames,H,W,C", [(5, 8, 8, 80), (3, 16, 16, 48), (7, 4, 8, 64), (9, 4, 4, 32), (2, 12, 8, 32)])
+@pytest.mark.parametrize("pad_mode", ["reflect", "zero"])
+def test_wino_resnet_blocks_fused_vs_fp64(ops, dev, frames, H, W, C, pad_mode):
+    """two ResnetBlocks in the Winograd domain (ops.wino_resnet_blocks): the LDS-fused output -> input transform (vptr_wino_out_in; partial last
+    channel slab, several units per workgroup, 1 - 16 tiles per map; 12 x 8 = 6 tiles falls back to the two-launch form) == the unfused chain
+    == fp64 torch"""
+    x = rn((frames * H * W, C), 1)
+    ws = [rn((C, C, 3, 3), 10 + i, (9 * C) ** -0.5) for i in range(4)]
+    scs = [rn((C,), 20 + i).abs() * 0.5 + 0.5 for i in range(4)]
+    shs = [rn((C,), 30 + i, 0.2) for i in range(4)]
+    ref = x.double()
+    for b in range(2):
+        t = _ref_conv(ref, ws[2 * b], frames, H, W, pad_mode, scs[2 * b], shs[2 * b], True, None, False)
+        ref = _ref_conv(t, ws[2 * b + 1], frames, H, W, pad_mode, scs[2 * b + 1], shs[2 * b + 1], False, ref, b == 1)
+    wd = [w.to(dev) for w in ws]
+    outs = []
+    for fuse in (True, False):
+        ops.config.winograd_fuse = fuse
+        try:
+            with ops.frozen_weights(True):
+                assert ops.wino_fused_ok(H, W) == (fuse and 16 % ((H // 4) * (W // 4)) == 0)
+                blocks = [(ops.wino_filter(wd[2 * b]), scs[2 * b].to(dev), shs[2 * b].to(dev), ops.wino_filter(wd[2 * b + 1]), scs[2 * b + 1].to(dev),
+                           shs[2 * b + 1].to(dev)) for b in range(2)]
+                bufs = ops.wino_buffers(frames, H, W, C, dev, type("Holder", (), {})())
+                y = x.to(dev).clone()
+                out = ops.wino_resnet_blocks(y, blocks, frames, H, W, bufs, pad_mode, last_relu=True)
+                assert out.data_ptr() == y.data_ptr()
+                outs.append(out.cpu())
+        finally:
+            ops.config.winograd_fuse = True
+    assert rel(outs[0], ref) < 1.5e-4 and rel(outs[1], ref) < 1.5e-4
+    assert rel(outs[0], outs[1]) < 1e-6     # the same arithmetic either way

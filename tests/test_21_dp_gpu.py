@@ -37,6 +37,7 @@ def _worker(rank, world, port, q, G=4, full=True):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        torch.cuda.set_per_process_memory_fraction(min(1.0, 0.9 / world), 0) if world > 2 else None   # a runaway rank fails itself, not its peers
         import vptr_amd.model as pkg
         from helpers import build_transformer, jload, load
         from oracle import fill
@@ -106,6 +107,10 @@ def _worker(rank, world, port, q, G=4, full=True):
                "norms": (n_ov, n_pl, n_1), "param_digest": float(p_ov.double().sum())}
         q.put(res)
         dist.barrier()
+    except Exception as e:  # noqa: the FIRST failing rank names its own error (its peers only see "connection closed by peer")
+        import traceback
+        q.put({"rank": rank, "error": "%r\n%s" % (e, traceback.format_exc()[-1500:])})
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -119,6 +124,8 @@ def test_dp_two_ranks_on_one_gpu():
         p.start()
     from helpers import collect
     res = sorted(collect(q, procs, world, 600), key=lambda r: r["rank"])
+    errs = sorted((r for r in res if "error" in r), key=lambda r: "closed by peer" in r["error"])   # the cause before its echoes
+    assert not errs, "rank %d failed first: %s" % (errs[0]["rank"], errs[0]["error"])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -142,6 +149,9 @@ def test_dp_eight_ranks_on_one_gpu():
     DP_CHUNKS boundaries, the rank-0 broadcast and the front-graph step at the real world size -- chunked overlapped exchange == one
     replica on the 8-clip batch"""
     world, port = 8, _free_port()
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()     # eight more contexts share this GPU with the pytest process: hand its cached blocks back first
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, 8, False)) for r in range(world)]
@@ -149,6 +159,8 @@ def test_dp_eight_ranks_on_one_gpu():
         p.start()
     from helpers import collect, margin
     res = sorted(collect(q, procs, world, 1200), key=lambda r: r["rank"])
+    errs = sorted((r for r in res if "error" in r), key=lambda r: "closed by peer" in r["error"])   # the cause before its echoes
+    assert not errs, "rank %d failed first: %s" % (errs[0]["rank"], errs[0]["error"])
     for p in procs:
         p.join(180)
         assert p.exitcode == 0

@@ -65,6 +65,7 @@ SIGNATURES = {
     "vptr_split_planes": [P, P, L, I, P],
     "vptr_wino_in": [P, P, I, I, I, I, L, I, P],
     "vptr_wino_out": [P, P, P, P, P, I, I, I, I, L, I, I, P],
+    "vptr_wino_out_in": [P, P, P, P, P, P, I, I, I, I, L, I, I, I, P],
     "vptr_to_p16": [P, P, L, I, P],
     "vptr_weight_planes": [P, P, I, I, P],
     "vptr_gemm_grouped": [ctypes.POINTER(GemmDesc), P, P, I, I, P],

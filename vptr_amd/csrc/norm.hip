@@ -59,51 +59,69 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // The same with the row held in registers between the three sweeps (NC4 float4 per lane; C <= 256 * NC4): one global read of x
 // instead of three dependent ones (a wave has nothing else to hide its round trips behind).
-template <int NC4>
+// NR rows per wave (round 6): the rows' load -> reduce -> reduce -> store chains are independent, so a wave overlaps their round trips
+// instead of sitting through one chain per row (10 240 x 528: one row per wave = 10 240 one-chain waves, 14 us for 43 MB).
+template <int NC4, int NR>
 __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y,
                                                          float* __restrict__ y2, const float* __restrict__ tab, int tab_div,
                                                          int tab_mod, float* __restrict__ mean, float* __restrict__ rstd,
                                                          int rows, int C, float eps, int p16) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * C);
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NR;
+  if (row0 >= rows) return;
   const int C4 = C >> 2;
-  float4 v[NC4];
-  float s = 0.f;
+  float4 v[NR][NC4];
+  float s[NR];
 #pragma unroll
-  for (int j = 0; j < NC4; ++j) {
-    const int i = lane + 64 * j;
-    v[j] = i < C4 ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-  }
-  const float mu = wave_sum(s) / (float)C;
-  float q = 0.f;
+  for (int r = 0; r < NR; ++r) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)min(row0 + r, rows - 1) * C);
+    s[r] = 0.f;
 #pragma unroll
-  for (int j = 0; j < NC4; ++j) {
-    if (lane + 64 * j < C4) {
-      const float a = v[j].x - mu, b = v[j].y - mu, c = v[j].z - mu, d = v[j].w - mu;
-      q += (a * a + b * b) + (c * c + d * d);
+    for (int j = 0; j < NC4; ++j) {
+      const int i = lane + 64 * j;
+      v[r][j] = i < C4 ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      s[r] += (v[r][j].x + v[r][j].y) + (v[r][j].z + v[r][j].w);
     }
   }
-  const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
-  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-  const float4* tr = tab ? reinterpret_cast<const float4*>(tab + (int64_t)((row / tab_div) % tab_mod) * C) : nullptr;
+  float mu[NR], rs[NR];
 #pragma unroll
-  for (int j = 0; j < NC4; ++j) {
-    const int i = lane + 64 * j;
-    if (i < C4) {
-      const float4 g = reinterpret_cast<const float4*>(gamma)[i];
-      const float4 b = reinterpret_cast<const float4*>(beta)[i];
-      float4 o;
-      o.x = (v[j].x - mu) * rs * g.x + b.x; o.y = (v[j].y - mu) * rs * g.y + b.y;
-      o.z = (v[j].z - mu) * rs * g.z + b.z; o.w = (v[j].w - mu) * rs * g.w + b.w;
-      vptr_store4_fmt(y, (int64_t)row * C + 4 * i, o, p16);
-      if (y2) {
-        const float4 t = tr[i];
-        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
-        vptr_store4_fmt(y2, (int64_t)row * C + 4 * i, o, p16);
+  for (int r = 0; r < NR; ++r) mu[r] = wave_sum(s[r]) / (float)C;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NC4; ++j) {
+      if (lane + 64 * j < C4) {
+        const float a = v[r][j].x - mu[r], b = v[r][j].y - mu[r], c = v[r][j].z - mu[r], d = v[r][j].w - mu[r];
+        q += (a * a + b * b) + (c * c + d * d);
+      }
+    }
+    s[r] = q;
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) rs[r] = rsqrtf(wave_sum(s[r]) / (float)C + eps);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int row = row0 + r;
+    if (row >= rows) break;
+    if (lane == 0) { mean[row] = mu[r]; rstd[row] = rs[r]; }
+    const float4* tr = tab ? reinterpret_cast<const float4*>(tab + (int64_t)((row / tab_div) % tab_mod) * C) : nullptr;
+#pragma unroll
+    for (int j = 0; j < NC4; ++j) {
+      const int i = lane + 64 * j;
+      if (i < C4) {
+        const float4 g = reinterpret_cast<const float4*>(gamma)[i];
+        const float4 b = reinterpret_cast<const float4*>(beta)[i];
+        float4 o;
+        o.x = (v[r][j].x - mu[r]) * rs[r] * g.x + b.x; o.y = (v[r][j].y - mu[r]) * rs[r] * g.y + b.y;
+        o.z = (v[r][j].z - mu[r]) * rs[r] * g.z + b.z; o.w = (v[r][j].w - mu[r]) * rs[r] * g.w + b.w;
+        vptr_store4_fmt(y, (int64_t)row * C + 4 * i, o, p16);
+        if (y2) {
+          const float4 t = tr[i];
+          o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+          vptr_store4_fmt(y2, (int64_t)row * C + 4 * i, o, p16);
+        }
       }
     }
   }
@@ -118,10 +136,16 @@ extern "C" int vptr_layernorm_fwd(const float* x, const float* gamma, const floa
   VPTR_CHECK(C % 4 == 0, "layernorm_fwd: C must be a multiple of 4 (got %d)", C);
   if (y2) VPTR_CHECK(tab && tab_div >= 1 && tab_mod >= 1, "layernorm_fwd: y2 needs tab, tab_div, tab_mod");
   const int C4 = C >> 2;
-  if (C4 <= 64)
-    ln_fwd_reg_kernel<1><<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(x, gamma, beta, y, y2, y2 ? tab : nullptr, tab_div, tab_mod, mean, rstd, rows, C, eps, p16);
-  else if (C4 <= 192)
-    ln_fwd_reg_kernel<3><<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(x, gamma, beta, y, y2, y2 ? tab : nullptr, tab_div, tab_mod, mean, rstd, rows, C, eps, p16);
+  static int ln_rows = 0;   // VPTR_LN_ROWS = 1 | 2 | 4 rows per wave for the register-resident kernels (default 2 from 4096 rows on)
+  if (!ln_rows) { const char* e = getenv("VPTR_LN_ROWS"); ln_rows = (e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4)) ? atoi(e) : 2; }
+  const int nr = rows >= 4096 ? ln_rows : 1;
+#define LN_FWD_GO(NC, NR) ln_fwd_reg_kernel<NC, NR><<<cdiv(rows, 4 * NR), 256, 0, (hipStream_t)stream>>>(x, gamma, beta, y, y2, y2 ? tab : nullptr, tab_div, tab_mod, mean, rstd, rows, C, eps, p16)
+  if (C4 <= 64) {
+    if (nr == 4) LN_FWD_GO(1, 4); else if (nr == 2) LN_FWD_GO(1, 2); else LN_FWD_GO(1, 1);
+  } else if (C4 <= 192) {
+    if (nr == 4) LN_FWD_GO(3, 4); else if (nr == 2) LN_FWD_GO(3, 2); else LN_FWD_GO(3, 1);
+  }
+#undef LN_FWD_GO
   else
     ln_fwd_kernel<<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(x, gamma, beta, y, y2, y2 ? tab : nullptr, tab_div, tab_mod,
                                                                   mean, rstd, rows, C, eps, p16);
@@ -201,32 +225,45 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_fused_kernel(const float* __re
     ab[k] = z;
   }
   const float inv_c = 1.f / (float)C;
+  // the operands of a wave's NEXT row are requested before the two reductions of the current one (round 6: a wave walks rpb / NW rows one
+  // dependent load -> reduce -> store chain after the other, and 2 560 such waves are all a 10 240-row launch has)
+  float4 gN[NC4], xN[NC4];
+  float muN = 0.f, rsN = 0.f;
+  auto fetch = [&](const int row) {
+    muN = mean[row];
+    rsN = rstd[row];
+#pragma unroll
+    for (int k = 0; k < NC4; ++k) {
+      const int ic = min(lane + 64 * k, C4 - 1);
+      gN[k] = reinterpret_cast<const float4*>(dy_)[(int64_t)row * C4 + ic];
+      if (dy2_) {
+        const float4 g2 = reinterpret_cast<const float4*>(dy2_)[(int64_t)row * C4 + ic];
+        gN[k].x += g2.x; gN[k].y += g2.y; gN[k].z += g2.z; gN[k].w += g2.w;
+      }
+      xN[k] = reinterpret_cast<const float4*>(x_)[(int64_t)row * C4 + ic];
+    }
+  };
+  if (r0 + wv < r1) fetch(r0 + wv);
   for (int row = r0 + wv; row < r1; row += NW) {
-    const float4* dy = reinterpret_cast<const float4*>(dy_) + (int64_t)row * C4;
-    const float4* x = reinterpret_cast<const float4*>(x_) + (int64_t)row * C4;
     float4* dx = reinterpret_cast<float4*>(dx_) + (int64_t)row * C4;
-    const float mu = mean[row], rs = rstd[row];
+    const float mu = muN, rs = rsN;
     float4 g[NC4], xh[NC4], ra[NC4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int k = 0; k < NC4; ++k) {
       const int i = lane + 64 * k;
       const float m = i < C4 ? 1.f : 0.f;
-      const int ic = min(i, C4 - 1);
-      float4 gv = dy[ic];
+      const float4 gv = gN[k];
+      const float4 xv = xN[k];
       ra[k] = z;
-      if (dx_add_) ra[k] = reinterpret_cast<const float4*>(dx_add_)[(int64_t)row * C4 + ic];
-      if (dy2_) {
-        const float4 g2 = reinterpret_cast<const float4*>(dy2_)[(int64_t)row * C4 + ic];
-        gv.x += g2.x; gv.y += g2.y; gv.z += g2.z; gv.w += g2.w;
-      }
-      const float4 xv = x[ic];
+      if (dx_add_) ra[k] = reinterpret_cast<const float4*>(dx_add_)[(int64_t)row * C4 + min(i, C4 - 1)];
       g[k] = make_float4(gv.x * m, gv.y * m, gv.z * m, gv.w * m);
       xh[k] = make_float4((xv.x - mu) * rs * m, (xv.y - mu) * rs * m, (xv.z - mu) * rs * m, (xv.w - mu) * rs * m);
       const float4 gg = make_float4(g[k].x * gam[k].x, g[k].y * gam[k].y, g[k].z * gam[k].z, g[k].w * gam[k].w);
       s1 += (gg.x + gg.y) + (gg.z + gg.w);
       s2 += (gg.x * xh[k].x + gg.y * xh[k].y) + (gg.z * xh[k].z + gg.w * xh[k].w);
     }
+    if (row + NW < r1) fetch(row + NW);   // in flight under the two reductions and the stores below
     s1 = wave_sum(s1) * inv_c;
     s2 = wave_sum(s2) * inv_c;
 #pragma unroll
@@ -264,11 +301,19 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_fused_kernel(const float* __re
   }
 }
 
+// rows per workgroup of the deferred launch for 256 < C <= 768 (the step's LayerNorm(528)): 16 = 4 waves x 4 rows, 640 workgroups of 10 240
+// rows, three of them per CU -- all resident at once (round 6; VPTR_LN_BWD_RPB=32 restores 8 waves x 4 rows: 320 workgroups, ONE per CU at
+// 140 VGPRs, i.e. 1.25 rounds)
+static int ln_bwd_rpb() {
+  static int v = 0;
+  if (!v) { const char* e = getenv("VPTR_LN_BWD_RPB"); v = (e && atoi(e) == 32) ? 32 : 16; }
+  return v;
+}
 // rows of partial sums a deferred backward call writes (0: this geometry has no deferred variant)
 extern "C" int vptr_layernorm_bwd_partials(int rows, int C) {
   if (g_vptr_deterministic) return (C % 4 == 0 && C <= 1024 && rows > 0) ? cdiv(rows, 32) : 0;   // every vectorised geometry: no atomics at all
   if (rows < 4096 || C % 4 != 0 || C <= 256 || C > 768) return 0;
-  return cdiv(rows, 32);
+  return cdiv(rows, ln_bwd_rpb());
 }
 static int layernorm_bwd_impl(const float* dy, const float* dy2, const float* x, const float* gamma, const float* mean,
                               const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int C,
@@ -278,6 +323,7 @@ static int layernorm_bwd_impl(const float* dy, const float* dy2, const float* x,
     // deferred parameter gradients: no atomics, so more and shorter workgroups (32 rows each instead of 64) cost nothing
     VPTR_CHECK(dx && vptr_layernorm_bwd_partials(rows, C) > 0, "layernorm_bwd: no deferred variant for rows %d, C %d", rows, C);
     if (C <= 256) ln_bwd_fused_kernel<1, 4><<<cdiv(rows, 32), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, nullptr, nullptr, rows, C, 32, dx_add, partials);
+    else if (C <= 768 && !g_vptr_deterministic && ln_bwd_rpb() == 16) ln_bwd_fused_kernel<3, 4><<<cdiv(rows, 16), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, nullptr, nullptr, rows, C, 16, dx_add, partials);
     else if (C <= 768) ln_bwd_fused_kernel<3, 8><<<cdiv(rows, 32), 512, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, nullptr, nullptr, rows, C, 32, dx_add, partials);
     else ln_bwd_fused_kernel<4, 4><<<cdiv(rows, 32), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, nullptr, nullptr, rows, C, 32, dx_add, partials);
     VPTR_LAUNCH_CHECK();
@@ -1574,6 +1620,99 @@ __global__ __launch_bounds__(256) void dwconv_norm_fwd3_kernel(const float* __re
     }
   }
 }
+// The same operator on an LDS slab (second generation, round 6; VPTR_DWN_LDS=0 restores the register-walk kernel above, which measured 84 us
+// per launch at the K64 step's shape -- 150 VGPRs, three waves per SIMD, an eight-row dependent chain per thread -- against 67 us for the two
+// kernels it replaces).  One workgroup = one frame x 64 channels: phase 1 normalises + activates the slab's H*W x 16 channel quads ONCE (all
+// loads of a thread issued before the first use), leaves them in LDS ([pixel][16 quads] float4: every wave access is 1 KB contiguous, no bank
+// conflicts) and writes the fp16 side copy; phase 2 reads the nine taps of every output from LDS.  ~60 VGPRs, LDS H*W*256 B (16 KB on 8 x 8 maps).
+__global__ __launch_bounds__(256) void dwconv_norm_lds_kernel(const float* __restrict__ x_, const float* __restrict__ raw_stats,
+                                                              const float* __restrict__ aw_, const float* __restrict__ ab_, float eps, int act,
+                                                              const float* __restrict__ w9, const float* __restrict__ b, float* __restrict__ y_,
+                                                              _Float16* __restrict__ ah, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                              int H, int W, int F4, float* __restrict__ stats) {
+  extern __shared__ float4 dwn_tile[];   // [H * W][16]
+  const int tid = threadIdx.x, c4l = tid & 15, p0 = tid >> 4;
+  const int c4 = blockIdx.x * 16 + c4l;
+  const int64_t f = blockIdx.y;
+  const int HW = H * W;
+  const float4* __restrict__ x = reinterpret_cast<const float4*>(x_);
+  const float4* __restrict__ aw = reinterpret_cast<const float4*>(aw_);
+  const float4* __restrict__ ab = reinterpret_cast<const float4*>(ab_);
+  float4* __restrict__ y = reinterpret_cast<float4*>(y_);
+  // the frame's statistics from its producer's sums (see norm_act_fwd_kernel / dwconv_norm_fwd3_kernel)
+  const int P = HW * F4;
+  const float inv_n = 1.f / ((float)P * 4.f);
+  float m = raw_stats[2 * f] * inv_n;
+  const float e2 = raw_stats[2 * f + 1] * inv_n;
+  float var = fmaxf(e2 - m * m, 0.f);
+  if (var < 1e-3f * e2) {   // block-uniform: |mean| > ~30 std -- exact second pass of every wave over its frame, around the approximate mean
+    const float4* xf = x + f * P;
+    float sq = 0.f, s1 = 0.f;
+    for (int j = tid & 63; j < P; j += 64) {
+      const float4 t = xf[j];
+      const float a = t.x - m, b2 = t.y - m, c = t.z - m, d = t.w - m;
+      s1 += (a + b2) + (c + d);
+      sq += (a * a + b2 * b2) + (c * c + d * d);
+    }
+    const float dm = wave_sum(s1) * inv_n;
+    var = fmaxf(wave_sum(sq) * inv_n - dm * dm, 0.f);
+    m += dm;
+  }
+  const float r = rsqrtf(var + eps);
+  if (tid == 0 && blockIdx.x == 0) { mean_out[f] = m; rstd_out[f] = r; }
+  float4 w[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) w[t] = reinterpret_cast<const float4*>(w9)[(int64_t)t * F4 + c4];
+  const float4 bias = b ? reinterpret_cast<const float4*>(b)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  // ---- phase 1: four pixels per thread and trip (64 pixels per trip of the block): loads first, then the activations
+  for (int pb = 0; pb < HW; pb += 64) {
+    float4 xv[4], wv[4], bv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = min(pb + p0 + 16 * k, HW - 1);
+      xv[k] = x[(f * HW + p) * F4 + c4];
+      wv[k] = aw[(int64_t)p * F4 + c4];
+      bv[k] = ab[(int64_t)p * F4 + c4];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = pb + p0 + 16 * k;
+      if (p < HW) {
+        const float4 a = dwn_act4(xv[k], m, r, wv[k], bv[k], act, 1.f);
+        dwn_tile[p * 16 + c4l] = a;
+        if (ah) dwn_store_half4(ah, ((f * HW + p) * F4 + c4) * 4, a);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: nine taps from LDS (zero padding of the ACTIVATED tensor)
+  float ssum = 0.f, ssq = 0.f;
+  for (int p = p0; p < HW; p += 16) {
+    const int py = p / W, px = p - py * W;
+    float4 a = bias;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = py + ky - 1;
+      if (yy < 0 || yy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xx = px + kx - 1;
+        if (xx < 0 || xx >= W) continue;
+        fma4(a, w[ky * 3 + kx], dwn_tile[(yy * W + xx) * 16 + c4l]);
+      }
+    }
+    y[(f * HW + p) * F4 + c4] = a;
+    ssum += (a.x + a.y) + (a.z + a.w);
+    ssq += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+  }
+  if (stats) {
+    const float S = wave_sum(ssum), Q = wave_sum(ssq);
+    if ((tid & 63) == 0) {
+      unsafeAtomicAdd(stats + 2 * f, S);
+      unsafeAtomicAdd(stats + 2 * f + 1, Q);
+    }
+  }
+}
 extern "C" int vptr_dwconv3x3_norm_fwd(const float* x, const float* raw_stats, const float* aff_w, const float* aff_b, float eps, int act,
                                        const float* w9, const float* b, float* y, void* a_half, float* mean_out, float* rstd_out,
                                        int frames, int H, int W, int F, float* frame_stats, vptr_stream_t stream) {
@@ -1585,6 +1724,14 @@ extern "C" int vptr_dwconv3x3_norm_fwd(const float* x, const float* raw_stats, c
   VPTR_CHECK(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(aff_w) | reinterpret_cast<uintptr_t>(aff_b) |
                reinterpret_cast<uintptr_t>(w9) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 && (reinterpret_cast<uintptr_t>(a_half) & 7) == 0,
              "dwconv3x3_norm_fwd: operands must be 16-byte aligned");
+  static int use_lds = -1;
+  if (use_lds < 0) { const char* e = getenv("VPTR_DWN_LDS"); use_lds = (e && atoi(e) == 0) ? 0 : 1; }
+  if (use_lds && F % 64 == 0 && H * W <= 256 && frames <= 65535) {   // LDS slab: H * W * 256 bytes <= 64 KB
+    dwconv_norm_lds_kernel<<<dim3(F / 64, frames), 256, (size_t)H * W * 256, (hipStream_t)stream>>>(
+        x, raw_stats, aff_w, aff_b, eps, act, w9, b, y, reinterpret_cast<_Float16*>(a_half), mean_out, rstd_out, H, W, F / 4, frame_stats);
+    VPTR_LAUNCH_CHECK();
+    return 0;
+  }
   const int64_t total = (int64_t)frames * W2 * (F / 4);
   dwconv_norm_fwd3_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
       x, raw_stats, aff_w, aff_b, eps, act, w9, b, y, reinterpret_cast<_Float16*>(a_half), mean_out, rstd_out, frames, H, W, F / 4, frame_stats);

@@ -165,3 +165,120 @@ extern "C" int vptr_wino_out(const float* M36, const float* scale, const float* 
   VPTR_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Output transform of one convolution and input transform of the NEXT in one pass: the activated map of a (frame, 16-quad channel slab)
+// unit stays in LDS between the two ([pixel][16 quads] float4, H * W * 256 bytes), so the intermediate map of a ResnetBlock never
+// touches HBM and the residual stream is written once and not re-read (per convolution: one 43 MB write and one 2.25x-overlapped read
+// less).  Unit = T tiles x 16 quads threads (T = (H/4)(W/4) must divide 16: 4 x 4 ... 16 x 16 maps); 256 / (16 T) units per workgroup,
+// 64 KB of LDS.  C4 need not be a multiple of 16: the lanes of the last slab beyond C4 idle.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino_out_in_kernel(const float* __restrict__ M_, const float* __restrict__ scale_, const float* __restrict__ shift_,
+                                                           const float* residual_, float* y_, unsigned char* __restrict__ V, const int frames, const int H,
+                                                           const int W, const int C4, const int64_t Mpad, const int relu, const int act_after,
+                                                           const int pad_mode) {
+  extern __shared__ float4 wino_map[];   // [unit][H * W][16]
+  const int TH = H >> 2, TW = W >> 2, T = TH * TW, HW = H * W;
+  const int upw = 256 / (16 * T);                 // units per workgroup
+  const int tid = threadIdx.x;
+  const int u = tid / (16 * T), l = tid - u * 16 * T;
+  const int c4l = l & 15, tile = l >> 4;
+  const int nslab = (C4 + 15) >> 4;
+  const int64_t unit = (int64_t)blockIdx.x * upw + u;
+  const int64_t f = unit / nslab;
+  const int c4 = (int)(unit - f * nslab) * 16 + c4l;
+  const bool live = f < frames && c4 < C4;
+  const int ty = tile / TW, tx = tile - ty * TW;
+  const int64_t row = f * T + tile;
+  float4* map = wino_map + (size_t)u * HW * 16;
+  if (live) {
+    const float4* __restrict__ M = reinterpret_cast<const float4*>(M_);
+    const float4* residual = reinterpret_cast<const float4*>(residual_);
+    float4* y = reinterpret_cast<float4*>(y_);
+    const int64_t pitch = Mpad * C4, base = row * C4 + c4;
+    float4 t[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const float4 m0 = M[(0 * 6 + j) * pitch + base], m1 = M[(1 * 6 + j) * pitch + base], m2 = M[(2 * 6 + j) * pitch + base];
+      const float4 m3 = M[(3 * 6 + j) * pitch + base], m4 = M[(4 * 6 + j) * pitch + base], m5 = M[(5 * 6 + j) * pitch + base];
+      wino_at4(m0, m1, m2, m3, m4, m5, t[0][j], t[1][j], t[2][j], t[3][j]);
+    }
+    const float4 sc = scale_ ? reinterpret_cast<const float4*>(scale_)[c4] : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = shift_ ? reinterpret_cast<const float4*>(shift_)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 o[4];
+      wino_at4(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], o[0], o[1], o[2], o[3]);
+      const int pix = (4 * ty + i) * W + 4 * tx;
+      const int64_t e = (f * HW + pix) * C4 + c4;
+      float4 r[4];
+      if (residual) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = residual[e + (int64_t)j * C4];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float4 v = make_float4(fmaf(o[j].x, sc.x, sh.x), fmaf(o[j].y, sc.y, sh.y), fmaf(o[j].z, sc.z, sh.z), fmaf(o[j].w, sc.w, sh.w));
+        if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        if (residual) v = f4_add(v, r[j]);
+        if (act_after) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        if (y) y[e + (int64_t)j * C4] = v;
+        map[(pix + j) * 16 + c4l] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  int sx[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) sx[j] = wino_src(4 * tx - 1 + j, W, pad_mode);
+  float4 d[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int sy = wino_src(4 * ty - 1 + i, H, pad_mode);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const bool ok = sy >= 0 && sx[j] >= 0;
+      const float4 v = map[((ok ? sy : 0) * W + (ok ? sx[j] : 0)) * 16 + c4l];
+      d[i][j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) wino_bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
+  const int64_t C = (int64_t)C4 * 4;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float4 v[6];
+    wino_bt6(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], v[0], v[1], v[2], v[3], v[4], v[5]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) vptr_p16_store4(V, ((int64_t)(i * 6 + j) * Mpad + row) * C + (int64_t)c4 * 4, v[j]);
+  }
+}
+
+extern "C" int vptr_wino_out_in(const float* M36, const float* scale, const float* shift, const float* residual, float* y, void* V_next, int frames,
+                                int H, int W, int C, int64_t Mpad, int relu, int act_after, int pad_mode, vptr_stream_t stream) {
+  VPTR_CHECK(M36 && V_next && frames > 0 && H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && C > 0 && C % 16 == 0,
+             "wino_out_in: needs H, W multiples of 4 and C a multiple of 16 (got H %d W %d C %d)", H, W, C);
+  const int T = (H / 4) * (W / 4);
+  VPTR_CHECK(T <= 16 && 16 % T == 0, "wino_out_in: (H/4)*(W/4) must divide 16 (got H %d W %d): use vptr_wino_out + vptr_wino_in", H, W);
+  VPTR_CHECK(pad_mode >= 0 && pad_mode <= 2, "wino_out_in: pad_mode 0 zero / 1 reflect / 2 replicate");
+  const int64_t rows = (int64_t)frames * T;
+  VPTR_CHECK(Mpad >= rows, "wino_out_in: Mpad %lld < tile rows %lld", (long long)Mpad, (long long)rows);
+  VPTR_CHECK(((reinterpret_cast<uintptr_t>(M36) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
+               reinterpret_cast<uintptr_t>(residual)) & 15) == 0 && (reinterpret_cast<uintptr_t>(V_next) & 63) == 0 && M36 != V_next,
+             "wino_out_in: operands must be 16-byte aligned, V 64-byte aligned and distinct from M36");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_out_in_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) {
+      vptr_set_error("wino_out_in: cannot reserve 64 KB of LDS");
+      return -1;
+    }
+    attr_set = true;
+  }
+  const int upw = 256 / (16 * T);
+  const int64_t units = (int64_t)frames * ((C / 4 + 15) / 16);
+  wino_out_in_kernel<<<(unsigned)((units + upw - 1) / upw), 256, 65536, (hipStream_t)stream>>>(
+      M36, scale, shift, residual, y, reinterpret_cast<unsigned char*>(V_next), frames, H, W, C / 4, Mpad, relu, act_after, pad_mode);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}

@@ -221,18 +221,17 @@ class ResnetEncoder(nn.Module):
         # of 144 (ops.wino_conv3x3: input transform, one 36-member strided-batch P16 GEMM, output transform with BN / ReLU / skip fused)
         wino = planes and ops.wino_ok(h, w, cin, cin) and all(c.bias is None for c in m[idx]._layers()[0])
         wbufs = ops.wino_buffers(B, h, w, cin, x.device, self) if wino else None
-        for bi in range(9):
+        if wino:
+            blocks = []
+            for bi in range(9):
+                convs, bns = m[idx + bi]._layers()
+                blocks.append((ops.wino_filter(convs[0].weight),) + tuple(_bn_eval(bns[0])) + (ops.wino_filter(convs[1].weight),) + tuple(_bn_eval(bns[1])))
+            y = ops.wino_resnet_blocks(y, blocks, B, h, w, wbufs, pad_mode, last_relu=True)
+        for bi in range(0 if not wino else 9, 9):
             blk = m[idx + bi]
             convs, bns = blk._layers()
             s1, b1 = _bn_eval(bns[0])
             s2, b2 = _bn_eval(bns[1])
-            if wino:
-                if bi == 0:
-                    tbuf = torch.empty_like(y)
-                t = ops.wino_conv3x3(y, ops.wino_filter(convs[0].weight), B, h, w, wbufs, pad_mode, colscale=s1, bias=b1, relu=True, out=tbuf)
-                y = ops.wino_conv3x3(t, ops.wino_filter(convs[1].weight), B, h, w, wbufs, pad_mode, colscale=s2, bias=b2, residual=y,
-                                     act_after=(bi == 8), out=y)
-                continue
             if planes:
                 # two persistent, zero-initialised plane buffers: the convs write their result in plane form themselves
                 # (pad channels and the all-zero row are never touched), only the very first input needs a split pass

@@ -50,7 +50,8 @@ from .layout import (  # noqa: F401
 )
 from .conv import (  # noqa: F401
     SubpixelWeights, conv_weight_as_gemm_b, in_flat_slab, weights_cacheable, frozen_weights, conv_nhwc, split_planes,
-    conv_weight_as_planes, conv_nhwc_planes, wino_ok, wino_filter, wino_buffers, wino_conv3x3, _Conv2dNHWCFn, conv2d_nhwc, _Conv7InFn, conv7_in, _Conv7OutFn, conv7_out, bn_fold,
+    conv_weight_as_planes, conv_nhwc_planes, wino_ok, wino_filter, wino_buffers, wino_in, wino_gemm, wino_out, wino_fused_ok, wino_out_in, wino_conv3x3,
+    wino_resnet_blocks, _Conv2dNHWCFn, conv2d_nhwc, _Conv7InFn, conv7_in, _Conv7OutFn, conv7_out, bn_fold,
 )
 from .losses import (  # noqa: F401
     _MseGdlFn, mse_gdl, _NceFn, nce_loss,

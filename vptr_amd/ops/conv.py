@@ -214,24 +214,82 @@ def wino_buffers(frames, H, W, C, device, holder):
     return hit[1], hit[2], Mpad
 
 
+def wino_in(x, frames, H, W, bufs, pad_mode="zero"):
+    """input transform: NHWC tokens x [frames * H * W, C] -> bufs' V (P16, [36][Mpad][C])"""
+    V, _, Mpad = bufs
+    x = _c(x)
+    check(lib.vptr_wino_in(ptr(x), ptr(V), frames, H, W, x.shape[1], Mpad, PAD_MODES[pad_mode], stream()), "vptr_wino_in")
+
+
+def wino_gemm(U, frames, H, W, bufs):
+    """M36[xi nu] = V[xi nu] . U[xi nu]^T: ONE strided-batch launch of the P16 nt GEMM, 36 members"""
+    V, M36, Mpad = bufs
+    Cout, C = U.shape[1], U.shape[2]
+    rows = frames * (H // 4) * (W // 4)
+    gemm_raw(V, U, M36, rows, Cout, C, 5, 3, lda=C, ldb=C, ldd=Cout, precision=3, batch_strided=(36, Mpad * C, Cout * C, Mpad * Cout))
+
+
+def wino_out(frames, H, W, C, bufs, colscale=None, bias=None, relu=False, residual=None, act_after=False, out=None):
+    """output transform + folded BN / ReLU / skip: bufs' M36 -> NHWC tokens (out may be `residual` itself)"""
+    _, M36, Mpad = bufs
+    if out is None:
+        out = torch.empty((frames * H * W, C), device=M36.device, dtype=torch.float32)
+    check(lib.vptr_wino_out(ptr(M36), ptr(colscale), ptr(bias), ptr(residual), ptr(out), frames, H, W, C, Mpad, int(bool(relu)),
+                            int(bool(act_after)), stream()), "vptr_wino_out")
+    return out
+
+
+def wino_fused_ok(H, W):
+    """can the output transform of one convolution feed the input transform of the next through LDS? (vptr_wino_out_in: whole maps of at most
+    16 tiles per 16-quad channel slab)"""
+    T = (H // 4) * (W // 4)
+    return config.winograd_fuse and 1 <= T <= 16 and 16 % T == 0
+
+
+def wino_out_in(frames, H, W, C, bufs, pad_mode="zero", colscale=None, bias=None, relu=False, residual=None, act_after=False, out=None):
+    """wino_out of this convolution + wino_in of the next in one pass (the map stays in LDS); `out` = None: the map itself is not kept"""
+    V, M36, Mpad = bufs
+    check(lib.vptr_wino_out_in(ptr(M36), ptr(colscale), ptr(bias), ptr(residual), ptr(out), ptr(V), frames, H, W, C, Mpad, int(bool(relu)),
+                               int(bool(act_after)), PAD_MODES[pad_mode], stream()), "vptr_wino_out_in")
+    return out
+
+
 def wino_conv3x3(x, U, frames, H, W, bufs, pad_mode="zero", colscale=None, bias=None, relu=False, residual=None, act_after=False, out=None):
     """y = [relu](conv3x3(x) * colscale + bias) [+ residual] [relu] on NHWC tokens x [frames * H * W, C] (stride 1, one pixel of `pad_mode`
     padding) as Winograd F(4x4, 3x3): input transform -> ONE strided-batch P16 GEMM of 36 members -> output transform with the epilogue.
     U from wino_filter, bufs from wino_buffers.  out may be `residual` itself."""
-    V, M36, Mpad = bufs
     C = x.shape[1]
-    Cout = U.shape[1]
-    if Cout != C:
-        raise RuntimeError("wino_conv3x3: square convolutions only (Cin %d, Cout %d)" % (C, Cout))
-    rows = frames * (H // 4) * (W // 4)
-    x = _c(x)
-    check(lib.vptr_wino_in(ptr(x), ptr(V), frames, H, W, C, Mpad, PAD_MODES[pad_mode], stream()), "vptr_wino_in")
-    gemm_raw(V, U, M36, rows, Cout, C, 5, 3, lda=C, ldb=C, ldd=Cout, precision=3, batch_strided=(36, Mpad * C, Cout * C, Mpad * Cout))
-    if out is None:
-        out = torch.empty((frames * H * W, Cout), device=x.device, dtype=torch.float32)
-    check(lib.vptr_wino_out(ptr(M36), ptr(colscale), ptr(bias), ptr(residual), ptr(out), frames, H, W, Cout, Mpad, int(bool(relu)),
-                            int(bool(act_after)), stream()), "vptr_wino_out")
-    return out
+    if U.shape[1] != C or U.shape[2] != C:
+        raise RuntimeError("wino_conv3x3: square convolutions only (C %d, filter %s)" % (C, tuple(U.shape)))
+    wino_in(x, frames, H, W, bufs, pad_mode)
+    wino_gemm(U, frames, H, W, bufs)
+    return wino_out(frames, H, W, C, bufs, colscale, bias, relu, residual, act_after, out)
+
+
+def wino_resnet_blocks(y, blocks, frames, H, W, bufs, pad_mode, last_relu=True):
+    """The ResnetBlock chain of the frozen encoder (ResNetAutoEncoder.py:153-157: y <- y + BN(conv(pad(ReLU(BN(conv(pad(y)))))))) in the Winograd
+    domain.  blocks = [(U1, scale1, shift1, U2, scale2, shift2), ...]; y [frames * H * W, C] fp32 is updated in place and returned.  With
+    wino_fused_ok the map of every convolution goes to the next one's input transform through LDS: one launch between two GEMMs."""
+    C = y.shape[1]
+    fused = wino_fused_ok(H, W)
+    tbuf = None if fused else torch.empty_like(y)
+    wino_in(y, frames, H, W, bufs, pad_mode)
+    n = len(blocks)
+    for bi, (U1, s1, b1, U2, s2, b2) in enumerate(blocks):
+        last = bi == n - 1
+        wino_gemm(U1, frames, H, W, bufs)
+        if fused:
+            wino_out_in(frames, H, W, C, bufs, pad_mode, colscale=s1, bias=b1, relu=True)
+        else:
+            wino_in(wino_out(frames, H, W, C, bufs, s1, b1, relu=True, out=tbuf), frames, H, W, bufs, pad_mode)
+        wino_gemm(U2, frames, H, W, bufs)
+        if last:
+            wino_out(frames, H, W, C, bufs, s2, b2, residual=y, act_after=last_relu, out=y)
+        elif fused:
+            wino_out_in(frames, H, W, C, bufs, pad_mode, colscale=s2, bias=b2, residual=y, out=y)
+        else:
+            wino_in(wino_out(frames, H, W, C, bufs, s2, b2, residual=y, out=y), frames, H, W, bufs, pad_mode)
+    return y
 
 
 # ---- trainable convolutions (stage-1 auto-encoder / PatchGAN training, train_AutoEncoder.py:44-86) -------------------------
