@@ -81,6 +81,13 @@ enum { VPTR_B_KCONTIG = 0, VPTR_B_KSTRIDED = 1,
 enum { VPTR_ACT_NONE = 0, VPTR_ACT_GELU = 1, VPTR_ACT_RELU = 2, VPTR_ACT_LRELU = 3 /* LeakyReLU(0.2), VPTR_modules.py:70 */ };
 enum { VPTR_PAD_ZERO = 0, VPTR_PAD_REFLECT = 1, VPTR_PAD_REPLICATE = 2 };
 
+/* ABI 10: floats per frame of a frame-statistics buffer (vptr_gemm_desc.frame_stats, vptr_dwconv3x3_fwd(frame_stats), raw_stats of
+ * vptr_norm_act_fwd / vptr_dwconv3x3_norm_fwd): [frames][VPTR_FRAME_STATS_STRIDE], sum at [0], sum of squares at [1], the rest unused.  One
+ * 128-byte line per frame: the producers' fp32 atomics of different frames never meet in one L2 line (with the [frames][2] layout of
+ * ABI <= 9 the 160 frames of a K64 step shared 10 lines and a launch's atomics serialised there: 120 of the 172 us of a fused
+ * normalise + depthwise launch, profiles/r06_dwn_probe.log). */
+#define VPTR_FRAME_STATS_STRIDE 32
+
 typedef struct vptr_gemm_desc {
   const float* A; /* a_mode 0: [M, lda] (k contiguous); 1: [K, lda] (m contiguous); 2: NHWC image, see conv_* */
   const float* B; /* b_mode 0: [N, ldb] (k contiguous, i.e. nn.Linear weight); 1: [K, ldb] (n contiguous) */
@@ -142,8 +149,8 @@ typedef struct vptr_gemm_desc {
      fp32 or P16.  Not combinable with bias / colscale / Dpre / rowscale / residual / act_after / atomic / batch / ksegs. */
   const float* act_grad_src;
   /* a_mode = VPTR_A_P16 only: per-frame statistics of the OUTPUT for the LayerNorm((F,H,W)) that consumes it (MlpDWBN,
-     VidHRFormer_modules.py:397-419): frame_stats[2 f] += sum, frame_stats[2 f + 1] += sum of squares of the rows
-     [f * frame_rows, (f + 1) * frame_rows) of D (fp32 atomics into a zeroed [M / frame_rows][2] buffer; frame_rows % 64 == 0).
+     VidHRFormer_modules.py:397-419): frame_stats[S f] += sum, frame_stats[S f + 1] += sum of squares (S = VPTR_FRAME_STATS_STRIDE) of the rows
+     [f * frame_rows, (f + 1) * frame_rows) of D (fp32 atomics into a zeroed [M / frame_rows][VPTR_FRAME_STATS_STRIDE] buffer; frame_rows % 64 == 0).
      vptr_norm_act_fwd(raw_stats = ...) turns them into mean / rstd -- no separate statistics pass over D. */
   float* frame_stats;
   int frame_rows;

@@ -453,8 +453,8 @@ __device__ __forceinline__ void gemm_epilogue_rows_halves_batched(const vptr_gem
 #pragma unroll
         for (int w = 0; w < GNT / 64; ++w) { s8 += red[2 * w]; q8 += red[2 * w + 1]; }
         const int fr = (m0 + h * HR) / p.frame_rows;
-        unsafeAtomicAdd(p.frame_stats + 2 * fr, s8);
-        unsafeAtomicAdd(p.frame_stats + 2 * fr + 1, q8);
+        unsafeAtomicAdd(p.frame_stats + VPTR_FRAME_STATS_STRIDE * fr, s8);
+        unsafeAtomicAdd(p.frame_stats + VPTR_FRAME_STATS_STRIDE * fr + 1, q8);
       }
     }
 #ifdef VPTR_P16_TIMING

@@ -708,8 +708,8 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const float* __restri
       const int f = row / HW, hw = row - f * HW;
       float m, r;
       if (raw_stats) {   // per-frame sum / sum of squares accumulated by the PRODUCER's epilogue (vptr_gemm frame_stats, vptr_dwconv3x3_fwd)
-        m = raw_stats[2 * f] * inv_n;
-        const float e2 = raw_stats[2 * f + 1] * inv_n;
+        m = raw_stats[VPTR_FRAME_STATS_STRIDE * f] * inv_n;
+        const float e2 = raw_stats[VPTR_FRAME_STATS_STRIDE * f + 1] * inv_n;
         float var = fmaxf(e2 - m * m, 0.f);
         // E[x^2] - mean^2 from fp32 sums loses log2(E[x^2] / var) bits.  |mean| > ~30 std: recompute the frame's variance around its
         // mean (exact two-pass; this workgroup reads the whole frame -- every workgroup of the frame finds the same value).  guard:
@@ -788,8 +788,8 @@ __global__ __launch_bounds__(256) void norm_act_fwd_pos_kernel(const float* __re
     const float4 v = reinterpret_cast<const float4*>(x)[i];
     float m, r;
     if (raw_stats) {
-      m = raw_stats[2 * f] * inv_n;
-      const float e2 = raw_stats[2 * f + 1] * inv_n;
+      m = raw_stats[VPTR_FRAME_STATS_STRIDE * f] * inv_n;
+      const float e2 = raw_stats[VPTR_FRAME_STATS_STRIDE * f + 1] * inv_n;
       float var = fmaxf(e2 - m * m, 0.f);
       if (guard && var < 1e-3f * e2) {   // see norm_act_fwd_kernel; guard implies P % 256 == 0: every thread of the workgroup is live
         const float4* xf = reinterpret_cast<const float4*>(x) + (int64_t)f * P;
@@ -1422,8 +1422,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd2_kernel(const float* __restric
   if (stats) {   // the wave lies inside one frame (W2 * F4 % 64 == 0): per-frame sum / sum of squares for the LayerNorm((F,H,W)) that follows
     const float S = wave_sum(ssum), Q = wave_sum(ssq);
     if ((threadIdx.x & 63) == 0) {
-      unsafeAtomicAdd(stats + 2 * f, S);
-      unsafeAtomicAdd(stats + 2 * f + 1, Q);
+      unsafeAtomicAdd(stats + VPTR_FRAME_STATS_STRIDE * f, S);
+      unsafeAtomicAdd(stats + VPTR_FRAME_STATS_STRIDE * f + 1, Q);
     }
   }
 }
@@ -1487,8 +1487,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd3_kernel(const float* __restric
   if (stats) {   // the wave lies inside one frame (W2 * F4 % 64 == 0)
     const float S = wave_sum(ssum), Q = wave_sum(ssq);
     if ((threadIdx.x & 63) == 0) {
-      unsafeAtomicAdd(stats + 2 * f, S);
-      unsafeAtomicAdd(stats + 2 * f + 1, Q);
+      unsafeAtomicAdd(stats + VPTR_FRAME_STATS_STRIDE * f, S);
+      unsafeAtomicAdd(stats + VPTR_FRAME_STATS_STRIDE * f + 1, Q);
     }
   }
 }
@@ -1533,8 +1533,8 @@ __global__ __launch_bounds__(256) void dwconv_norm_fwd3_kernel(const float* __re
   // the frame's statistics from its producer's sums (see norm_act_fwd_kernel)
   const int P = H * W * F4;
   const float inv_n = 1.f / ((float)P * 4.f);
-  float m = raw_stats[2 * f] * inv_n;
-  const float e2 = raw_stats[2 * f + 1] * inv_n;
+  float m = raw_stats[VPTR_FRAME_STATS_STRIDE * f] * inv_n;
+  const float e2 = raw_stats[VPTR_FRAME_STATS_STRIDE * f + 1] * inv_n;
   float var = fmaxf(e2 - m * m, 0.f);
   if (var < 1e-3f * e2) {   // wave-uniform (f is): |mean| > ~30 std -- exact second pass of this wave over its frame, around the approximate mean
     const float4* xf = x + f * P;
@@ -1615,8 +1615,8 @@ __global__ __launch_bounds__(256) void dwconv_norm_fwd3_kernel(const float* __re
   if (stats) {
     const float S = wave_sum(ssum), Q = wave_sum(ssq);
     if ((threadIdx.x & 63) == 0) {
-      unsafeAtomicAdd(stats + 2 * f, S);
-      unsafeAtomicAdd(stats + 2 * f + 1, Q);
+      unsafeAtomicAdd(stats + VPTR_FRAME_STATS_STRIDE * f, S);
+      unsafeAtomicAdd(stats + VPTR_FRAME_STATS_STRIDE * f + 1, Q);
     }
   }
 }
@@ -1629,7 +1629,9 @@ __global__ __launch_bounds__(256) void dwconv_norm_lds_kernel(const float* __res
                                                               const float* __restrict__ aw_, const float* __restrict__ ab_, float eps, int act,
                                                               const float* __restrict__ w9, const float* __restrict__ b, float* __restrict__ y_,
                                                               _Float16* __restrict__ ah, float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                              int H, int W, int F4, float* __restrict__ stats) {
+                                                              int H, int W, int F4, float* __restrict__ stats, const int dbg) {
+  // dbg (VPTR_DWN_DBG, elimination runs of tools/dwn_probe.py; 0 in production): 1 no fp16 side copy, 2 no statistics atomics, 4 centre tap only,
+  // 16 no affine-table loads, 32 no y store
   extern __shared__ float4 dwn_tile[];   // [H * W][16]
   const int tid = threadIdx.x, c4l = tid & 15, p0 = tid >> 4;
   const int c4 = blockIdx.x * 16 + c4l;
@@ -1642,8 +1644,8 @@ __global__ __launch_bounds__(256) void dwconv_norm_lds_kernel(const float* __res
   // the frame's statistics from its producer's sums (see norm_act_fwd_kernel / dwconv_norm_fwd3_kernel)
   const int P = HW * F4;
   const float inv_n = 1.f / ((float)P * 4.f);
-  float m = raw_stats[2 * f] * inv_n;
-  const float e2 = raw_stats[2 * f + 1] * inv_n;
+  float m = raw_stats[VPTR_FRAME_STATS_STRIDE * f] * inv_n;
+  const float e2 = raw_stats[VPTR_FRAME_STATS_STRIDE * f + 1] * inv_n;
   float var = fmaxf(e2 - m * m, 0.f);
   if (var < 1e-3f * e2) {   // block-uniform: |mean| > ~30 std -- exact second pass of every wave over its frame, around the approximate mean
     const float4* xf = x + f * P;
@@ -1671,8 +1673,8 @@ __global__ __launch_bounds__(256) void dwconv_norm_lds_kernel(const float* __res
     for (int k = 0; k < 4; ++k) {
       const int p = min(pb + p0 + 16 * k, HW - 1);
       xv[k] = x[(f * HW + p) * F4 + c4];
-      wv[k] = aw[(int64_t)p * F4 + c4];
-      bv[k] = ab[(int64_t)p * F4 + c4];
+      if (dbg & 16) { wv[k] = make_float4(1.f, 1.f, 1.f, 1.f); bv[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      else { wv[k] = aw[(int64_t)p * F4 + c4]; bv[k] = ab[(int64_t)p * F4 + c4]; }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1680,7 +1682,7 @@ __global__ __launch_bounds__(256) void dwconv_norm_lds_kernel(const float* __res
       if (p < HW) {
         const float4 a = dwn_act4(xv[k], m, r, wv[k], bv[k], act, 1.f);
         dwn_tile[p * 16 + c4l] = a;
-        if (ah) dwn_store_half4(ah, ((f * HW + p) * F4 + c4) * 4, a);
+        if (ah && !(dbg & 1)) dwn_store_half4(ah, ((f * HW + p) * F4 + c4) * 4, a);
       }
     }
   }
@@ -1690,26 +1692,34 @@ __global__ __launch_bounds__(256) void dwconv_norm_lds_kernel(const float* __res
   for (int p = p0; p < HW; p += 16) {
     const int py = p / W, px = p - py * W;
     float4 a = bias;
+    if (dbg & 4) fma4(a, w[4], dwn_tile[p * 16 + c4l]);
+    else {
+      // branch-free taps: a clamped address and a 0 / 1 factor instead of divergent skips
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int yy = py + ky - 1;
-      if (yy < 0 || yy >= H) continue;
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = py + ky - 1;
+        const bool yok = yy >= 0 && yy < H;
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int xx = px + kx - 1;
-        if (xx < 0 || xx >= W) continue;
-        fma4(a, w[ky * 3 + kx], dwn_tile[(yy * W + xx) * 16 + c4l]);
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xx = px + kx - 1;
+          const bool ok = yok && xx >= 0 && xx < W;
+          const float4 v = dwn_tile[(ok ? yy * W + xx : p) * 16 + c4l];
+          fma4(a, w[ky * 3 + kx], scale4(v, ok ? 1.f : 0.f));
+        }
       }
     }
-    y[(f * HW + p) * F4 + c4] = a;
+    if (!(dbg & 32) || a.x == 12345.678f) y[(f * HW + p) * F4 + c4] = a;
     ssum += (a.x + a.y) + (a.z + a.w);
     ssq += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
   }
-  if (stats) {
+  if (stats && !(dbg & 2)) {   // one pair of atomics per workgroup: the four waves' sums meet in LDS first
+    __shared__ float dwn_red[8];
     const float S = wave_sum(ssum), Q = wave_sum(ssq);
-    if ((tid & 63) == 0) {
-      unsafeAtomicAdd(stats + 2 * f, S);
-      unsafeAtomicAdd(stats + 2 * f + 1, Q);
+    if ((tid & 63) == 0) { dwn_red[tid >> 6] = S; dwn_red[4 + (tid >> 6)] = Q; }
+    __syncthreads();
+    if (tid == 0) {
+      unsafeAtomicAdd(stats + VPTR_FRAME_STATS_STRIDE * f, (dwn_red[0] + dwn_red[1]) + (dwn_red[2] + dwn_red[3]));
+      unsafeAtomicAdd(stats + VPTR_FRAME_STATS_STRIDE * f + 1, (dwn_red[4] + dwn_red[5]) + (dwn_red[6] + dwn_red[7]));
     }
   }
 }
@@ -1724,11 +1734,16 @@ extern "C" int vptr_dwconv3x3_norm_fwd(const float* x, const float* raw_stats, c
   VPTR_CHECK(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(aff_w) | reinterpret_cast<uintptr_t>(aff_b) |
                reinterpret_cast<uintptr_t>(w9) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 && (reinterpret_cast<uintptr_t>(a_half) & 7) == 0,
              "dwconv3x3_norm_fwd: operands must be 16-byte aligned");
-  static int use_lds = -1;
-  if (use_lds < 0) { const char* e = getenv("VPTR_DWN_LDS"); use_lds = (e && atoi(e) == 0) ? 0 : 1; }
+  static int use_lds = -1, dbg = 0;
+  if (use_lds < 0) {
+    const char* e = getenv("VPTR_DWN_LDS");
+    use_lds = (e && atoi(e) == 0) ? 0 : 1;
+    const char* d = getenv("VPTR_DWN_DBG");
+    dbg = d ? atoi(d) : 0;
+  }
   if (use_lds && F % 64 == 0 && H * W <= 256 && frames <= 65535) {   // LDS slab: H * W * 256 bytes <= 64 KB
     dwconv_norm_lds_kernel<<<dim3(F / 64, frames), 256, (size_t)H * W * 256, (hipStream_t)stream>>>(
-        x, raw_stats, aff_w, aff_b, eps, act, w9, b, y, reinterpret_cast<_Float16*>(a_half), mean_out, rstd_out, H, W, F / 4, frame_stats);
+        x, raw_stats, aff_w, aff_b, eps, act, w9, b, y, reinterpret_cast<_Float16*>(a_half), mean_out, rstd_out, H, W, F / 4, frame_stats, dbg);
     VPTR_LAUNCH_CHECK();
     return 0;
   }

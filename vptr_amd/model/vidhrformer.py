@@ -258,7 +258,7 @@ class MlpDWBN(nn.Module):
         HW, frames, rows = g.H * g.W, g.N * g.T, u.shape[0]
         S = self.layer_norm and P and ops.frame_stats_ok(rows, HW, F) and ops.frame_stats_ok(rows, HW, self.out_features)
         Sd = S and ops.frame_stats_ok(rows, HW, F, g.W)
-        buf = ops.frame_stats_buffer(3 * frames, u.device).view(3, frames, 2) if S else None   # one fill for the three normalisations
+        buf = ops.frame_stats_buffer(3 * frames, u.device).view(3, frames, ops.FRAME_STATS_STRIDE) if S else None   # one fill for the three normalisations
         st = [buf[i] if k else None for i, k in enumerate((S, Sd, S))]
         h = ops.linear(u, self.fc1.weight.view(F, C), self.fc1.bias, x_p16=x_p16, dy_p16=P, frame_stats=st[0], frame_rows=HW)
         if st[0] is not None and ops.norm_dwconv_ok(rows, HW, F, g.H, g.W) and tuple(self.norm1.normalized_shape[1:]) == (g.H, g.W):
@@ -478,12 +478,12 @@ class VidHRformerDecoderNAR(nn.Module):
 
 
 def _ln_ffn_stats_floats(stack, frames):
-    """floats of frame-statistics accumulators one forward of `stack` requests (3 x [frames, 2] per LayerNorm conv-FFN)"""
+    """floats of frame-statistics accumulators one forward of `stack` requests (3 x [frames, FRAME_STATS_STRIDE] per LayerNorm conv-FFN)"""
     n = getattr(stack, "_n_ln_ffn", None)
     if n is None:
         n = sum(1 for m in stack.modules() if isinstance(m, MlpDWBN) and m.layer_norm)
         stack.__dict__["_n_ln_ffn"] = n
-    return n * 3 * frames * 2
+    return n * 3 * frames * ops.FRAME_STATS_STRIDE
 
 
 def _assign_sites(module, base=0):

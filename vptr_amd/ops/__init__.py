@@ -29,7 +29,7 @@ from .planes import (  # noqa: F401
     invalidate_weight_planes, weight_planes_for, linear_weights_of,
 )
 from .linear import (  # noqa: F401
-    _linear_param_grads, _LinearFn, _LinearFn_apply, linear, frame_stats_ok, _zero_arena, zero_arena, frame_stats_buffer, _MlpFn,
+    _linear_param_grads, _LinearFn, _LinearFn_apply, linear, frame_stats_ok, _zero_arena, zero_arena, FRAME_STATS_STRIDE, frame_stats_buffer, _MlpFn,
     _MlpFn_apply, mlp,
 )
 from .norm import (  # noqa: F401

@@ -157,7 +157,7 @@ _LinearFn_apply = _direct_apply(_LinearFn)
 
 def linear(x, W, b=None, residual=None, alpha=1.0, act=ACT_NONE, rowscale=None, rs_div=1, rs_mod=1, dropout_p=0.0, site=0,
            x_p16=False, out_p16=False, dy_p16=False, frame_stats=None, frame_rows=0):
-    """frame_stats / frame_rows: a zeroed [rows / frame_rows, 2] buffer (frame_stats_buffer) that the GEMM epilogue fills with each
+    """frame_stats / frame_rows: a zeroed [rows / frame_rows, FRAME_STATS_STRIDE] buffer (frame_stats_buffer) that the GEMM epilogue fills with each
     frame's sum / sum of squares of y, for norm_act(..., raw_stats=...) -- the LayerNorm((F,H,W)) after a 1x1 convolution then needs no
     statistics pass of its own."""
     return _LinearFn_apply(x, W, b, residual, rowscale, float(alpha), int(act), int(rs_div), int(rs_mod), float(dropout_p),
@@ -193,16 +193,19 @@ class zero_arena:
         return False
 
 
+FRAME_STATS_STRIDE = 32   # include/vptr_hip.h VPTR_FRAME_STATS_STRIDE: one 128-byte line per frame (sum at [0], sum of squares at [1])
+
+
 def frame_stats_buffer(frames, device):
-    """a zeroed [frames, 2] fp32 buffer for one producer / consumer pair (a slice of the forward's zero_arena when one is open;
-    inside a graph capture the arena's fill is re-run at every replay)"""
-    n = 2 * int(frames)
+    """a zeroed [frames, FRAME_STATS_STRIDE] fp32 buffer for one producer / consumer pair (a slice of the forward's zero_arena when one is
+    open; inside a graph capture the arena's fill is re-run at every replay)"""
+    n = FRAME_STATS_STRIDE * int(frames)
     buf = _zero_arena["buf"]
     if buf is not None and buf.device == torch.device(device) and _zero_arena["off"] + n <= buf.numel():
         off = _zero_arena["off"]
         _zero_arena["off"] = off + n
-        return buf[off:off + n].view(frames, 2)
-    return torch.zeros((frames, 2), device=device, dtype=torch.float32)
+        return buf[off:off + n].view(frames, FRAME_STATS_STRIDE)
+    return torch.zeros((frames, FRAME_STATS_STRIDE), device=device, dtype=torch.float32)
 
 
 class _MlpFn(torch.autograd.Function):
