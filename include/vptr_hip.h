@@ -391,6 +391,15 @@ int vptr_norm_act_bwd_deferred(const float* dy, const float* x, const float* mea
                                float* dx, float* scratch, int rows, int F, int HW, int act, int const_stats, float dropout_p,
                                const uint64_t* seed_dev, uint32_t site, const float* rowscale, int rs_div, int rs_mod, int p16,
                                float* partials, vptr_stream_t stream);
+/* ABI 10.  The LayerNorm((F,H,W)) mode of vptr_norm_act_bwd_deferred in ONE pass over dy and x (cooperative: the workgroups of a chunk of 10
+ * frames exchange the frames' two sums through sync_ws and wait for each other; 260 MB per [10240 x 2112] call instead of 432, one launch
+ * instead of three).  vptr_norm_act_bwd_coop_partials = rows of the partial-sum buffer [chunks][2][HW * F] it writes (0: take the two-phase
+ * call -- VPTR_NORM_COOP=0, deterministic mode, fewer than 16 frames, a chunk too large to be co-resident).  sync_ws: [(rows / HW) + 1][32]
+ * floats, 128-byte aligned, ZERO on entry, not restored (last line: != 0 if a bounded wait ever ran out). */
+int vptr_norm_act_bwd_coop_partials(int rows, int F, int HW);
+int vptr_norm_act_bwd_coop(const float* dy, const float* x, const float* mean, const float* rstd, const float* w, const float* b, float* dx,
+                           float* sync_ws, int rows, int F, int HW, int act, float dropout_p, const uint64_t* seed_dev, uint32_t site,
+                           const float* rowscale, int rs_div, int rs_mod, int p16, float* partials, vptr_stream_t stream);
 int vptr_norm_act_bwd_partials(int rows, int F, int HW, int per_col);   /* a plain number (0: use vptr_norm_act_bwd) */
 /* depthwise 3x3, pad 1 (VidHRFormer_modules.py:404-409,433); w given tap-major [9, F]. */
 /* frame_stats (may be NULL): [frames][2] zeroed buffer that receives each frame's sum / sum of squares of y (see

@@ -315,3 +315,40 @@ def test_norm_dwconv_large_mean_guard(ops, dev):
     a = 0.5 * z * (1.0 + torch.erf(z / 2 ** 0.5))
     ref = F.conv2d(a.view(frames, H, W, F_).permute(0, 3, 1, 2), dwt.double(), None, padding=1, groups=F_).permute(0, 2, 3, 1).reshape(rows, F_)
     assert float((o.double() - ref).norm() / ref.norm()) < 1e-4
+
+
+@pytest.mark.parametrize("frames,HW,F_,p", [(32, 64, 192, 0.0), (23, 64, 528, 0.1), (160, 64, 2112, 0.1), (40, 256, 96, 0.0)])
+def test_norm_act_bwd_coop_matches_two_phase(ops, dev, frames, HW, F_, p):
+    """round 6: the cooperative ONE-pass LayerNorm((F,H,W)) backward (vptr_norm_act_bwd_coop: workgroups of a 10-frame chunk exchange the frames'
+    sums through one workspace line per frame) == the two-phase deferred call (frame sums + affine partials, then dx): dx and the affine
+    gradients (partial rows summed), with dropout + row scale, fp32 and P16 dx; the time-out flag of the workspace stays clear"""
+    from vptr_amd._lib import check, lib, ptr, stream
+    rows = frames * HW
+    assert lib.vptr_norm_act_bwd_coop_partials(rows, F_, HW) == (frames + 9) // 10
+    x, dy = rn((rows, F_), 1).to(dev), rn((rows, F_), 2).to(dev)
+    w, b = (rn((HW, F_), 3).abs() + 0.5).to(dev), rn((HW, F_), 4, 0.3).to(dev)
+    xf = x.view(frames, -1)
+    mean = xf.mean(1).contiguous()
+    rstd = torch.rsqrt(xf.var(1, unbiased=False) + 1e-5).contiguous()
+    rowscale = (torch.rand(frames, device=dev) > 0.2).float() / 0.8
+    seed = ops.seed_tensor(dev) if p > 0 else None
+    for p16 in (0, 1):
+        dx_a, dx_b = torch.empty_like(x), torch.empty_like(x)
+        n2 = lib.vptr_norm_act_bwd_partials(rows, F_, HW, 0)
+        assert n2 > 0
+        part2 = torch.empty((n2, 2, HW * F_), device=dev)
+        scratch = torch.empty((max(2 * F_, 2 * frames * (1 + 4 * ((HW * F_ // 4 + 255) // 256))),), device=dev)
+        check(lib.vptr_norm_act_bwd_deferred(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(b), ptr(dx_a), ptr(scratch), rows, F_, HW, 1, 0, p,
+                                             ptr(seed), 7, ptr(rowscale), HW, frames, p16, ptr(part2), stream()), "two-phase")
+        n1 = (frames + 9) // 10
+        part1 = torch.empty((n1, 2, HW * F_), device=dev)
+        ws = torch.zeros((frames + 1) * 32, device=dev)
+        check(lib.vptr_norm_act_bwd_coop(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(b), ptr(dx_b), ptr(ws), rows, F_, HW, 1, p, ptr(seed), 7,
+                                         ptr(rowscale), HW, frames, p16, ptr(part1), stream()), "coop")
+        torch.cuda.synchronize()
+        assert int(ws.view(torch.int32)[frames * 32]) == 0, "a bounded wait of the cooperative kernel ran out"
+        assert int(ws.view(torch.int32).view(frames + 1, 32)[:frames, 2].min()) == (HW * F_ // 4 + 255) // 256
+        a = ops.p16_decode(dx_a) if p16 else dx_a
+        bb = ops.p16_decode(dx_b) if p16 else dx_b
+        assert rel(bb, a) < 2e-6, (p16, rel(bb, a))
+        assert rel(part1.sum(0), part2.sum(0)) < 2e-6

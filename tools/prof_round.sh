@@ -4,7 +4,7 @@
 # MI355X_MICROARCH.md), (3) MFMA utilisation / wait / LDS counters of the top kernels (own passes, --kernel-trace only).
 # Writes gpurun_out/r02/*; copy the summaries into profiles/.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=${R:-r05}; export R
+R=${R:-r06}; export R
 OUT=gpurun_out/$R; mkdir -p $OUT; rm -rf $OUT/stats $OUT/pmc $OUT/rccl
 BENCH="python bench.py --graph 0 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs"   # eager launches: one traced kernel per launch
 SHORT="python bench.py --graph 0 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs"
@@ -15,6 +15,10 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc -o w --output-format csv -
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $OUT/pmc -o m1 --output-format csv -- $SHORT > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc -o m2 --output-format csv -- $SHORT > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM -d $OUT/pmc -o m3 --output-format csv -- $SHORT > /dev/null 2>&1
+XCH="python bench.py --force-exchange --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs"   # the multi-rank code path: 4 plain weight-gradient chunks
+rm -rf $OUT/pmcx
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmcx -o f --output-format csv -- $XCH > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmcx -o w --output-format csv -- $XCH > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/rccl -o r --output-format csv -- python bench.py --force-exchange --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-other-configs > $OUT/rccl_stdout.log 2>&1
 python - <<'PY'
 import csv, collections, json, glob, os
@@ -75,6 +79,24 @@ json.dump({"gemm_source_sha16": src_hash, "unit": "KB per launch (rocprofv3 FETC
           open(OUT + "/%s_pmc_traffic.json" % R, "w"), indent=1)
 for k, v in list(out.items())[:12]:
     print("%-46s launches %5d  FETCH_SIZE %12.1f KB  WRITE_SIZE %12.1f KB per launch" % (k[:46], v.get("launches", 0), v.get("FETCH_SIZE", 0), v.get("WRITE_SIZE", 0)))
+# ---- (2b) the same counters on the exchange path: fabric bytes of the PLAIN chunked weight-gradient launches that an
+# all-reduce shares the fabric with
+try:
+    resx = {}
+    for tag, cname in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(OUT + "/pmcx/%s_counter_collection.csv" % tag)):
+            if r["Counter_Name"] != cname or "wgrad" not in r["Kernel_Name"]: continue
+            k = short(r["Kernel_Name"]); agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
+        for k, (n, v) in agg.items():
+            resx.setdefault(k, {})[cname] = v / n; resx[k]["launches"] = n
+    for k, v in resx.items():
+        v["hbm_side_MB_per_launch"] = round((2.0 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024 / 1e6, 1)
+    json.dump({"unit": "KB per launch; HBM-side bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024", "command": "python bench.py --force-exchange --steps 2 --warmup 1 ...",
+               "kernels": resx}, open(OUT + "/%s_pmc_traffic_exchange.json" % R, "w"), indent=1)
+    print(json.dumps(resx, indent=1)[:1500])
+except Exception as e:
+    print("exchange traffic failed:", e)
 # ---- (3) MFMA utilisation
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for f in sorted(glob.glob(OUT + "/pmc/m*_counter_collection.csv")):

@@ -92,6 +92,8 @@ SIGNATURES = {
     "vptr_norm_act_fwd": [P, P, P, P, P, P, I, I, I, I, I, F, P, U, P, I, I, P, I, P, F, P],
     "vptr_norm_act_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P, U, P, I, I, I, P],
     "vptr_norm_act_bwd_deferred": [P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, U, P, I, I, I, P, P],
+    "vptr_norm_act_bwd_coop_partials": [I, I, I],
+    "vptr_norm_act_bwd_coop": [P, P, P, P, P, P, P, P, I, I, I, I, F, P, U, P, I, I, I, P, P],
     "vptr_norm_act_bwd_partials": [I, I, I, I],
     "vptr_dwconv3x3_fwd": [P, P, P, P, I, I, I, I, P, P],
     "vptr_dwconv3x3_bwd": [P, P, P, P, P, P, I, I, I, I, P],

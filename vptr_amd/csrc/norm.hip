@@ -1073,6 +1073,160 @@ __global__ __launch_bounds__(256) void norm_act_bwd_frame_affine(const float* __
     unsafeAtomicAdd(db + (int64_t)e * 4 + q, ab[q] + sred[0][lane][4 + q] + sred[1][lane][4 + q] + sred[2][lane][4 + q]);
   }
 }
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6: the two phases in ONE pass over dy and x (LayerNorm((F,H,W)), deferred affine gradients).  A workgroup = 256 element quads
+// (one 64-quad range per wave) x NF frames; every thread keeps g*w and xhat of its NF frames in registers (2 NF float4), the workgroup
+// publishes its share of each frame's two sums -- the four waves' sums meet in LDS first, ONE thread per frame then adds them to the
+// frame's own 128-byte line of the workspace (sum, sum, arrival counter) -- and every wave waits until all gridDim.x workgroups of its
+// frame chunk have arrived before it computes dx from its registers: 260 MB per [10240 x 2112] call instead of 432, one launch instead
+// of three.  Round 3 built this with 528 workgroups adding to 16-frames-per-line words and measured the whole step TWICE as slow; the
+// elimination runs of round 6 (tools/dwn_probe.py) showed why -- same-line atomics serialise at the memory-side atomic unit -- and what
+// it takes: one line per frame, as few atomics per frame as the register budget allows (here 132 x 3).
+// Ordering: the two sums are added with RETURNING atomics whose results the thread waits for, then the counter is bumped with release
+// semantics; a reader that has seen the counter complete (acquire) reads the sums with device-scope loads.
+// Co-residency: the waiters of a chunk (blockIdx.y, the slow grid axis) only wait for workgroups dispatched before or together with them;
+// the launcher takes this path only when a chunk is a small fraction of what the device holds.  A bounded spin turns a scheduling surprise
+// into wrong numbers and a raised flag (sync_ws line `frames`), never into a hang.
+// sync_ws: [frames + 1][32] floats, ZERO on entry (not restored: the caller hands a fresh zeroed slice per call).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NF>
+__global__ __launch_bounds__(256) void norm_act_bwd_coop_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ w, const float* __restrict__ b,
+                                                                float* __restrict__ dx, float* __restrict__ part /* [gridDim.y][2][4 * E4] */,
+                                                                float* __restrict__ sync_ws, int E4, int F, int HW, int act, float p,
+                                                                const uint64_t* seed_dev, uint32_t site, int frames,
+                                                                const float* __restrict__ rowscale, int rs_div, int rs_mod, int p16) {
+  __shared__ float sred[NF][4][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e_raw = blockIdx.x * 256 + threadIdx.x;
+  const bool live = e_raw < E4;
+  const int e = live ? e_raw : E4 - 1;
+  const float lv = live ? 1.f : 0.f;
+  uint64_t seed = 0;
+  if (p > 0.f) seed = *seed_dev;
+  const int f0 = blockIdx.y * NF, f1 = min(frames, f0 + NF);
+  const float4 wv = reinterpret_cast<const float4*>(w)[e], bv = reinterpret_cast<const float4*>(b)[e];
+  const float ws[4] = {wv.x, wv.y, wv.z, wv.w}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
+  float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+  const int hw = (e * 4) / F;
+  float4 gw[NF], xh4[NF];
+  // every frame's loads first (NF x 2 independent 16-byte loads in flight per thread)
+#pragma unroll
+  for (int k = 0; k < NF; ++k) {
+    const int f = min(f0 + k, frames - 1);
+    gw[k] = reinterpret_cast<const float4*>(dy)[(int64_t)f * E4 + e];
+    xh4[k] = reinterpret_cast<const float4*>(x)[(int64_t)f * E4 + e];
+  }
+#pragma unroll
+  for (int k = 0; k < NF; ++k) {
+    const int f = f0 + k;
+    float t1 = 0.f, t2 = 0.f;
+    if (f < f1) {   // block-uniform
+      const float mu = mean[f], rs = rstd[f];
+      const int64_t i = ((int64_t)f * E4 + e) * 4;
+      float rsc = 1.f;
+      if (rowscale) rsc = rowscale[((f * HW + hw) / rs_div) % rs_mod];
+      const float dv[4] = {gw[k].x, gw[k].y, gw[k].z, gw[k].w}, xs[4] = {xh4[k].x, xh4[k].y, xh4[k].z, xh4[k].w};
+      float go[4], xo[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xh = (xs[q] - mu) * rs;
+        const float ds = (p > 0.f ? vptr_drop_scale(seed, site, (uint64_t)(i + q), p) : 1.f) * rsc;
+        const float g = norm_act_g(dv[q], xh, ws[q], bs[q], act, ds) * lv;
+        aw[q] += g * xh;
+        ab[q] += g;
+        go[q] = g * ws[q];
+        xo[q] = xh;
+        t1 += go[q];
+        t2 += go[q] * xh;
+      }
+      gw[k] = make_float4(go[0], go[1], go[2], go[3]);
+      xh4[k] = make_float4(xo[0], xo[1], xo[2], xo[3]);
+    }
+    t1 = wave_sum(t1);
+    t2 = wave_sum(t2);
+    if (lane == 0) { sred[k][wave][0] = t1; sred[k][wave][1] = t2; }
+  }
+  __syncthreads();
+  if (threadIdx.x < NF && f0 + (int)threadIdx.x < f1) {   // thread k publishes frame f0 + k
+    const int f = f0 + threadIdx.x, k = threadIdx.x;
+    float* line = sync_ws + (int64_t)f * 32;
+    const float r1 = __hip_atomic_fetch_add(line, (sred[k][0][0] + sred[k][1][0]) + (sred[k][2][0] + sred[k][3][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float r2 = __hip_atomic_fetch_add(line + 1, (sred[k][0][1] + sred[k][1][1]) + (sred[k][2][1] + sred[k][3][1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(r1), "v"(r2) : "memory");   // both additions have been performed (their old values are back) ...
+    __hip_atomic_fetch_add(reinterpret_cast<int*>(line + 2), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before this workgroup counts as arrived
+  }
+  // affine gradients of this frame chunk: one row pair of the partial-sum buffer (every thread owns its quad: no reduction needed)
+  if (live) {
+    float4* pw = reinterpret_cast<float4*>(part + ((int64_t)blockIdx.y * 2) * 4 * E4) + e;
+    pw[0] = make_float4(aw[0], aw[1], aw[2], aw[3]);
+    pw[E4] = make_float4(ab[0], ab[1], ab[2], ab[3]);
+  }
+  // phase 2 from registers
+  const float inv_n = 1.f / ((float)HW * (float)F);
+#pragma unroll
+  for (int k = 0; k < NF; ++k) {
+    const int f = f0 + k;
+    if (f < f1) {
+      float s1 = 0.f, s2 = 0.f;
+      if (lane == 0) {
+        const float* line = sync_ws + (int64_t)f * 32;
+        int spins = 0;
+        while (__hip_atomic_load(reinterpret_cast<const int*>(line + 2), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1 << 22)) { reinterpret_cast<int*>(sync_ws + (int64_t)frames * 32)[0] = 1; break; }   // (about a second: never in a healthy launch)
+        }
+        s1 = __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s2 = __hip_atomic_load(line + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      s1 = __shfl(s1, 0, 64) * inv_n;
+      s2 = __shfl(s2, 0, 64) * inv_n;
+      const float rs = rstd[f];
+      if (live) {
+        const float4 o = make_float4(rs * (gw[k].x - s1 - xh4[k].x * s2), rs * (gw[k].y - s1 - xh4[k].y * s2),
+                                     rs * (gw[k].z - s1 - xh4[k].z * s2), rs * (gw[k].w - s1 - xh4[k].w * s2));
+        vptr_store4_fmt(dx, ((int64_t)f * E4 + e) * 4, o, p16);
+      }
+    }
+  }
+}
+constexpr int NORM_COOP_NF = 10;
+// chunks of the one-pass launch (= rows of its partial-sum buffer); 0: this geometry / configuration takes the two-phase path
+extern "C" int vptr_norm_act_bwd_coop_partials(int rows, int F, int HW) {
+  static int on = -1, capacity = 0;
+  if (on < 0) {
+    const char* e = getenv("VPTR_NORM_COOP");
+    on = (e && atoi(e) == 0) ? 0 : 1;
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (on && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, norm_act_bwd_coop_kernel<NORM_COOP_NF>, 256, 0) == hipSuccess)
+      capacity = per_cu * prop.multiProcessorCount;
+    if (capacity <= 0) on = 0;
+  }
+  if (!on || g_vptr_deterministic || HW < 1 || rows % HW != 0 || F % 4 != 0) return 0;
+  const int frames = rows / HW;
+  const int wgs = cdiv(HW * (F / 4), 256);   // mutually waiting workgroups of one chunk: at most a quarter of what the device holds at once
+  if (frames < 16 || wgs * 4 > capacity) return 0;
+  return cdiv(frames, NORM_COOP_NF);
+}
+extern "C" int vptr_norm_act_bwd_coop(const float* dy, const float* x, const float* mean, const float* rstd, const float* w, const float* b,
+                                      float* dx, float* sync_ws, int rows, int F, int HW, int act, float dropout_p, const uint64_t* seed_dev,
+                                      uint32_t site, const float* rowscale, int rs_div, int rs_mod, int p16, float* partials, vptr_stream_t stream) {
+  const int chunks = vptr_norm_act_bwd_coop_partials(rows, F, HW);
+  VPTR_CHECK(chunks > 0 && dy && x && mean && rstd && w && b && dx && sync_ws && partials, "norm_act_bwd_coop: no one-pass variant for rows %d, F %d, HW %d", rows, F, HW);
+  VPTR_CHECK(((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(w) |
+               reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(partials)) & 15) == 0 && (reinterpret_cast<uintptr_t>(sync_ws) & 127) == 0,
+             "norm_act_bwd_coop: operands must be 16-byte aligned, sync_ws 128-byte aligned");
+  if (p16) VPTR_CHECK(F % 16 == 0 && (reinterpret_cast<uintptr_t>(dx) & 63) == 0, "norm_act_bwd_coop: a P16 dx needs F %% 16 == 0 and a 64-byte aligned dx");
+  if (dropout_p > 0.f) VPTR_CHECK(seed_dev && dropout_p < 1.f, "norm_act_bwd_coop: dropout needs seed_dev");
+  const int E4 = HW * (F / 4);
+  norm_act_bwd_coop_kernel<NORM_COOP_NF><<<dim3(cdiv(E4, 256), chunks), 256, 0, (hipStream_t)stream>>>(
+      dy, x, mean, rstd, w, b, dx, partials, sync_ws, E4, F, HW, act, dropout_p, seed_dev, site, rows / HW, rowscale, rs_div, rs_mod, p16);
+  VPTR_LAUNCH_CHECK();
+  return 0;
+}
 // phase 2: dx = rstd * (g*w - S1/n - xhat*S2/n)
 template <bool PER_COL>
 __global__ __launch_bounds__(256) void norm_act_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,

@@ -22,6 +22,16 @@ def _norm_act_backward(dy, x, w, b, mean, rstd, rowscale, HW, per_col, act, cons
     dw, db = (sw, sb) if in_slab else (_bw_zeros(w.shape, w.device), _bw_zeros(b.shape, b.device))
     frames = rows // HW
     scratch = torch.empty((max(2 * F, 2 * frames * (1 + 4 * ((HW * F // 4 + 255) // 256))),), device=x.device, dtype=torch.float32)
+    ncoop = lib.vptr_norm_act_bwd_coop_partials(rows, F, HW) if (in_slab and config.defer_ln_param_grads and not per_col and config.norm_coop) else 0
+    if ncoop > 0:
+        # LayerNorm((F,H,W)): both phases in ONE cooperative pass over (dy, x) -- the workgroups of a 10-frame chunk exchange the frames' sums through
+        # a zeroed workspace line per frame (csrc/norm.hip norm_act_bwd_coop_kernel); affine gradients as per-chunk partial sums like below
+        part = torch.empty((ncoop, 2, HW * F), device=x.device, dtype=torch.float32)
+        ws = _bw_zeros(((frames + 1) * 32,), x.device)
+        check(lib.vptr_norm_act_bwd_coop(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(b), ptr(dx), ptr(ws), rows, F, HW, act, p, ptr(seed), site,
+                                         ptr(rowscale), rs_div, rs_mod, int(dx_p16), ptr(part), stream()), "vptr_norm_act_bwd_coop")
+        defer_partial_reduce(part, sw, sb, ncoop, HW * F)
+        return dx, None, None
     nparts = lib.vptr_norm_act_bwd_partials(rows, F, HW, int(per_col)) if (in_slab and config.defer_ln_param_grads) else 0
     if nparts > 0:
         # affine gradients with an in-place destination: per-chunk partial sums, added by the backward pass's one reduction launch
