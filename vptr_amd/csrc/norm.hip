@@ -1082,8 +1082,8 @@ __global__ __launch_bounds__(256) void norm_act_bwd_frame_affine(const float* __
 // of three.  Round 3 built this with 528 workgroups adding to 16-frames-per-line words and measured the whole step TWICE as slow; the
 // elimination runs of round 6 (tools/dwn_probe.py) showed why -- same-line atomics serialise at the memory-side atomic unit -- and what
 // it takes: one line per frame, as few atomics per frame as the register budget allows (here 132 x 3).
-// Ordering: the two sums are added with RETURNING atomics whose results the thread waits for, then the counter is bumped with release
-// semantics; a reader that has seen the counter complete (acquire) reads the sums with device-scope loads.
+// Ordering: the two sums are added with RETURNING atomics whose results the thread waits for (they are performed at the memory side by
+// then), only then the counter is bumped; a reader that has seen the counter complete reads the sums with device-scope atomic loads.
 // Co-residency: the waiters of a chunk (blockIdx.y, the slow grid axis) only wait for workgroups dispatched before or together with them;
 // the launcher takes this path only when a chunk is a small fraction of what the device holds.  A bounded spin turns a scheduling surprise
 // into wrong numbers and a raised flag (sync_ws line `frames`), never into a hang.
@@ -1155,7 +1155,10 @@ __global__ __launch_bounds__(256) void norm_act_bwd_coop_kernel(const float* __r
     const float r1 = __hip_atomic_fetch_add(line, (sred[k][0][0] + sred[k][1][0]) + (sred[k][2][0] + sred[k][3][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float r2 = __hip_atomic_fetch_add(line + 1, (sred[k][0][1] + sred[k][1][1]) + (sred[k][2][1] + sred[k][3][1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("" ::"v"(r1), "v"(r2) : "memory");   // both additions have been performed (their old values are back) ...
-    __hip_atomic_fetch_add(reinterpret_cast<int*>(line + 2), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before this workgroup counts as arrived
+    // ... before this workgroup counts as arrived.  RELAXED on purpose: device-scope atomics are performed at the memory side, which is all the
+    // ordering this exchange needs; a release / acquire pair at agent scope writes back / invalidates the XCD's whole L2 on gfx950 (the L2s of
+    // the eight XCDs are not coherent with each other) -- measured 728 us per launch instead of ~50.
+    __hip_atomic_fetch_add(reinterpret_cast<int*>(line + 2), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // affine gradients of this frame chunk: one row pair of the partial-sum buffer (every thread owns its quad: no reduction needed)
   if (live) {
@@ -1173,10 +1176,11 @@ __global__ __launch_bounds__(256) void norm_act_bwd_coop_kernel(const float* __r
       if (lane == 0) {
         const float* line = sync_ws + (int64_t)f * 32;
         int spins = 0;
-        while (__hip_atomic_load(reinterpret_cast<const int*>(line + 2), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x) {
+        while (__hip_atomic_load(reinterpret_cast<const int*>(line + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x) {
           __builtin_amdgcn_s_sleep(1);
           if (++spins > (1 << 22)) { reinterpret_cast<int*>(sync_ws + (int64_t)frames * 32)[0] = 1; break; }   // (about a second: never in a healthy launch)
         }
+        asm volatile("" ::: "memory");   // the sums are requested only after the counter was seen complete
         s1 = __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s2 = __hip_atomic_load(line + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
