@@ -920,6 +920,9 @@ def main():
             "config": {"workload": workload, "name": args.config, "baseline_config": job["baseline_config"],
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch, "frames_per_clip": frames, "parallelism": "dp%d" % world,
                        "launch": graph_note, "dec_weight_grads": True,
+                       # the frozen encoder's 18 ResnetBlock convolutions: Winograd F(4x4, 3x3) executes 25.7 of their 102.8 algorithmic GF each;
+                       # alg_tflop_per_step_per_gpu below stays the reference's algorithmic count, roofline.all_gemm counts what is executed
+                       "frozen_encoder_convs": "winograd F(4x4,3x3), 36 strided-batch P16 products per convolution" if ops.config.winograd else "direct implicit GEMM",
                        "alg_tflop_per_step_per_gpu": round(job["gf"] * args.batch / 1e3, 2),
                        "step_tflops_per_gpu": round(job["gf"] * args.batch / 1e3 / (ms * 1e-3), 1)},
             "per_rank_ms_per_step": {"min": round(min(per_rank) / args.steps * 1e3, 3), "max": round(max(per_rank) / args.steps * 1e3, 3)},

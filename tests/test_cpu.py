@@ -603,3 +603,21 @@ def test_analytic_zero_class_is_an_allow_list():
         gn = json.loads(str(z["grad_norms"]))
         classed += sum(analytic_zero(gn[k], gn.values(), k) for k in gn)   # asserts inside on a name outside the list
     assert classed > 0
+
+
+def test_winograd_filter_transform_matches_direct_convolution():
+    """host side of the frozen encoder's Winograd path (vptr_amd/ops/conv.py::_WINO_G, the G of F(4x4, 3x3)) against the kernels' B^T and A^T
+    (csrc/winograd.hip wino_bt6 / wino_at4, restated here): A^T [(G g G^T) . (B^T d B)] A == the direct 3 x 3 convolution of a 6 x 6 patch"""
+    from vptr_amd.ops.conv import _WINO_G
+    G = torch.tensor(_WINO_G, dtype=torch.float64)
+    BT = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                       [0, 4, 0, -5, 0, 1]], dtype=torch.float64)
+    AT = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float64)
+    g = torch.randn(5, 3, 3, 3, dtype=torch.float64)          # [Cout, Cin, 3, 3]
+    d = torch.randn(1, 3, 6, 6, dtype=torch.float64)
+    U = torch.einsum("ia,kcab,jb->ijkc", G, g, G)             # as ops.wino_filter
+    V = torch.einsum("ij,cjk,lk->ilc", BT, d[0], BT)          # B^T d B per channel
+    M = torch.einsum("ijkc,ijc->ijk", U, V)
+    Y = torch.einsum("ai,ijk,bj->kab", AT, M, AT)             # [Cout, 4, 4]
+    ref = torch.nn.functional.conv2d(d, g)[0]
+    assert float((Y - ref).abs().max()) < 1e-12
