@@ -941,9 +941,14 @@ def main():
                 # the WHOLE step against the same roof: every algorithmic GEMM / convolution FLOP of one step over the timed step time
                 # (memory-bound kernels, launch gaps and the optimizer all count against it)
                 step_t = res["roofline"]["all_gemm"]["alg_gflop_per_step"] / 1e3 / (ms * 1e-3)
+                ref_t = job["gf"] * args.batch / 1e3 / (ms * 1e-3)   # the reference's algorithmic FLOPs (direct convolutions) over the same time
                 res["roofline"]["step"] = {"achieved": round(step_t, 1), "unit": "TFLOP/s", "frac": round(step_t / MFMA_PEAK_TFLOPS, 4),
                                            "frac_of_3pass_ceiling": round(step_t / (MFMA_PEAK_TFLOPS / 3.0), 4),
-                                           "what": "algorithmic GEMM + convolution FLOPs of one step (event-timed launches' 2MNK sum) / ms_per_step"}
+                                           "achieved_reference_flops": round(ref_t, 1), "frac_reference_flops": round(ref_t / MFMA_PEAK_TFLOPS, 4),
+                                           "what": "EXECUTED GEMM + convolution FLOPs of one step (event-timed launches' 2MNK sum; the Winograd encoder executes "
+                                                   "25.7 of the 102.8 algorithmic GF of each ResnetBlock convolution) / ms_per_step; *_reference_flops: the "
+                                                   "reference's algorithmic count (config.alg_tflop_per_step_per_gpu) over the same time -- the figure that is "
+                                                   "comparable across rounds"}
             except Exception as e:  # noqa
                 res["roofline"] = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
                                    "traffic": None, "error": str(e)[:200]}
