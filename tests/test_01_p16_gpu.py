@@ -260,7 +260,12 @@ def test_norm_dwconv_fused_matches_chain_and_fp64(ops, dev, geo):
     # F % 64 == 0 and H * W <= 256: the LDS-slab kernel (dwconv_norm_lds_kernel); F = 96 on 16 x 16 maps: the register-walk kernel
     frames, H, W, C, F_ = geo
     HW, rows = H * W, frames * H * W
-    assert ops.norm_dwconv_ok(rows, HW, F_, H, W)
+    assert ops.norm_dwconv_ok(rows, HW, F_, H, W) == (HW <= 64)    # default: only where the fused launch pays (8 x 8 maps, cache-resident tensors)
+    ops.config.fused_norm_dwconv_mode = 2
+    try:
+        assert ops.norm_dwconv_ok(rows, HW, F_, H, W)               # ... but valid on the larger maps too
+    finally:
+        ops.config.fused_norm_dwconv_mode = 1
     x0, W1, b1 = rn((rows, C), 1).to(dev), rn((F_, C), 2, C ** -0.5).to(dev), rn((F_,), 3).to(dev)
     aw, ab = (rn((HW, F_), 5).abs() + 0.5).to(dev), rn((HW, F_), 6, 0.3).to(dev)
     dwt, dbias = rn((F_, 1, 3, 3), 7, 0.3).to(dev), rn((F_,), 8, 0.1).to(dev)

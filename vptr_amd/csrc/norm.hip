@@ -1354,17 +1354,22 @@ __global__ __launch_bounds__(256) void norm_act_bwd_dx4_pos_kernel(const float4*
   }
 }
 // phase 1c: s1[f], s2[f] = sum of the per-wave partials of phase 1
-__global__ __launch_bounds__(64) void norm_act_bwd_frame_final(const float* __restrict__ part, float* __restrict__ fsum, int nparts,
-                                                              int frames) {
+// (256 threads per frame since round 6: one wave walked 33 dependent strides per frame on 16 x 16 maps -- 14.5 us for 170 KB)
+__global__ __launch_bounds__(256) void norm_act_bwd_frame_final(const float* __restrict__ part, float* __restrict__ fsum, int nparts,
+                                                               int frames) {
+  __shared__ float red[8];
   const int f = blockIdx.x;
   float t1 = 0.f, t2 = 0.f;
-  for (int q = threadIdx.x; q < nparts; q += 64) {
-    t1 += part[((int64_t)q * frames + f) * 2];
-    t2 += part[((int64_t)q * frames + f) * 2 + 1];
+  for (int q = threadIdx.x; q < nparts; q += 256) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((int64_t)q * frames + f) * 2);
+    t1 += v.x;
+    t2 += v.y;
   }
   t1 = wave_sum(t1);
   t2 = wave_sum(t2);
-  if (threadIdx.x == 0) { fsum[f] = t1; fsum[frames + f] = t2; }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = t1; red[4 + (threadIdx.x >> 6)] = t2; }
+  __syncthreads();
+  if (threadIdx.x == 0) { fsum[f] = (red[0] + red[1]) + (red[2] + red[3]); fsum[frames + f] = (red[4] + red[5]) + (red[6] + red[7]); }
 }
 __global__ void accum2_kernel(const float* __restrict__ acc, float* __restrict__ dw, float* __restrict__ db, int F) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -1440,7 +1445,7 @@ static int norm_act_bwd_impl(const float* dy, const float* x, const float* mean,
     norm_act_bwd_frame_affine<<<dim3(nparts, cdiv(frames, fpb)), 256, 0, st>>>(dy, x, mean, rstd, w, b, dw, db, part, E4, F, HW, act,
                                                                                      dropout_p, seed_dev, site, frames, fpb, rowscale,
                                                                                      rs_div, rs_mod, partials);
-    norm_act_bwd_frame_final<<<frames, 64, 0, st>>>(part, scratch, nparts, frames);
+    norm_act_bwd_frame_final<<<frames, 256, 0, st>>>(part, scratch, nparts, frames);
     if (vec4 && norm_pos_mode() && frames >= 16 && (int64_t)rows * (F / 4) >= (1 << 18))
       norm_act_bwd_dx4_pos_kernel<<<dim3(cdiv(HW * (F / 4), 256), (frames / 4 < 1 ? 1 : (frames / 4 > 65535 ? 65535 : frames / 4))), 256, 0, st>>>(
           reinterpret_cast<const float4*>(dy), reinterpret_cast<const float4*>(x), mean, rstd, w, b, scratch, dx, frames, F / 4, HW, act, dropout_p,
@@ -1915,14 +1920,15 @@ extern "C" int vptr_dwconv3x3_norm_fwd(const float* x, const float* raw_stats, c
 // dw9[tap, c] += sum_{f,y,x} dy[f,y,x,c] * x[f,y+ky-1,x+kx-1,c];  db[c] += sum dy.
 // Block = 32 channel quads x 8 x-lanes over a chunk of frames; every thread walks its columns with the same rolling window
 // (1 + 3 float4 loads per pixel), the 8 x-lanes are summed through LDS and each block issues 40 atomics per channel quad.
-#define DWB_C4 32
-#define DWB_XL 8
-template <bool PAIR, bool XH = false>  // PAIR (W even): lane = (x pair, frame parity), 4 x + 2 dy loads per two pixels instead of 6 + 2; XH: x is the fp16 side copy of dwconv_norm_fwd3_kernel
+// CQ channel quads x (256 / CQ) x-lanes per block: 32 x 8 (rounds 1 - 5) or 16 x 16 (round 6: twice the blocks for the same atomics -- the
+// K64 step's launch is 340 blocks of the 32-quad form on 256 CUs, KTH 128 x 128's 170: latency-bound, 3.6x the time for 2x the data)
+template <bool PAIR, bool XH = false, int CQ = 32>  // PAIR (W even): lane = (x pair, frame parity), 4 x + 2 dy loads per two pixels instead of 6 + 2; XH: x is the fp16 side copy of dwconv_norm_fwd3_kernel
 __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restrict__ dy_, const void* __restrict__ x_,
                                                            float* __restrict__ dw9, float* __restrict__ db, int frames, int H,
                                                            int W, int F4, int fpb) {
   typedef typename std::conditional<XH, half4_t, float4>::type XT;
   static_assert(PAIR || !XH, "the fp16 operand comes with the paired form");
+  constexpr int DWB_C4 = CQ, DWB_XL = 256 / CQ;
   __shared__ float red[DWB_XL * DWB_C4 * 41];
   const int cl = threadIdx.x % DWB_C4, xl = threadIdx.x / DWB_C4;
   const int c4 = blockIdx.x * DWB_C4 + cl;
@@ -1935,7 +1941,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restri
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (PAIR) {
-    for (int64_t f = f0 + (xl >> 2); f < f1; f += 2)
+    for (int64_t f = f0 + (xl >> 2); f < f1; f += DWB_XL / 4)
       for (int xw0 = (xl & 3) * 2; xw0 < W; xw0 += 8) {
         DwRow2 r0 = dw_load_row2(x, f * H, -1, H, xw0, W, F4, c4c), r1 = dw_load_row2(x, f * H, 0, H, xw0, W, F4, c4c);
         for (int yh = 0; yh < H; ++yh) {
@@ -2040,12 +2046,20 @@ static int dwconv3x3_bwd_impl(const float* dy, const void* x, int x_half, const 
   }
   if (dw9 && db) {
     const int fpb = g_vptr_deterministic ? frames : (frames >= 64 ? 8 : 1);   // deterministic: one adder per tap and channel
-    if (x_half)
-      dwconv_bwd_w_kernel<true, true><<<dim3(cdiv(F / 4, DWB_C4), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
+    static int cq16 = -1;
+    if (cq16 < 0) { const char* e = getenv("VPTR_DWB_CQ"); cq16 = (e && atoi(e) == 32) ? 0 : 1; }
+    // 16-quad blocks (paired forms) while the 32-quad grid would leave CUs idle
+    const bool narrow = cq16 && !g_vptr_deterministic && fpb >= 8 && cdiv(F / 4, 32) * cdiv(frames, fpb) < 1024;
+    if (x_half && narrow)
+      dwconv_bwd_w_kernel<true, true, 16><<<dim3(cdiv(F / 4, 16), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
+    else if (x_half)
+      dwconv_bwd_w_kernel<true, true><<<dim3(cdiv(F / 4, 32), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
+    else if (W % 2 == 0 && narrow)
+      dwconv_bwd_w_kernel<true, false, 16><<<dim3(cdiv(F / 4, 16), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
     else if (W % 2 == 0)
-      dwconv_bwd_w_kernel<true><<<dim3(cdiv(F / 4, DWB_C4), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
+      dwconv_bwd_w_kernel<true><<<dim3(cdiv(F / 4, 32), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
     else
-      dwconv_bwd_w_kernel<false><<<dim3(cdiv(F / 4, DWB_C4), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
+      dwconv_bwd_w_kernel<false><<<dim3(cdiv(F / 4, 32), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
   }
   VPTR_LAUNCH_CHECK();
   return 0;

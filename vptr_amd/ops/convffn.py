@@ -168,6 +168,11 @@ def norm_dwconv_ok(rows, HW, F, H, W):
     """can the conv-FFN's first normalisation + activation run inside the depthwise kernel's load path? (LayerNorm((F,H,W)) statistics
     delivered by fc1's epilogue, x pairs of a channel quad in adjacent lanes, whole waves inside one frame)"""
     W2 = W // 2
+    # where it pays (profiles/r06_cfg4 / cfg5_kernel_stats.md): maps of at most 64 pixels (16 KB LDS slabs: four workgroups per CU) and hidden tensors
+    # that stay in the 256 MB Infinity Cache -- on 16 x 16 maps (KTH 128 x 128: 164 us against 48 + 48) and on 251 MB tensors (BAIR, 29 frames per
+    # clip: 175 against 65 + 86) the two-launch form is faster; VPTR_FUSED_NORM_DW=2 forces the fused launch wherever it is valid
+    if config.fused_norm_dwconv_mode != 2 and (H * W > 64 or rows * F * 4 > (128 << 20)):
+        return False
     return (config.fused_norm_dwconv and not config.deterministic and frame_stats_ok(rows, HW, F, W) and W % 2 == 0 and W2 >= 1 and 16 % W2 == 0
             and H * W == HW)
 

@@ -51,6 +51,7 @@ class _Config:
     winograd = os.environ.get("VPTR_ENC_WINOGRAD", "1") != "0"   # frozen 3x3 stride-1 convolutions of VPTREnc as Winograd F(4x4, 3x3) (round 6)
     norm_coop = os.environ.get("VPTR_NORM_COOP", "0") == "1"   # LayerNorm((F,H,W)) backward as one cooperative pass (round 6: correct, 133 vs 69 us per call -- off)
     winograd_fuse = os.environ.get("VPTR_WINO_FUSE", "1") != "0"   # output transform + next input transform in one pass through LDS
+    fused_norm_dwconv_mode = int(os.environ.get("VPTR_FUSED_NORM_DW", "1") or 1)   # 0 off, 1 where it pays (ops.norm_dwconv_ok), 2 wherever valid
     fused_norm_dwconv = os.environ.get("VPTR_FUSED_NORM_DW", "1") != "0"   # conv-FFN norm1 + act1 inside the depthwise kernel's load path (round 6)
     loose_grad_arena = os.environ.get("VPTR_GRAD_ARENA", "1") != "0"   # models without a trainer: `.grad` tensors are views of one buffer per model
     deterministic = False   # ops.set_deterministic / VPTR_DETERMINISTIC=1
