@@ -2045,12 +2045,16 @@ static int dwconv3x3_bwd_impl(const float* dy, const void* x, int x_half, const 
       dwconv_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(dy, w9, nullptr, dx, frames, H, W, F / 4, 1);
   }
   if (dw9 && db) {
-    const int fpb = g_vptr_deterministic ? frames : (frames >= 64 ? 8 : 1);   // deterministic: one adder per tap and channel
-    static int cq16 = -1;
-    if (cq16 < 0) { const char* e = getenv("VPTR_DWB_CQ"); cq16 = (e && atoi(e) == 32) ? 0 : 1; }
+    static int fpb_env = -1;
+    if (fpb_env < 0) { const char* e = getenv("VPTR_DWB_FPB"); fpb_env = (e && atoi(e) > 0) ? atoi(e) : 8; }
+    const int fpb = g_vptr_deterministic ? frames : (frames >= 64 ? fpb_env : 1);   // deterministic: one adder per tap and channel
+    static int cq16 = -1, cq8 = 0;
+    if (cq16 < 0) { const char* e = getenv("VPTR_DWB_CQ"); cq16 = (e && atoi(e) == 32) ? 0 : 1; cq8 = (e && atoi(e) == 8) ? 1 : 0; }
     // 16-quad blocks (paired forms) while the 32-quad grid would leave CUs idle
-    const bool narrow = cq16 && !g_vptr_deterministic && fpb >= 8 && cdiv(F / 4, 32) * cdiv(frames, fpb) < 1024;
-    if (x_half && narrow)
+    const bool narrow = cq16 && !g_vptr_deterministic && fpb >= 4 && cdiv(F / 4, 32) * cdiv(frames, fpb) < 1024;
+    if (x_half && narrow && cq8)   // experiment (VPTR_DWB_CQ=8): 8 quads x 32 lanes
+      dwconv_bwd_w_kernel<true, true, 8><<<dim3(cdiv(F / 4, 8), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
+    else if (x_half && narrow)
       dwconv_bwd_w_kernel<true, true, 16><<<dim3(cdiv(F / 4, 16), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
     else if (x_half)
       dwconv_bwd_w_kernel<true, true><<<dim3(cdiv(F / 4, 32), cdiv(frames, fpb)), 256, 0, st>>>(dy, x, dw9, db, frames, H, W, F / 4, fpb);
