@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_fused_kernel(const float* __re
 // 140 VGPRs, i.e. 1.25 rounds)
 static int ln_bwd_rpb() {
   static int v = 0;
-  if (!v) { const char* e = getenv("VPTR_LN_BWD_RPB"); v = (e && atoi(e) == 32) ? 32 : 16; }
+  if (!v) { const char* e = getenv("VPTR_LN_BWD_RPB"); v = (e && atoi(e) == 32) ? 32 : ((e && atoi(e) == 8) ? 8 : 16); }
   return v;
 }
 // rows of partial sums a deferred backward call writes (0: this geometry has no deferred variant)
@@ -323,7 +323,7 @@ static int layernorm_bwd_impl(const float* dy, const float* dy2, const float* x,
     // deferred parameter gradients: no atomics, so more and shorter workgroups (32 rows each instead of 64) cost nothing
     VPTR_CHECK(dx && vptr_layernorm_bwd_partials(rows, C) > 0, "layernorm_bwd: no deferred variant for rows %d, C %d", rows, C);
     if (C <= 256) ln_bwd_fused_kernel<1, 4><<<cdiv(rows, 32), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, nullptr, nullptr, rows, C, 32, dx_add, partials);
-    else if (C <= 768 && !g_vptr_deterministic && ln_bwd_rpb() == 16) ln_bwd_fused_kernel<3, 4><<<cdiv(rows, 16), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, nullptr, nullptr, rows, C, 16, dx_add, partials);
+    else if (C <= 768 && !g_vptr_deterministic && ln_bwd_rpb() <= 16) ln_bwd_fused_kernel<3, 4><<<cdiv(rows, ln_bwd_rpb()), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, nullptr, nullptr, rows, C, ln_bwd_rpb(), dx_add, partials);
     else if (C <= 768) ln_bwd_fused_kernel<3, 8><<<cdiv(rows, 32), 512, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, nullptr, nullptr, rows, C, 32, dx_add, partials);
     else ln_bwd_fused_kernel<4, 4><<<cdiv(rows, 32), 256, 0, st>>>(dy, dy2, x, gamma, mean, rstd, dx, nullptr, nullptr, rows, C, 32, dx_add, partials);
     VPTR_LAUNCH_CHECK();
