@@ -38,6 +38,14 @@ def _check(d, per_gpu_batch, frames):
     assert c["launched_by"].startswith("bench.py self-launch")
     assert c["allreduce_bytes_per_step"] > 0 and c["allreduce_calls_per_step"] >= 1
     assert c["exposed_comm_ms_per_step"]["max"] >= 0.0
+    # round 6: the tuning table of the first real multi-GPU run -- per rank, chunk-end and all-reduce-done times of one untimed step
+    tl = c["exchange_timeline"]
+    assert "error" not in tl, tl
+    assert [t["rank"] for t in tl["per_rank"]] == [0, 1] and c["dp_chunks"] == 4
+    for t in tl["per_rank"]:
+        assert len(t["chunk_end_ms"]) >= 1 and len(t["allreduce_done_ms"]) == len(t["allreduce_bytes"]) >= 1
+        assert sum(t["allreduce_bytes"]) == c["allreduce_bytes_per_step"]
+        assert all(b >= a for a, b in zip(t["allreduce_done_ms"], t["allreduce_done_ms"][1:]))
     pr = d["per_rank_ms_per_step"]
     assert 0 < pr["min"] <= pr["max"] <= d["ms_per_step"] * 1.05
     assert abs(d["value"] - 2 * per_gpu_batch * frames / d["ms_per_step"] * 1e3) <= 1e-3 * d["value"] + 0.5
