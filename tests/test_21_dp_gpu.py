@@ -43,8 +43,6 @@ def _dead_worker_tails(port, world, procs):
 def _worker(rank, world, port, q, G=4, full=True):
     fd = os.open(_stderr_path(port, rank), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)   # this rank's stderr (runtime aborts included) to a file
     os.dup2(fd, 2)
-    if world <= 2:
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")   # (the same precaution for three processes on one GPU, see below)
     if world > 2:
         # eight processes on ONE GPU oversubscribe its hardware queues; the scheduler then time-slices them with wave save / restore, under which
         # a queue intermittently aborts with HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION (4 of 8 runs, profiles/r06_dp8_repeat.log) -- an artefact of

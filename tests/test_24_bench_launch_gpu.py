@@ -15,9 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(extra, timeout=900):
-    # GPU_MAX_HW_QUEUES: several processes on ONE GPU oversubscribe its hardware queues and the runtime then time-slices them, under which a
-    # queue can abort (tests/test_21_dp_gpu.py::_worker); two queues per rank keep three processes under the limit
-    env = dict(os.environ, VPTR_BENCH_SHARE_GPU="1", VPTR_BENCH_BACKEND="gloo", GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "2"))
+    env = dict(os.environ, VPTR_BENCH_SHARE_GPU="1", VPTR_BENCH_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
