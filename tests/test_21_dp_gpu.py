@@ -188,7 +188,7 @@ def test_dp_eight_ranks_on_one_gpu():
             p.start()
         import queue
         try:
-            res = sorted(collect(q, procs, world, 420), key=lambda r: r["rank"])    # (a healthy run takes 25 s)
+            res = sorted(collect(q, procs, world, 180), key=lambda r: r["rank"])    # (a healthy run takes 25 s)
         except (RuntimeError, queue.Empty) as e:
             for p in procs:
                 p.join(5)
@@ -198,7 +198,7 @@ def test_dp_eight_ranks_on_one_gpu():
             # the runtime killed a queue of a time-sliced process, or the ranks that lost a peer that way never came back: not a statement about
             # the exchange path (the 2-rank test above drives the same code without sharing queues)
             if "HSA_STATUS_ERROR" in tails or isinstance(e, queue.Empty):
-                tails = tails or "no report within 420 s (workers killed)"
+                tails = tails or "no report within 180 s (workers killed)"
                 print("attempt %d: %s" % (attempt, tails[-600:]))
                 res = None
                 continue

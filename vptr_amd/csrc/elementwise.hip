@@ -292,13 +292,31 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
   const float step_size = lr / bc1;
   const float inv_sqrt_bc2 = rsqrtf(bc2);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float gi = g[i] * coef;
-    float pi = p[i] * (1.f - lr * wd);
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  auto upd = [&](const float graw, float& pi, float& mi, float& vi) {
+    const float gi = graw * coef;
+    pi = pi * (1.f - lr * wd);
+    mi = b1 * mi + (1.f - b1) * gi;
+    vi = b2 * vi + (1.f - b2) * gi * gi;
     const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
     pi -= step_size * mi / denom;
+  };
+  // 16-byte accesses (round 6: the scalar form issued seven 4-byte memory instructions per element -- 4.8 TB/s on a 3.3 GB stream); same arithmetic
+  // per element, so results are bit-identical.  n4 = 0 when a pointer is not 16-byte aligned.
+  const int64_t n4 = (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) ? n / 4 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+    float4 p4 = reinterpret_cast<float4*>(p)[i], m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
+    upd(g4.x, p4.x, m4.x, v4.x);
+    upd(g4.y, p4.y, m4.y, v4.y);
+    upd(g4.z, p4.z, m4.z, v4.z);
+    upd(g4.w, p4.w, m4.w, v4.w);
+    reinterpret_cast<float4*>(p)[i] = p4;
+    reinterpret_cast<float4*>(m)[i] = m4;
+    reinterpret_cast<float4*>(v)[i] = v4;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    upd(g[i], pi, mi, vi);
     p[i] = pi; m[i] = mi; v[i] = vi;
   }
 }
@@ -306,7 +324,7 @@ extern "C" int vptr_adamw(float* p, const float* g, float* m, float* v, int64_t 
                           float weight_decay, const float* step_dev, const float* sumsq_dev, float max_norm, float grad_scale,
                           vptr_stream_t stream) {
   VPTR_CHECK(n > 0 && p && g && m && v && step_dev, "adamw: bad arguments");
-  const int blocks = (int)hmin64((n + 255) / 256, 4096);
+  const int blocks = (int)hmin64((n / 4 + 255) / 256 + 1, 4096);
   adamw_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step_dev, sumsq_dev,
                                                        max_norm, grad_scale);
   VPTR_LAUNCH_CHECK();
