@@ -704,6 +704,9 @@ def main():
         self_launch(args.gpus, sys.argv[1:])       # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("VPTR_BENCH_HANG_DUMP_S"):   # diagnostics: every thread's stack to stderr after that many seconds (a hung rank says where)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["VPTR_BENCH_HANG_DUMP_S"]), exit=False)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:   # in either direction: never report a job of a different size than the one asked for
         raise SystemExit("bench.py --gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
